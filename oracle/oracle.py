@@ -1,0 +1,179 @@
+"""ctypes front-end of the CPU oracle (oracle/bnn_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under bnn_chaos_model_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+
+class OrcArch(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("hidden", C.c_int32), ("latent", C.c_int32), ("T", C.c_int32),
+                ("zero_mask", C.c_uint64), ("lowest", C.c_double)]
+
+
+class OrcSchedule(C.Structure):
+    _fields_ = [("order", C.POINTER(C.c_int32) * 6), ("order_len", C.c_int32 * 6), ("pool_parts", C.c_int32)]
+
+
+# v50 flags: fix_megno2 -> {7}; !include_mmr -> {3,6}; !include_nan -> {38,39,40};
+# !include_eplusminus -> {1,2,4,5}
+def zero_mask_from_flags(fix_megno=False, fix_megno2=True, include_mmr=False, include_nan=False,
+                         include_eplusminus=False):
+    cols = []
+    if fix_megno or fix_megno2:
+        cols += [7]
+    if not include_mmr:
+        cols += [3, 6]
+    if not include_nan:
+        cols += [38, 39, 40]
+    if not include_eplusminus:
+        cols += [1, 2, 4, 5]
+    m = 0
+    for c in cols:
+        m |= 1 << c
+    return m
+
+
+def build(force=False):
+    """Compile the oracle with gcc (a few seconds)."""
+    so = os.path.join(_BUILD, "libbnn_oracle.so")
+    src = os.path.join(_HERE, "bnn_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def _cpu_has_avx2_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return "avx2" in fl and "fma" in fl
+    except OSError:
+        pass
+    return False
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        name = "libbnn_oracle_avx2.so" if _cpu_has_avx2_fma() else "libbnn_oracle.so"
+        _lib = C.CDLL(os.path.join(_BUILD, name))
+        for pfx in ("orc32_", "orc64_"):
+            getattr(_lib, pfx + "param_count").restype = C.c_int
+            getattr(_lib, pfx + "swag_draw").restype = C.c_int
+            getattr(_lib, pfx + "forward").restype = C.c_int
+            getattr(_lib, pfx + "multiswag").restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def make_arch(T=100, zero_mask=None, lowest=0.5, n_features=41, hidden=40, latent=20):
+    if zero_mask is None:
+        zero_mask = zero_mask_from_flags()
+    return OrcArch(n_features, hidden, latent, T, zero_mask, lowest)
+
+
+def make_schedule(orders=None, pool_parts=1):
+    """orders: list of 6 int sequences (or None) -- see orc_schedule in bnn_oracle.c."""
+    s = OrcSchedule()
+    keep = []
+    for l in range(6):
+        o = None if orders is None else orders[l]
+        if o is None:
+            s.order[l] = C.POINTER(C.c_int32)()
+            s.order_len[l] = 0
+        else:
+            a = np.ascontiguousarray(o, dtype=np.int32)
+            keep.append(a)
+            s.order[l] = a.ctypes.data_as(C.POINTER(C.c_int32))
+            s.order_len[l] = len(a)
+    s.pool_parts = pool_parts
+    s._keep = keep
+    return s
+
+
+def _pfx(dtype):
+    return ("orc32_", np.float32) if np.dtype(dtype) == np.float32 else ("orc64_", np.float64)
+
+
+def swag_draw(w_avg, w2_avg, pre_D, z1, z2, scale=0.5, dtype=np.float32):
+    pfx, dt = _pfx(dtype)
+    w_avg, w2_avg, pre_D = _arr(w_avg, dt), _arr(w2_avg, dt), _arr(pre_D, dt)
+    z1, z2 = _arr(np.reshape(z1, -1), dt), _arr(np.reshape(z2, -1), dt)
+    d, K = pre_D.shape
+    assert z1.size == d and z2.size == K
+    w = np.empty(d, dt)
+    rc = getattr(lib(), pfx + "swag_draw")(_p(w_avg), _p(w2_avg), _p(pre_D), C.c_int(d), C.c_int(K), _p(z1), _p(z2),
+                                           C.c_double(scale), _p(w))
+    if rc:
+        raise RuntimeError(f"oracle swag_draw rc={rc}")
+    return w
+
+
+def forward(x, w, eps1, eps2, eps_in=None, eps_sum=None, arch=None, sched=None, dtype=np.float32, extras=False):
+    """Returns out[B,2] (and, with extras, a dict pre_clamp/summary/latents)."""
+    pfx, dt = _pfx(dtype)
+    x = _arr(x, dt)
+    B, T, F = x.shape
+    arch = arch or make_arch(T=T)
+    assert arch.T == T and arch.n_features == F
+    L = arch.latent
+    w, eps1, eps2 = _arr(w, dt), _arr(eps1, dt), _arr(eps2, dt)
+    eps_in, eps_sum = _arr(eps_in, dt), _arr(eps_sum, dt)
+    assert eps1.shape == (B, L) and eps2.shape == (B, L)
+    out = np.empty((B, 2), dt)
+    pre = np.empty((B, 2), dt) if extras else None
+    summ = np.empty((B, 2 * L), dt) if extras else None
+    lat = np.empty((B, T, L), dt) if extras else None
+    rc = getattr(lib(), pfx + "forward")(C.byref(arch), _p(x), C.c_int64(B), _p(w), _p(eps_in), _p(eps1), _p(eps2),
+                                         _p(eps_sum), C.byref(sched) if sched is not None else None, _p(out), _p(pre),
+                                         _p(summ), _p(lat))
+    if rc:
+        raise RuntimeError(f"oracle forward rc={rc}")
+    if extras:
+        return out, {"pre_clamp": pre, "summary": summ, "latents": lat}
+    return out
+
+
+def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1, z2, eps, nchunks=1, scale=0.5, arch=None, sched=None,
+              dtype=np.float32):
+    """x[B,T,F]; state [S,d],[S,d],[S,d,K]; seed_idx[J]; z1[J,d]; z2[J,K]; eps[J/nchunks,B,2,L] -> out[J/nchunks,B,2]."""
+    pfx, dt = _pfx(dtype)
+    x = _arr(x, dt)
+    B, T, F = x.shape
+    arch = arch or make_arch(T=T)
+    w_avg, w2_avg, pre_D = _arr(w_avg, dt), _arr(w2_avg, dt), _arr(pre_D, dt)
+    S, d, K = pre_D.shape
+    seed_idx = _arr(seed_idx, np.int32)
+    J = seed_idx.size
+    z1, z2, eps = _arr(z1, dt), _arr(z2, dt), _arr(eps, dt)
+    R = J // nchunks
+    assert z1.shape == (J, d) and z2.shape == (J, K) and eps.shape == (R, B, 2, arch.latent)
+    out = np.zeros((R, B, 2), dt)
+    rc = getattr(lib(), pfx + "multiswag")(C.byref(arch), _p(x), C.c_int64(B), _p(w_avg), _p(w2_avg), _p(pre_D),
+                                           C.c_int(S), C.c_int(K), _p(seed_idx), C.c_int64(J), C.c_int64(nchunks),
+                                           _p(z1), _p(z2), _p(eps), C.c_double(scale),
+                                           C.byref(sched) if sched is not None else None, _p(out))
+    if rc:
+        raise RuntimeError(f"oracle multiswag rc={rc}")
+    return out

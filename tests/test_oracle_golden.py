@@ -1,0 +1,184 @@
+"""Pins the CPU oracle (oracle/bnn_oracle.c) to vectors produced by the UNMODIFIED reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import close_report, load_golden, tape
+from oracle import oracle as orc
+
+SEEDS = (0, 12)
+INPUTS = ("slow", "iid", "const4")
+
+
+@pytest.mark.parametrize("si", SEEDS)
+def test_swag_draw_matches_reference(si, swag_states):
+    st = swag_states[si]
+    z = load_golden(f"case_swagfast_v50_{si}_slow.npz")
+    tp = tape(z)
+    w = orc.swag_draw(st["w_avg"], st["w2_avg"], st["pre_D"], tp[0][1], tp[1][1], scale=0.5)
+    # diag term is bit-identical; the [d,K] GEMV differs from MKL only in summation order
+    err = np.abs(w.astype(np.float64) - z["w"])
+    assert err.max() <= 2e-6, err.max()
+    assert np.mean(w == z["w"]) > 0.5
+    # fp64 restatement against the fp64 truth of the fixture
+    w64 = orc.swag_draw(st["w_avg"], st["w2_avg"], st["pre_D"], tp[0][1], tp[1][1], scale=0.5, dtype=np.float64)
+    assert np.abs(w64 - z["w_f64"]).max() < 1e-12
+
+
+def test_negative_variance_element_needs_abs(swag_states):
+    st = swag_states[12]  # v50_12 has one negative w2_avg - w_avg^2
+    var = st["w2_avg"] - st["w_avg"] ** 2
+    assert (var < 0).sum() >= 1
+    z = load_golden("case_swagfast_v50_12_slow.npz")
+    assert np.isfinite(z["w"]).all()
+
+
+@pytest.mark.parametrize("si", SEEDS)
+@pytest.mark.parametrize("xname", INPUTS)
+def test_forward_swag_fast_matches_reference(si, xname, swag_states, inputs):
+    z = load_golden(f"case_swagfast_v50_{si}_{xname}.npz")
+    tp = tape(z)
+    assert [k for k, _ in tp] == ["torch.randn", "torch.randn", "torch.randn_like", "torch.randn_like"]
+    x = inputs[xname]
+    # forward with the REFERENCE's sampled weights isolates the forward restatement
+    out, ex = orc.forward(x, z["w"], tp[2][1], tp[3][1], extras=True)
+    nbad, mx = close_report(out, z["out"])
+    assert nbad == 0, (nbad, mx)
+    nbad, mx = close_report(ex["summary"], z["summary"], rtol=2e-5, atol=2e-5)
+    assert nbad == 0, (nbad, mx)
+    nbad, mx = close_report(ex["pre_clamp"], z["pre_clamp"], rtol=1e-4, atol=1e-4)
+    assert nbad == 0, (nbad, mx)
+    nbad, mx = close_report(ex["latents"][:2], z["latents"], rtol=1e-5, atol=2e-5)
+    assert nbad == 0, (nbad, mx)
+    # end to end: oracle draw + oracle forward
+    st = swag_states[si]
+    w = orc.swag_draw(st["w_avg"], st["w2_avg"], st["pre_D"], tp[0][1], tp[1][1], scale=0.5)
+    out2 = orc.forward(x, w, tp[2][1], tp[3][1])
+    nbad, mx = close_report(out2, z["out"])
+    assert nbad == 0, (nbad, mx)
+    # fp64 restatement vs the fixture's fp64 truth (same noise)
+    out64 = orc.forward(x, z["w_f64"], tp[2][1], tp[3][1], dtype=np.float64)
+    assert np.abs(out64 - z["out_f64"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("si", SEEDS)
+@pytest.mark.parametrize("noisy", (0, 1))
+def test_varmodel_forward_matches_reference(si, noisy, inputs):
+    z = load_golden(f"case_forward_v50_{si}_noisy{noisy}.npz")
+    tp = tape(z)
+    x = inputs["slow"]
+    if noisy:
+        assert [a.shape for _, a in tp] == [(32, 100, 41), (32, 20), (32, 20), (32, 40)]
+        out = orc.forward(x, z["w"], tp[1][1], tp[2][1], eps_in=tp[0][1], eps_sum=tp[3][1])
+    else:
+        assert [a.shape for _, a in tp] == [(32, 20), (32, 20)]
+        out = orc.forward(x, z["w"], tp[0][1], tp[1][1])
+    nbad, mx = close_report(out, z["out"])
+    assert nbad == 0, (nbad, mx)
+
+
+def test_varmodel_sample_matches_reference(inputs):
+    """VarModel.sample (spock_reg_model.py:530-545): mean over samples of mu + randn*std."""
+    z = load_golden("case_sample_v50_0.npz")
+    tp = tape(z)
+    x = inputs["slow"]
+    n = int(z["samples"])
+    assert len(tp) == 5 * n
+    acc = []
+    for s in range(n):
+        e_in, e1, e2, e_sum, nz = (tp[5 * s + i][1] for i in range(5))
+        out = orc.forward(x, z["w"], e1, e2, eps_in=e_in, eps_sum=e_sum)
+        acc.append(out[:, 0].astype(np.float64) + nz * out[:, 1].astype(np.float64))
+    got = np.average(acc, axis=0)
+    nbad, mx = close_report(got, z["out"], rtol=2e-5, atol=2e-5)
+    assert nbad == 0, (nbad, mx)
+
+
+def _grid_from_tape(tp, B, L=20):
+    """Unpack [randint, randn(1,d), randn(K,1), randn_like(Bc,L) x2] * J into arrays."""
+    seed_idx, z1, z2, e1, e2 = [], [], [], [], []
+    for i in range(0, len(tp), 5):
+        assert tp[i][0] == "np.randint"
+        seed_idx.append(int(tp[i][1]))
+        z1.append(tp[i + 1][1].reshape(-1))
+        z2.append(tp[i + 2][1].reshape(-1))
+        e1.append(tp[i + 3][1])
+        e2.append(tp[i + 4][1])
+    return np.array(seed_idx, np.int32), np.stack(z1), np.stack(z2), e1, e2
+
+
+def _stack_states(swag_states, members):
+    return (np.stack([swag_states[m]["w_avg"] for m in members]), np.stack([swag_states[m]["w2_avg"] for m in members]),
+            np.stack([swag_states[m]["pre_D"] for m in members]))
+
+
+def test_multiswag_grid_matches_reference(swag_states, inputs):
+    """sample_full_swag x3 (figures/spock/regression.py:74-92 semantics): seed pick + forward_swag_fast."""
+    z = load_golden("case_multiswag_grid.npz")
+    tp = tape(z)
+    x = inputs["slow"]
+    seed_idx, z1, z2, e1, e2 = _grid_from_tape(tp, x.shape[0])
+    assert seed_idx.tolist() == [int(t[1]) for t in tp[::5]]
+    eps = np.stack([np.stack([a, b], axis=1) for a, b in zip(e1, e2)])  # [J,B,2,L]
+    wa, w2, pd = _stack_states(swag_states, z["ensemble"])
+    out = orc.multiswag(x, wa, w2, pd, seed_idx, z1, z2, eps, nchunks=1)
+    nbad, mx = close_report(out, z["out"])
+    assert nbad == 0, (nbad, mx)
+
+
+def test_chunk_loop_matches_reference(swag_states, inputs):
+    """The 5-planet MC loop (figures/multiswag_5_planet.py:295-298): samples x torch.chunk(X, 10)."""
+    z = load_golden("case_chunk_loop.npz")
+    tp = tape(z)
+    B, nch, S = int(z["nrows"]), int(z["chunks"]), int(z["samples"])
+    x = inputs["slow"][:B]
+    seed_idx, z1, z2, e1, e2 = _grid_from_tape(tp, B)
+    assert len(seed_idx) == S * nch
+    csz = -(-B // nch)
+    eps = np.zeros((S, B, 2, 20), np.float32)
+    for e in range(S * nch):
+        s, c = divmod(e, nch)
+        eps[s, c * csz:(c + 1) * csz, 0] = e1[e]
+        eps[s, c * csz:(c + 1) * csz, 1] = e2[e]
+    wa, w2, pd = _stack_states(swag_states, z["ensemble"])
+    out = orc.multiswag(x, wa, w2, pd, seed_idx, z1, z2, eps, nchunks=nch)
+    nbad, mx = close_report(out, z["out"])
+    assert nbad == 0, (nbad, mx)
+
+
+def test_schedule_changes_only_rounding(swag_states, inputs):
+    """A pinned accumulation order (orc_schedule) must stay within rounding of the natural order."""
+    z = load_golden("case_swagfast_v50_0_slow.npz")
+    tp = tape(z)
+    x = inputs["slow"]
+    rng = np.random.default_rng(0)
+    orders = [np.concatenate([rng.permutation(41), [-1]]), rng.permutation(40), rng.permutation(40),
+              rng.permutation(40), rng.permutation(40), rng.permutation(40)]
+    sched = orc.make_schedule(orders, pool_parts=4)
+    a = orc.forward(x, z["w"], tp[2][1], tp[3][1])
+    b = orc.forward(x, z["w"], tp[2][1], tp[3][1], sched=sched)
+    nbad, mx = close_report(b, a)
+    assert nbad == 0 and mx > 0, (nbad, mx)
+    nbad, mx = close_report(b, z["out"])
+    assert nbad == 0, (nbad, mx)
+
+
+def test_known_answer_properties(swag_states, inputs):
+    st = swag_states[0]
+    z = load_golden("case_swagfast_v50_0_slow.npz")
+    tp = tape(z)
+    x = inputs["slow"].copy()
+    # scale = 0 => w == w_avg exactly
+    w0 = orc.swag_draw(st["w_avg"], st["w2_avg"], st["pre_D"], tp[0][1], tp[1][1], scale=0.0)
+    assert np.array_equal(w0, st["w_avg"])
+    base = orc.forward(x, z["w"], tp[2][1], tp[3][1])
+    # masked columns do not affect the output
+    x2 = x.copy()
+    x2[:, :, [1, 2, 3, 4, 5, 6, 7, 38, 39, 40]] = 123.0
+    assert np.array_equal(orc.forward(x2, z["w"], tp[2][1], tp[3][1]), base)
+    # ranges of soft_clamp
+    assert (base[:, 0] >= 4).all() and (base[:, 0] <= 12).all() and (base[:, 1] >= 0.5).all() and (base[:, 1] <= 6).all()
+    # time-pool is order invariant up to rounding
+    perm = np.random.default_rng(1).permutation(100)
+    nbad, mx = close_report(orc.forward(x[:, perm], z["w"], tp[2][1], tp[3][1]), base)
+    assert nbad == 0, (nbad, mx)
