@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI in include/bnn_chaos_hip.h (libbnn_chaos_hip.so, gfx950 only).
+
+There is NO CPU fallback: if the shared library is missing or a call fails this module raises.
+torch is imported first so that the library binds to the HIP runtime torch already loaded
+(both export soname libamdhip64.so.7) and device pointers / streams are interchangeable.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede loading the HIP library)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libbnn_chaos_hip.so")
+
+BNN_OK = 0
+ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_RANGE = -1, -2, -3, -4, -5
+
+
+class BnnArch(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("hidden", C.c_int32), ("latent", C.c_int32), ("reserved", C.c_int32),
+                ("zero_mask", C.c_uint64), ("lowest_std", C.c_float), ("pad", C.c_float)]
+
+
+class BnnGrid(C.Structure):
+    _fields_ = [("B", C.c_int64), ("T", C.c_int32), ("J", C.c_int32), ("nchunks", C.c_int32),
+                ("systems_per_block", C.c_int32)]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"bnn_chaos_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+_vp = C.c_void_p
+
+
+def lib():
+    """Load libbnn_chaos_hip.so; build it with hipcc first if sources are newer (needs ROCm)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        from .csrc import build as _b
+        _b.build()
+    L = C.CDLL(SO_PATH)
+    L.bnn_last_error.restype = C.c_char_p
+    L.bnn_plan_create.argtypes = [C.POINTER(BnnArch), C.POINTER(_vp)]
+    L.bnn_plan_destroy.argtypes = [_vp]
+    L.bnn_plan_layer_order.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int]
+    L.bnn_param_count.argtypes = [C.POINTER(BnnArch)]
+    L.bnn_swag_draw_f32.argtypes = [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_float,
+                                    C.c_uint64, C.c_int64, _vp, _vp]
+    L.bnn_forward_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64,
+                                  _vp, _vp, _vp, _vp]
+    L.bnn_multiswag_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp,
+                                    _vp, C.c_float, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp]
+    L.bnn_moments_f64.argtypes = [_vp, C.c_int64, C.c_int64, _vp, C.c_int32, _vp]
+    L.bnn_philox_normal_f32.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                        _vp, _vp]
+    L.bnn_philox_raw_u32.argtypes = [C.c_uint32] * 6 + [C.c_int64, _vp, _vp]
+    if L.bnn_abi_version() != 1:
+        raise NativeError(-1, "ABI version mismatch")
+    _lib = L
+    return L
+
+
+EXPORTS = ("bnn_abi_version", "bnn_last_error", "bnn_device_count", "bnn_param_count", "bnn_plan_create",
+           "bnn_plan_destroy", "bnn_plan_layer_order", "bnn_swag_draw_f32", "bnn_forward_f32", "bnn_multiswag_f32",
+           "bnn_moments_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32")
+
+
+def check(rc):
+    if rc < 0:
+        raise NativeError(rc, lib().bnn_last_error().decode())
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor on the GPU")
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Plan:
+    """Owns a bnn_plan (device operand tables) for one architecture / column mask."""
+
+    def __init__(self, zero_mask, lowest_std=0.5, n_features=41, hidden=40, latent=20):
+        self.arch = BnnArch(n_features, hidden, latent, 0, zero_mask, lowest_std, 0.0)
+        self.d = check(lib().bnn_param_count(C.byref(self.arch)))
+        h = _vp()
+        check(lib().bnn_plan_create(C.byref(self.arch), C.byref(h)))
+        self.handle = h
+
+    def layer_order(self, layer, noisy=False):
+        import numpy as np
+        buf = np.zeros(64, np.int32)
+        n = check(lib().bnn_plan_layer_order(self.handle, layer, int(noisy), buf.ctypes.data, 64))
+        return buf[:n].copy()
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib().bnn_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

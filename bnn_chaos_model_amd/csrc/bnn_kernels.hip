@@ -1,0 +1,783 @@
+// bnn_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the MultiSWAG inference hot path and the
+// C ABI of include/bnn_chaos_hip.h.
+//
+// Reference path (MilesCranmer/bnn_chaos_model): SWAGModel.sample_weights + forward_swag_fast /
+// VarModel.forward in spock_reg_model.py:415-450, 486-528, 815-908, driven by
+// figures/spock/regression.py:74-92 and figures/multiswag_5_planet.py:295-298.
+//
+// Kernel shape (DESIGN.md has the long form):
+//   * one 256-thread workgroup = 4 independent waves; a workgroup serves ONE weight draw and a
+//     block of systems.  Prologue: the draw (or a copy of a materialised draw) lands in LDS as the
+//     reference's flat parameter vector; each wave gathers its MFMA A-operand fragments (74 VGPRs
+//     for the v50 column mask) from LDS once and keeps them in registers.
+//   * main loop, per wave, no barriers, no LDS: 16 rows (4 systems x 4 consecutive timesteps) per
+//     step are read from HBM straight into the B-operand layout of v_mfma_f32_16x16x4_f32
+//     (each lane: 8 consecutive floats of its row), then 24 + 30 + 20 MFMAs evaluate the three
+//     feature_nn layers; accumulators of one layer are the B operands of the next (bnn_layout.h).
+//   * time pooling: per-lane Welford over the lane's 25 timesteps, merged over the 4 lanes of a
+//     quad (Chan), then the reference's sampled-moment formulas with explicit or Philox noise.
+//   * regress_nn for 16 systems at a time on the same MFMA path, soft_clamp, 8-byte stores.
+// fp32 MFMA is bit-for-bit a k-ordered fmaf chain, so the whole forward is reproducible on a CPU
+// with the accumulation order exported by bnn_plan_layer_order().
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fmaf/MFMA are the only fusions).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bnn_chaos_hip.h"
+#include "bnn_layout.h"
+#include "bnn_tables.h"
+
+using namespace bnn;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+#define DEVINL __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) and the normals derived from it.
+// Counters use GLOBAL draw / output-row / system ids, so results are invariant to sharding.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t TAG_Z1 = 0x10000000u, TAG_Z2 = 0x20000000u, TAG_EPS = 0x30000000u;
+
+DEVINL uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// Box-Muller on 24-bit uniforms in (0,1); v_sin/v_cos take revolutions, so no range reduction.
+DEVINL f32x2 box_muller(uint32_t a, uint32_t b) {
+    float u1 = ((float)(a >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    float u2 = ((float)(b >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    float r = sqrtf(-2.0f * __logf(u1));
+    f32x2 o;
+    o.x = r * __builtin_amdgcn_cosf(u2);
+    o.y = r * __builtin_amdgcn_sinf(u2);
+    return o;
+}
+
+DEVINL f32x4 philox_normal4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint64_t seed) {
+    uint4 r = philox4x32_10(make_uint4(c0, c1, c2, c3), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    f32x2 a = box_muller(r.x, r.y), b = box_muller(r.z, r.w);
+    f32x4 o = {a.x, a.y, b.x, b.y};
+    return o;
+}
+
+// z1[draw][i], z2[draw][k]: counter = (tag | quad, draw lo, draw hi, 0)
+DEVINL float philox_z(uint32_t tag, int64_t draw, int elem, uint64_t seed) {
+    f32x4 n = philox_normal4(tag | (uint32_t)(elem >> 2), (uint32_t)draw, (uint32_t)((uint64_t)draw >> 32), 0u, seed);
+    return n[elem & 3];
+}
+// eps[row][sys][kind][n], quad = (kind*20 + n) / 4: counter = (tag | quad, sys lo, sys hi16 | row hi16 << 16, row lo)
+DEVINL f32x4 philox_eps4(int64_t row, int64_t sys, int quad, uint64_t seed) {
+    uint32_t c2 = (uint32_t)(((uint64_t)sys >> 32) & 0xffffu) | ((uint32_t)(((uint64_t)row >> 32) & 0xffffu) << 16);
+    return philox_normal4(TAG_EPS | (uint32_t)quad, (uint32_t)sys, c2, (uint32_t)row, seed);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel parameters
+// ------------------------------------------------------------------------------------------------
+struct FwdParams {
+    const float* x;
+    int64_t B;
+    int32_t T, ntiles;
+    int32_t J, nch;
+    int64_t csz;
+    int32_t spc;  // systems per workgroup (multiple of 64)
+    int32_t K, S;
+    const float* W;  // [J,d] materialised draws (unfused) or nullptr
+    const float* w_avg;
+    const float* w2_avg;
+    const float* pre_D;
+    const int32_t* seed_idx;
+    const float* z1;
+    const float* z2;
+    float c1, c2, scale;
+    const float* eps;
+    const float* eps_in;
+    const float* eps_sum;
+    uint64_t seed;
+    int64_t draw_id0, row_id0, sys_id0;
+    float* out;
+    float* pre_clamp;
+    float* summary;
+    const int16_t* tab_f1;
+    const int16_t* tab_f2;
+    uint64_t zero_mask;
+    float std_lo, std_span;
+};
+
+DEVINL f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+DEVINL f32x4 relu4(f32x4 v) {
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaxf(v[i], 0.0f);
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SWAG draw of rows [i0, i0+64) by one wave (SWAGModel.sample_weights, spock_reg_model.py:815-838).
+// pre_D rows are staged through a wave-private LDS slab so the HBM/L2 read is one contiguous
+// 64*K-float run; lane l then owns row i0+l and accumulates its K-term dot product in k order.
+// Callers bracket the two phases with workgroup barriers (stage -> barrier -> compute -> barrier).
+// ------------------------------------------------------------------------------------------------
+DEVINL void draw_stage(const float* __restrict__ pre_D_s, int i0, int K, int lane, float* slab) {
+    const int64_t base = (int64_t)i0 * K, lim = (int64_t)D * K;
+    for (int n = 0; n < K; ++n) {
+        int idx = n * 64 + lane;
+        if (base + idx < lim) slab[idx] = pre_D_s[base + idx];
+    }
+}
+
+DEVINL float draw_row(const float* __restrict__ w_avg_s, const float* __restrict__ w2_avg_s, int i, int K, int lane,
+                      const float* slab, const float* zsh, float z1v, float c1, float c2, float scale) {
+    // D = pre_D - w_avg[:,None] (:826); sigma = abs(diag(w2_avg - w_avg**2)) (:832)
+    // w = w_avg + scale/sqrt2 * z1 @ sigma**0.5 (:834);  w += scale * (D @ z2).T / sqrt(2(K-1)) (:835)
+    float wa = w_avg_s[i], w2 = w2_avg_s[i];
+    float sq = wa * wa;
+    float var = w2 - sq;
+    float sd = sqrtf(fabsf(var));
+    float t1 = (c1 * z1v) * sd;
+    float w = wa + t1;
+    float dot = 0.0f;
+    const float* row = slab + lane * K;
+    for (int k = 0; k < K; ++k) {
+        float Dk = row[k] - wa;
+        dot = fmaf(Dk, zsh[k], dot);
+    }
+    float t2 = (scale * dot) / c2;
+    return w + t2;
+}
+
+constexpr int SLAB = 64 * MAXK;  // floats per wave
+
+__global__ __launch_bounds__(256) void bnn_swag_draw_kernel(const float* __restrict__ w_avg, const float* __restrict__ w2_avg,
+                                                            const float* __restrict__ pre_D, int S, int K,
+                                                            const int32_t* __restrict__ seed_idx, const float* __restrict__ z1,
+                                                            const float* __restrict__ z2, float c1, float c2, float scale,
+                                                            uint64_t seed, int64_t draw_id0, float* __restrict__ W_out) {
+    __shared__ float slabs[4 * SLAB];
+    __shared__ float zsh[MAXK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.y;
+    int s = seed_idx[e];
+    const bool bad = (s < 0 || s >= S);
+    if (bad) s = 0;
+    if (threadIdx.x < K)
+        zsh[threadIdx.x] = z2 ? z2[(int64_t)e * K + threadIdx.x] : philox_z(TAG_Z2, draw_id0 + e, threadIdx.x, seed);
+    const int i0 = (blockIdx.x * 4 + wave) * 64;
+    const float* pd = pre_D + (int64_t)s * D * K;
+    if (i0 < D) draw_stage(pd, i0, K, lane, slabs + wave * SLAB);
+    __syncthreads();
+    const int i = i0 + lane;
+    if (i < D) {
+        float z1v = z1 ? z1[(int64_t)e * D + i] : philox_z(TAG_Z1, draw_id0 + e, i, seed);
+        float w = draw_row(w_avg + (int64_t)s * D, w2_avg + (int64_t)s * D, i, K, lane, slabs + wave * SLAB, zsh, z1v, c1, c2,
+                           scale);
+        W_out[(int64_t)e * D + i] = bad ? __builtin_nanf("") : w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// x tile -> B operands.  Lane (g, c) owns row `rowp` (41 floats) and k slots kmap_input(NK1, s, g).
+// ------------------------------------------------------------------------------------------------
+template <int NK1>
+struct XTile {
+    float v[NK1];
+};
+
+template <int NK1>
+DEVINL XTile<NK1> load_x(const float* __restrict__ rowp, int g) {
+    XTile<NK1> t;
+    if constexpr (NK1 == 8) {
+        const float* p = rowp + 8 + 8 * g;
+        f32x4 a = *reinterpret_cast<const f32x4u*>(p);
+        f32x4 b = *reinterpret_cast<const f32x4u*>(p + 4);  // group 3: columns 36..39, 38/39 replaced below
+        float x0 = rowp[0];
+        t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w;
+        t.v[4] = b.x; t.v[5] = b.y;
+        t.v[6] = (g == 3) ? x0 : b.z;
+        t.v[7] = (g == 3) ? 1.0f : b.w;
+    } else {
+        const float* p = rowp + 11 * g;
+        f32x4 a = *reinterpret_cast<const f32x4u*>(p);
+        f32x4 b = *reinterpret_cast<const f32x4u*>(p + 4);
+        const float* pc = (g == 3) ? rowp + 38 : p + 8;  // group 3 has no columns 41..43: stay inside the row
+        f32x3 c = *reinterpret_cast<const f32x3u*>(pc);
+        t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w;
+        t.v[4] = b.x; t.v[5] = b.y; t.v[6] = b.z; t.v[7] = b.w;
+        t.v[8] = (g == 3) ? 1.0f : c.x;  // slot 41 = bias
+        t.v[9] = (g == 3) ? 0.0f : c.y;
+        t.v[10] = (g == 3) ? 0.0f : c.z;
+    }
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused kernel
+// ------------------------------------------------------------------------------------------------
+template <int NK1, bool NOISY, bool FUSED>
+__global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot
+    float* zsh = lds + FLAT_LDS;       // [MAXK]
+    float* slabs = zsh + MAXK;         // [4][SLAB] pre_D staging during a fused draw ...
+    float* f2frag = slabs;             // ... then [NF2][64] regress_nn operands in fragment order
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+
+    // ---- work item: draw e, block `sub` of its chunk of systems (torch.chunk semantics)
+    const int64_t id = blockIdx.x;
+    const int e = (int)(id % p.J);
+    const int64_t sub = id / p.J;
+    const int ch = e % p.nch;
+    const int64_t r = e / p.nch;  // output row
+    const int64_t seg0 = (int64_t)ch * p.csz;
+    const int64_t seg1 = (seg0 + p.csz < p.B) ? seg0 + p.csz : p.B;
+    const int64_t b0 = seg0 + sub * p.spc;
+    const int64_t b1 = (b0 + p.spc < seg1) ? b0 + p.spc : seg1;
+    if (b0 >= b1) return;
+
+    // ---- prologue: flat parameter vector of draw e -> LDS
+    bool bad_seed = false;
+    if constexpr (FUSED) {
+        int s = p.seed_idx[e];
+        bad_seed = (s < 0 || s >= p.S);
+        if (bad_seed) s = 0;
+        const int K = p.K;
+        if (tid < K) zsh[tid] = p.z2 ? p.z2[(int64_t)e * K + tid] : philox_z(TAG_Z2, p.draw_id0 + e, tid, p.seed);
+        const float* wa = p.w_avg + (int64_t)s * D;
+        const float* w2 = p.w2_avg + (int64_t)s * D;
+        const float* pd = p.pre_D + (int64_t)s * D * K;
+        float* slab = slabs + wave * SLAB;
+        for (int step = 0; step * 256 < D; ++step) {
+            const int i0 = (step * 4 + wave) * 64;
+            if (i0 < D) draw_stage(pd, i0, K, lane, slab);
+            __syncthreads();
+            const int i = i0 + lane;
+            if (i < D) {
+                float z1v = p.z1 ? p.z1[(int64_t)e * D + i] : philox_z(TAG_Z1, p.draw_id0 + e, i, p.seed);
+                flat[i] = draw_row(wa, w2, i, K, lane, slab, zsh, z1v, p.c1, p.c2, p.scale);
+            }
+            __syncthreads();
+        }
+    } else {
+        const float* We = p.W + (int64_t)e * D;
+        for (int i = tid; i < D; i += 256) flat[i] = We[i];
+    }
+    if (tid == 0) flat[ZERO_IDX] = 0.0f;
+    __syncthreads();
+
+    // ---- feature_nn operands: registers for the whole workgroup lifetime
+    constexpr int NW1 = 3 * NK1, IW2 = NW1, IW3 = IW2 + 30, IB2 = IW3 + 20, IB3 = IB2 + 12, NF1 = IB3 + 8;
+    float wf[NF1];
+#pragma unroll
+    for (int f = 0; f < NF1; ++f) wf[f] = flat[p.tab_f1[f * 64 + lane]];
+
+    // regress_nn operands -> LDS in fragment order (read back with immediate offsets, once per 16 systems)
+    for (int f = wave; f < NF2; f += 4) f2frag[f * 64 + lane] = flat[p.tab_f2[f * 64 + lane]];
+    __syncthreads();
+
+    float in_scale[NOISY ? NK1 : 1];
+    if constexpr (NOISY) {
+#pragma unroll
+        for (int s = 0; s < NK1; ++s) {
+            int col = 11 * g + s;
+            in_scale[s] = col < F ? expf(flat[OFF_INLV + col] / 2.0f) : 0.0f;  // exp(logvar/2), :445
+        }
+    }
+
+    const int T = p.T, ntiles = p.ntiles;
+    const float nm1 = (float)(T - 1), nT = (float)T;
+    const float half_n0 = (float)ntiles * 0.5f;
+    const int64_t rowstride = (int64_t)T * F;
+
+    // ---- wave-batches of 16 systems
+    for (int64_t wb0 = b0 + (int64_t)wave * 16; wb0 < b1; wb0 += 64) {
+        float skeep[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) skeep[k] = 0.0f;
+
+        for (int q = 0; q < 4; ++q) {
+            if (wb0 + 4 * q >= b1) break;  // wave-uniform
+            const int64_t sys = wb0 + 4 * q + (c >> 2);
+            const bool valid = sys < b1;
+            const int64_t sysc = valid ? sys : b1 - 1;
+            const float* rowp = p.x + sysc * rowstride + (int64_t)(c & 3) * F;
+            const float* epin = nullptr;
+            if constexpr (NOISY) epin = p.eps_in + (r * p.B + sysc) * rowstride + (int64_t)(c & 3) * F;
+
+            f32x4 mean0 = {0, 0, 0, 0}, m20 = {0, 0, 0, 0};
+            float mean1 = 0.0f, m21 = 0.0f;
+
+            XTile<NK1> cur = load_x<NK1>(rowp, g);
+            XTile<NK1> ncur;
+            if constexpr (NOISY) ncur = load_x<NK1>(epin, g);
+            for (int it = 0; it < ntiles; ++it) {
+                XTile<NK1> nxt = cur, nnxt;
+                if (it + 1 < ntiles) {
+                    nxt = load_x<NK1>(rowp + (int64_t)(it + 1) * 4 * F, g);
+                    if constexpr (NOISY) nnxt = load_x<NK1>(epin + (int64_t)(it + 1) * 4 * F, g);
+                }
+                if constexpr (NOISY) {
+                    // masks then add_input_noise (:486-504): masked columns become pure noise
+#pragma unroll
+                    for (int s = 0; s < NK1; ++s) {
+                        int col = 11 * g + s;
+                        if (col < F) {
+                            float xv = ((p.zero_mask >> col) & 1ull) ? 0.0f : cur.v[s];
+                            cur.v[s] = xv + ncur.v[s] * in_scale[s];
+                        }
+                    }
+                }
+                // feature_nn.0 + ReLU
+                f32x4 h[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+                for (int s = 0; s < NK1; ++s)
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt) h[mt] = mfma(wf[s * 3 + mt], cur.v[s], h[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) h[mt] = relu4(h[mt]);
+                // feature_nn.2 + ReLU
+                f32x4 h2[3];
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) h2[mt] = (f32x4){wf[IB2 + mt * 4], wf[IB2 + mt * 4 + 1], wf[IB2 + mt * 4 + 2], wf[IB2 + mt * 4 + 3]};
+#pragma unroll
+                for (int ks = 0; ks < NKH; ++ks)
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt) h2[mt] = mfma(wf[IW2 + ks * 3 + mt], h[ks >> 2][ks & 3], h2[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) h2[mt] = relu4(h2[mt]);
+                // feature_nn.4
+                f32x4 y[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) y[mt] = (f32x4){wf[IB3 + mt * 4], wf[IB3 + mt * 4 + 1], wf[IB3 + mt * 4 + 2], wf[IB3 + mt * 4 + 3]};
+#pragma unroll
+                for (int ks = 0; ks < NKH; ++ks)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) y[mt] = mfma(wf[IW3 + ks * 2 + mt], h2[ks >> 2][ks & 3], y[mt]);
+                // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
+                const float rcn = 1.0f / (float)(it + 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float dl = y[0][i] - mean0[i];
+                    float mn = mean0[i] + dl * rcn;
+                    m20[i] = m20[i] + dl * (y[0][i] - mn);
+                    mean0[i] = mn;
+                }
+                {
+                    float dl = y[1][0] - mean1;
+                    float mn = mean1 + dl * rcn;
+                    m21 = m21 + dl * (y[1][0] - mn);
+                    mean1 = mn;
+                }
+                cur = nxt;
+                if constexpr (NOISY) ncur = nnxt;
+            }
+
+            // merge the 4 lanes of a quad (timesteps t = 4*it + (c&3)): equal-count Chan update, symmetric
+            float mean[5] = {mean0[0], mean0[1], mean0[2], mean0[3], mean1};
+            float m2[5] = {m20[0], m20[1], m20[2], m20[3], m21};
+            float half_n = half_n0;
+#pragma unroll
+            for (int stage = 1; stage <= 2; stage <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    float om = __shfl_xor(mean[k], stage), o2 = __shfl_xor(m2[k], stage);
+                    float dl = om - mean[k];
+                    float mm = (mean[k] + om) * 0.5f;
+                    float qq = (m2[k] + o2) + (dl * dl) * half_n;
+                    mean[k] = mm;
+                    m2[k] = qq;
+                }
+                half_n = half_n * 2.0f;
+            }
+
+            // compute_summary_stats (:420-431) with the two randn_like draws
+            f32x4 e1a, e2a;
+            float e1b, e2b;
+            if (p.eps) {
+                const float* ep = p.eps + (r * p.B + sysc) * (2 * L);
+                e1a = *reinterpret_cast<const f32x4*>(ep + 4 * g);
+                e1b = ep[16 + g];
+                e2a = *reinterpret_cast<const f32x4*>(ep + L + 4 * g);
+                e2b = ep[L + 16 + g];
+            } else {
+                const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + sysc;
+                e1a = philox_eps4(grow, gsys, g, p.seed);
+                e1b = philox_eps4(grow, gsys, 4, p.seed)[g];
+                e2a = philox_eps4(grow, gsys, 5 + g, p.seed);
+                e2b = philox_eps4(grow, gsys, 9, p.seed)[g];
+            }
+            float snew[10];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                float e1 = k < 4 ? e1a[k] : e1b, e2 = k < 4 ? e2a[k] : e2b;
+                float sample_mu = mean[k];
+                float sd = sqrtf(m2[k] / nm1);   // torch.std (unbiased)
+                float sample_var = sd * sd;      // **2
+                float std_in_mu = sqrtf(sample_var / nT);
+                float std_in_var = sqrtf((2.0f * (sample_var * sample_var)) / nm1);
+                float mu_s = e1 * std_in_mu + sample_mu;
+                float var_s = e2 * std_in_var + sample_var;
+                snew[k] = mu_s;
+                snew[5 + k] = sqrtf(fabsf(var_s) + 1e-5f);  // EPSILON (:337)
+            }
+            if (p.summary && valid && (c & 3) == 0) {
+                float* sp = p.summary + (r * p.B + sys) * S2;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    int n = k < 4 ? 4 * g + k : 16 + g;
+                    sp[n] = snew[k];
+                    sp[L + n] = snew[5 + k];
+                }
+            }
+            if ((c & 3) == q) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) skeep[k] = snew[k];
+            }
+        }
+
+        // ---- regress_nn on 16 systems: column c <-> system wb0 + 4*(c&3) + (c>>2)
+        const int64_t sysb = wb0 + 4 * (c & 3) + (c >> 2);
+        const bool validb = sysb < b1;
+        if constexpr (NOISY) {
+            // add_summary_noise (:448-450)
+            const int64_t sc = validb ? sysb : b1 - 1;
+            const float* es = p.eps_sum + (r * p.B + sc) * S2;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                int n = kmap_summary(k, g);
+                skeep[k] = skeep[k] + es[n] * expf(flat[OFF_SUMLV + n] / 2.0f);
+            }
+        }
+        const float* f2l = f2frag + lane;
+        auto W2f = [&](int f) { return f2l[f * 64]; };
+        f32x4 a4[3], a5[3], a6;
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a4[mt] = (f32x4){W2f(70 + mt * 4), W2f(71 + mt * 4), W2f(72 + mt * 4), W2f(73 + mt * 4)};
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(ks * 3 + mt), skeep[ks], a4[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a4[mt] = relu4(a4[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a5[mt] = (f32x4){W2f(82 + mt * 4), W2f(83 + mt * 4), W2f(84 + mt * 4), W2f(85 + mt * 4)};
+#pragma unroll
+        for (int ks = 0; ks < NKH; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(30 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a5[mt] = relu4(a5[mt]);
+        a6 = (f32x4){W2f(94), W2f(95), W2f(96), W2f(97)};
+#pragma unroll
+        for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(60 + ks), a5[ks >> 2][ks & 3], a6);
+
+        if (g == 0 && validb) {
+            // predict_instability + soft_clamp (:295-296, :437-442)
+            float r0 = a6[0], r1 = a6[1];
+            float mu = (0.5f * (tanhf(r0) + 1.0f)) * 8.0f + 4.0f;
+            float sd = (0.5f * (tanhf(r1) + 1.0f)) * p.std_span + p.std_lo;
+            if (bad_seed) mu = sd = __builtin_nanf("");
+            const int64_t o = (r * p.B + sysb) * 2;
+            *reinterpret_cast<f32x2*>(p.out + o) = (f32x2){mu, sd};
+            if (p.pre_clamp) *reinterpret_cast<f32x2*>(p.pre_clamp + o) = (f32x2){r0, r1};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void bnn_moments_kernel(const float* __restrict__ samples, int64_t R, int64_t B, double* __restrict__ mom, int accumulate) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (accumulate) { s0 = mom[b * 4]; s1 = mom[b * 4 + 1]; s2 = mom[b * 4 + 2]; s3 = mom[b * 4 + 3]; }
+    for (int64_t r = 0; r < R; ++r) {
+        f32x2 v = *reinterpret_cast<const f32x2*>(samples + (r * B + b) * 2);
+        double mu = v.x, sd = v.y;
+        s0 += mu; s1 += mu * mu; s2 += sd; s3 += sd * sd;
+    }
+    mom[b * 4] = s0; mom[b * 4 + 1] = s1; mom[b * 4 + 2] = s2; mom[b * 4 + 3] = s3;
+}
+
+__global__ void bnn_philox_fill_kernel(int kind, uint64_t seed, int64_t id0, int64_t n_rows, int64_t B, int64_t sys0, int width,
+                                       float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (kind == 0 || kind == 1) {
+        int64_t total = n_rows * width;
+        if (i >= total) return;
+        int64_t row = i / width;
+        int el = (int)(i % width);
+        out[i] = philox_z(kind == 0 ? TAG_Z1 : TAG_Z2, id0 + row, el, seed);
+    } else {
+        int64_t total = n_rows * B * S2;
+        if (i >= total) return;
+        int el = (int)(i % S2);
+        int64_t sys = (i / S2) % B, row = i / (S2 * B);
+        out[i] = philox_eps4(id0 + row, sys0 + sys, el >> 2, seed)[el & 3];
+    }
+}
+
+__global__ void bnn_philox_raw_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int64_t n,
+                                      uint32_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 r = philox4x32_10(make_uint4(c0 + (uint32_t)i, c1, c2, c3), make_uint2(k0, k1));
+    out[i * 4] = r.x; out[i * 4 + 1] = r.y; out[i * 4 + 2] = r.z; out[i * 4 + 3] = r.w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) return fail(BNN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct bnn_plan {
+    bnn_arch arch;
+    Tables tab[2];  // [0] = arch mask, [1] = all 41 columns (noisy forward)
+    int16_t* d_f1[2] = {nullptr, nullptr};
+    int16_t* d_f2[2] = {nullptr, nullptr};
+    int device = 0;
+};
+
+static int check_arch(const bnn_arch* a) {
+    if (!a) return fail(BNN_ERR_INVALID, "arch is NULL");
+    if (a->n_features != F || a->hidden != H || a->latent != L)
+        return fail(BNN_ERR_UNSUPPORTED, "only the 41->40->40->20 / 40->40->40->2 network of the pretrained ensemble is built");
+    if (a->zero_mask >> F) return fail(BNN_ERR_INVALID, "zero_mask has bits beyond column 40");
+    return 0;
+}
+
+extern "C" {
+
+int bnn_abi_version(void) { return BNN_ABI_VERSION; }
+const char* bnn_last_error(void) { return g_err.c_str(); }
+
+int bnn_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(BNN_ERR_NO_DEVICE, hipGetErrorString(e));
+    return n;
+}
+
+int bnn_param_count(const bnn_arch* arch) {
+    int rc = check_arch(arch);
+    return rc ? rc : D;
+}
+
+int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
+    int rc = check_arch(arch);
+    if (rc) return rc;
+    if (!out) return fail(BNN_ERR_INVALID, "out is NULL");
+    bnn_plan* pl = new bnn_plan();
+    pl->arch = *arch;
+    pl->tab[0] = build_tables(arch->zero_mask, false);
+    pl->tab[1] = build_tables(arch->zero_mask, true);
+    if (hipGetDevice(&pl->device) != hipSuccess) {
+        delete pl;
+        return fail(BNN_ERR_NO_DEVICE, "no HIP device");
+    }
+    for (int v = 0; v < 2; ++v) {
+        size_t n1 = pl->tab[v].f1.size() * sizeof(int16_t), n2 = pl->tab[v].f2.size() * sizeof(int16_t);
+        if (hipMalloc(&pl->d_f1[v], n1) != hipSuccess || hipMalloc(&pl->d_f2[v], n2) != hipSuccess ||
+            hipMemcpy(pl->d_f1[v], pl->tab[v].f1.data(), n1, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(pl->d_f2[v], pl->tab[v].f2.data(), n2, hipMemcpyHostToDevice) != hipSuccess) {
+            bnn_plan_destroy(pl);
+            return fail(BNN_ERR_HIP, "plan table upload failed");
+        }
+    }
+    *out = pl;
+    return 0;
+}
+
+int bnn_plan_destroy(bnn_plan* pl) {
+    if (!pl) return 0;
+    for (int v = 0; v < 2; ++v) {
+        if (pl->d_f1[v]) (void)hipFree(pl->d_f1[v]);
+        if (pl->d_f2[v]) (void)hipFree(pl->d_f2[v]);
+    }
+    delete pl;
+    return 0;
+}
+
+int bnn_plan_layer_order(const bnn_plan* pl, int layer, int noisy, int32_t* host_order, int cap) {
+    if (!pl || layer < 0 || layer > 5) return fail(BNN_ERR_INVALID, "bad plan/layer");
+    const std::vector<int32_t>& o = pl->tab[noisy ? 1 : 0].order[layer];
+    if (host_order)
+        for (int i = 0; i < (int)o.size() && i < cap; ++i) host_order[i] = o[i];
+    return (int)o.size();
+}
+
+static int pick_spc(const bnn_grid* g, int64_t csz) {
+    if (g->systems_per_block > 0) return g->systems_per_block;
+    // enough workgroups to fill 256 CUs several times over, else shrink the block
+    for (int spc : {256, 128}) {
+        int64_t nsub = (csz + spc - 1) / spc;
+        if (nsub * (int64_t)g->J >= 4096) return spc;
+    }
+    return 64;
+}
+
+static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, bool fused, bool noisy, void* stream) {
+    if (!pl || !g) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
+    if (g->B < 0 || g->J < 0 || g->nchunks < 1) return fail(BNN_ERR_INVALID, "negative size");
+    if (g->J % g->nchunks) return fail(BNN_ERR_INVALID, "J must be a multiple of nchunks");
+    if (g->T < 8 || (g->T % 4)) return fail(BNN_ERR_UNSUPPORTED, "T must be a multiple of 4 and >= 8");
+    if (g->systems_per_block < 0 || (g->systems_per_block % 64)) return fail(BNN_ERR_INVALID, "systems_per_block must be a multiple of 64");
+    if (g->B == 0 || g->J == 0) return 0;
+    if (!p.x || !p.out) return fail(BNN_ERR_INVALID, "x/out is NULL");
+    if (p.draw_id0 % g->nchunks) return fail(BNN_ERR_INVALID, "draw_id0 must be a multiple of nchunks");
+    const int v = noisy ? 1 : 0;
+    p.B = g->B; p.T = g->T; p.ntiles = g->T / 4; p.J = g->J; p.nch = g->nchunks;
+    p.csz = (g->B + g->nchunks - 1) / g->nchunks;
+    p.spc = pick_spc(g, p.csz);
+    p.row_id0 = p.draw_id0 / g->nchunks;
+    p.tab_f1 = pl->d_f1[v]; p.tab_f2 = pl->d_f2[v];
+    p.zero_mask = pl->arch.zero_mask;
+    p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);
+    const int64_t nsub = (p.csz + p.spc - 1) / p.spc;
+    const int64_t nblk = nsub * g->J;
+    if (nblk > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "grid too large; split the draws");
+    const size_t shmem = sizeof(float) * (FLAT_LDS + MAXK + 4 * SLAB);
+    static_assert(NF2 * 64 <= 4 * SLAB, "regress_nn fragments alias the pre_D staging slabs");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)nblk), block(256);
+    const int nk1 = pl->tab[v].nk1;
+#define LAUNCH(NK, NZ, FU)                                                                                         \
+    do {                                                                                                           \
+        static std::once_flag once;                                                                                \
+        std::call_once(once, [] {                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag_kernel<NK, NZ, FU>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+        });                                                                                                        \
+        hipLaunchKernelGGL((bnn_multiswag_kernel<NK, NZ, FU>), grid, block, shmem, st, p);                         \
+    } while (0)
+    if (noisy) {
+        LAUNCH(11, true, false);
+    } else if (nk1 == 8) {
+        if (fused) LAUNCH(8, false, true); else LAUNCH(8, false, false);
+    } else {
+        if (fused) LAUNCH(11, false, true); else LAUNCH(11, false, false);
+    }
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int draw_consts(int K, float scale, float* c1, float* c2) {
+    if (K < 2 || K > MAXK) return fail(BNN_ERR_RANGE, "SWAG rank K must be in [2, 32]");
+    *c1 = (float)((double)scale * (1.0 / std::sqrt(2.0)));  // scale * (1.0/np.sqrt(2.0)), :834
+    *c2 = (float)std::sqrt(2.0 * (K - 1));                   // np.sqrt(2*(K-1)), :835
+    return 0;
+}
+
+int bnn_swag_draw_f32(const bnn_plan* plan, const float* w_avg, const float* w2_avg, const float* pre_D, int32_t S, int32_t K,
+                      const int32_t* seed_idx, int32_t J, const float* z1, const float* z2, float scale, uint64_t philox_seed,
+                      int64_t draw_id0, float* W_out, void* stream) {
+    if (!plan || !w_avg || !w2_avg || !pre_D || !seed_idx || !W_out) return fail(BNN_ERR_INVALID, "NULL argument");
+    if ((z1 == nullptr) != (z2 == nullptr)) return fail(BNN_ERR_INVALID, "z1 and z2 must both be given or both be NULL");
+    if (S < 1 || J < 0) return fail(BNN_ERR_INVALID, "bad S/J");
+    float c1, c2;
+    int rc = draw_consts(K, scale, &c1, &c2);
+    if (rc) return rc;
+    if (J == 0) return 0;
+    dim3 grid((D + 255) / 256, J), block(256);
+    hipLaunchKernelGGL(bnn_swag_draw_kernel, grid, block, 0, (hipStream_t)stream, w_avg, w2_avg, pre_D, S, K, seed_idx, z1, z2, c1,
+                       c2, scale, philox_seed, draw_id0, W_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps, const float* eps_in,
+                    const float* eps_sum, uint64_t philox_seed, int64_t draw_id0, int64_t system_id0, float* out, float* pre_clamp,
+                    float* summary, void* stream) {
+    if (!W) return fail(BNN_ERR_INVALID, "W is NULL");
+    if ((eps_in == nullptr) != (eps_sum == nullptr)) return fail(BNN_ERR_INVALID, "eps_in and eps_sum must both be given or both be NULL");
+    if (eps_in && !eps) return fail(BNN_ERR_UNSUPPORTED, "noisy forward needs explicit eps as well (in-kernel input noise is not built yet)");
+    FwdParams p{};
+    p.x = x; p.W = W; p.eps = eps; p.eps_in = eps_in; p.eps_sum = eps_sum;
+    p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
+    p.out = out; p.pre_clamp = pre_clamp; p.summary = summary;
+    return launch_forward(plan, grid, p, false, eps_in != nullptr, stream);
+}
+
+int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg, const float* w2_avg,
+                      const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx, const float* z1, const float* z2,
+                      const float* eps, float scale, uint64_t philox_seed, int64_t draw_id0, int64_t system_id0, float* out,
+                      float* pre_clamp, float* summary, void* stream) {
+    if (!w_avg || !w2_avg || !pre_D || !seed_idx) return fail(BNN_ERR_INVALID, "NULL ensemble argument");
+    if ((z1 == nullptr) != (z2 == nullptr)) return fail(BNN_ERR_INVALID, "z1 and z2 must both be given or both be NULL");
+    if (S < 1) return fail(BNN_ERR_INVALID, "bad S");
+    FwdParams p{};
+    int rc = draw_consts(K, scale, &p.c1, &p.c2);
+    if (rc) return rc;
+    p.scale = scale; p.K = K; p.S = S;
+    p.x = x; p.w_avg = w_avg; p.w2_avg = w2_avg; p.pre_D = pre_D; p.seed_idx = seed_idx; p.z1 = z1; p.z2 = z2; p.eps = eps;
+    p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
+    p.out = out; p.pre_clamp = pre_clamp; p.summary = summary;
+    return launch_forward(plan, grid, p, true, false, stream);
+}
+
+int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments, int32_t accumulate, void* stream) {
+    if (!samples || !moments || R < 0 || B < 0) return fail(BNN_ERR_INVALID, "bad argument");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(bnn_moments_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, samples, R, B, moments,
+                       accumulate);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bnn_philox_normal_f32(int32_t kind, uint64_t philox_seed, int64_t id0, int64_t n_rows, int64_t B, int64_t system_id0, int32_t width,
+                          float* out, void* stream) {
+    if (!out || kind < 0 || kind > 2 || n_rows < 0) return fail(BNN_ERR_INVALID, "bad argument");
+    int64_t total = (kind == 2) ? n_rows * B * S2 : n_rows * (int64_t)width;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(bnn_philox_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind, philox_seed,
+                       id0, n_rows, B, system_id0, width, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bnn_philox_raw_u32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int64_t n, uint32_t* out,
+                       void* stream) {
+    if (!out || n < 0) return fail(BNN_ERR_INVALID, "bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bnn_philox_raw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c0, c1, c2, c3, k0, k1,
+                       n, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// bnn_layout.h -- operand layout shared by the table builder (host) and the kernels (device).
+//
+// The network is evaluated with v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain).
+// For every Linear layer  out[neuron][row] = sum_k W[neuron][k] * act[k][row] + b[neuron]:
+//   A operand = weights      lane (g = lane>>4, m = lane&15) holds W[nmap(mt, m)][kmap(kstep, g)]
+//   B operand = activations  lane (g, c = lane&15)           holds act[kmap(kstep, g)][row c]
+//   C/D                      lane (g, c), register i         holds out[nmap(mt, 4g+i)][row c]
+// so a layer's output registers ARE the next layer's B operands: k-step (mt', i') of the next
+// layer consumes register i' of m-tile mt', whose lane group g carries neuron nmap(mt', 4g+i').
+// The neuron->(m-tile, row) maps below put padding in whole registers so that a 40-wide layer
+// costs 10 k-steps (not 12) downstream.
+#pragma once
+#include <stdint.h>
+
+#ifndef BNN_HD
+#ifdef __HIPCC__
+#define BNN_HD __host__ __device__
+#else
+#define BNN_HD
+#endif
+#endif
+
+namespace bnn {
+
+constexpr int F = 41;  // input features per timestep
+constexpr int H = 40;  // hidden width
+constexpr int L = 20;  // latent width (feature_nn output)
+constexpr int S2 = 2 * L;
+
+// flat parameter vector offsets (reference state_dict order, spock_reg_model.py:734-761)
+constexpr int OFF_INLV = 0;
+constexpr int OFF_SUMLV = OFF_INLV + F;       // 41
+constexpr int OFF_W1 = OFF_SUMLV + S2;        // 81
+constexpr int OFF_B1 = OFF_W1 + H * F;        // 1721
+constexpr int OFF_W2 = OFF_B1 + H;            // 1761
+constexpr int OFF_B2 = OFF_W2 + H * H;        // 3361
+constexpr int OFF_W3 = OFF_B2 + H;            // 3401
+constexpr int OFF_B3 = OFF_W3 + L * H;        // 4201
+constexpr int OFF_W4 = OFF_B3 + L;            // 4221
+constexpr int OFF_B4 = OFF_W4 + H * S2;       // 5821
+constexpr int OFF_W5 = OFF_B4 + H;            // 5861
+constexpr int OFF_B5 = OFF_W5 + H * H;        // 7461
+constexpr int OFF_W6 = OFF_B5 + H;            // 7501
+constexpr int OFF_B6 = OFF_W6 + 2 * H;        // 7581
+constexpr int D = OFF_B6 + 2;                 // 7583
+constexpr int ZERO_IDX = D;                   // LDS slot that always holds 0.0f
+constexpr int FLAT_LDS = 7616;                // floats reserved for the flat vector (+zero slot, 16B multiple)
+
+constexpr int MAXK = 32;  // SWAG rank supported (reference uses K = 30, run_swag.py:37)
+
+// v50 mask: live columns {0, 8..37}
+constexpr uint64_t V50_ZERO_MASK = (1ull << 7) | (1ull << 3) | (1ull << 6) | (1ull << 38) | (1ull << 39) | (1ull << 40) |
+                                   (1ull << 1) | (1ull << 2) | (1ull << 4) | (1ull << 5);
+
+constexpr int COL_BIAS = -1;  // k slot fed with 1.0: carries the layer-1 bias
+constexpr int COL_PAD = -2;   // k slot fed with 0
+
+// 40-wide layers: three m-tiles; neurons 32..39 sit in registers i = 0,1 of m-tile 2.
+BNN_HD inline int nmap_hidden(int mt, int m) {
+    if (mt < 2) return 16 * mt + m;
+    int g = m >> 2, i = m & 3;
+    return i < 2 ? 32 + 2 * g + i : -1;
+}
+// 20-wide latent layer: two m-tiles; neurons 16..19 sit in register 0 of m-tile 1.
+BNN_HD inline int nmap_latent(int mt, int m) {
+    if (mt == 0) return m;
+    int g = m >> 2, i = m & 3;
+    return i == 0 ? 16 + g : -1;
+}
+// 2-wide output layer: one m-tile, rows 0 and 1.
+BNN_HD inline int nmap_out(int m) { return m < 2 ? m : -1; }
+
+// k-steps over a 40-wide activation: 10 steps (mt', i'): (0,0..3), (1,0..3), (2,0..1).
+constexpr int NKH = 10;
+BNN_HD inline int kmap_hidden(int ks, int g) {
+    int mt = ks >> 2, i = ks & 3;
+    return nmap_hidden(mt, 4 * g + i);
+}
+// k-steps over the 40-wide summary [mu_sample(20) | std_sample(20)]: ks = kind*5 + r, r<4: register r of
+// latent m-tile 0, r=4: register 0 of latent m-tile 1.
+BNN_HD inline int kmap_summary(int ks, int g) {
+    int kind = ks / 5, r = ks % 5;
+    int n = r < 4 ? 4 * g + r : 16 + g;
+    return kind * L + n;
+}
+// layer-1 k slots.  NK1 = 8 (v50 fast path: 31 live columns + bias = 32 slots): lane group g reads 8
+// consecutive floats of its row starting at column 8+8g; group 3 takes columns 32..37, then column 0, then bias.
+// NK1 = 11 (generic / noisy path): group g reads columns 11g..11g+10; slot 41 is the bias, 42,43 padding.
+BNN_HD inline int kmap_input(int nk1, int s, int g) {
+    if (nk1 == 8) {
+        if (g < 3) return 8 + 8 * g + s;
+        if (s < 6) return 32 + s;
+        return s == 6 ? 0 : COL_BIAS;
+    }
+    int q = 11 * g + s;
+    if (q < F) return q;
+    return q == F ? COL_BIAS : COL_PAD;
+}
+
+// fragment table indices (see bnn_tables.cpp)
+BNN_HD inline int nf1(int nk1) { return 3 * nk1 + 30 + 20 + 12 + 8; }
+constexpr int NF2 = 30 + 30 + 10 + 12 + 12 + 4;
+
+}  // namespace bnn

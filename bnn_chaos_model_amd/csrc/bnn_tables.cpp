@@ -1,0 +1,132 @@
+// bnn_tables.cpp -- builds the per-lane gather tables that turn the reference's flat parameter
+// vector (spock_reg_model.py:734-761 order) into v_mfma_f32_16x16x4_f32 A operands and C-init biases.
+#include "bnn_tables.h"
+
+namespace bnn {
+
+namespace {
+
+struct Builder {
+    std::vector<int16_t>& t;
+    int f = 0;
+    explicit Builder(std::vector<int16_t>& tab) : t(tab) {}
+    template <class Fn>
+    void frag(Fn idx_of_lane) {
+        for (int lane = 0; lane < 64; ++lane) t[(size_t)f * 64 + lane] = (int16_t)idx_of_lane(lane >> 4, lane & 15);
+        ++f;
+    }
+};
+
+}  // namespace
+
+Tables build_tables(uint64_t zero_mask, bool all_columns) {
+    Tables T;
+    const bool v50 = !all_columns && zero_mask == V50_ZERO_MASK;
+    T.nk1 = v50 ? 8 : 11;
+    const int nk1 = T.nk1;
+    auto dropped = [&](int col) { return !all_columns && ((zero_mask >> col) & 1ull); };
+
+    T.f1.assign((size_t)nf1(nk1) * 64, (int16_t)ZERO_IDX);
+    Builder b1(T.f1);
+    // layer 1 (feature_nn.0): A[s][mt], lane (g, m)
+    for (int s = 0; s < nk1; ++s)
+        for (int mt = 0; mt < 3; ++mt)
+            b1.frag([&](int g, int m) {
+                int n = nmap_hidden(mt, m), col = kmap_input(nk1, s, g);
+                if (n < 0 || col == COL_PAD) return ZERO_IDX;
+                if (col == COL_BIAS) return OFF_B1 + n;
+                if (dropped(col)) return ZERO_IDX;
+                return OFF_W1 + n * F + col;
+            });
+    // layer 2 (feature_nn.2)
+    for (int ks = 0; ks < NKH; ++ks)
+        for (int mt = 0; mt < 3; ++mt)
+            b1.frag([&](int g, int m) {
+                int n = nmap_hidden(mt, m), k = kmap_hidden(ks, g);
+                return (n < 0 || k < 0) ? ZERO_IDX : OFF_W2 + n * H + k;
+            });
+    // layer 3 (feature_nn.4)
+    for (int ks = 0; ks < NKH; ++ks)
+        for (int mt = 0; mt < 2; ++mt)
+            b1.frag([&](int g, int m) {
+                int n = nmap_latent(mt, m), k = kmap_hidden(ks, g);
+                return (n < 0 || k < 0) ? ZERO_IDX : OFF_W3 + n * H + k;
+            });
+    // C-init biases: lane (g, c) register i <-> neuron nmap(mt, 4g+i)
+    for (int mt = 0; mt < 3; ++mt)
+        for (int i = 0; i < 4; ++i)
+            b1.frag([&](int g, int) {
+                int n = nmap_hidden(mt, 4 * g + i);
+                return n < 0 ? ZERO_IDX : OFF_B2 + n;
+            });
+    for (int mt = 0; mt < 2; ++mt)
+        for (int i = 0; i < 4; ++i)
+            b1.frag([&](int g, int) {
+                int n = nmap_latent(mt, 4 * g + i);
+                return n < 0 ? ZERO_IDX : OFF_B3 + n;
+            });
+
+    T.f2.assign((size_t)NF2 * 64, (int16_t)ZERO_IDX);
+    Builder b2(T.f2);
+    // layer 4 (regress_nn.0): k over the summary vector
+    for (int ks = 0; ks < 10; ++ks)
+        for (int mt = 0; mt < 3; ++mt)
+            b2.frag([&](int g, int m) {
+                int n = nmap_hidden(mt, m), k = kmap_summary(ks, g);
+                return n < 0 ? ZERO_IDX : OFF_W4 + n * S2 + k;
+            });
+    // layer 5 (regress_nn.2)
+    for (int ks = 0; ks < NKH; ++ks)
+        for (int mt = 0; mt < 3; ++mt)
+            b2.frag([&](int g, int m) {
+                int n = nmap_hidden(mt, m), k = kmap_hidden(ks, g);
+                return (n < 0 || k < 0) ? ZERO_IDX : OFF_W5 + n * H + k;
+            });
+    // layer 6 (regress_nn.4)
+    for (int ks = 0; ks < NKH; ++ks)
+        b2.frag([&](int g, int m) {
+            int n = nmap_out(m), k = kmap_hidden(ks, g);
+            return (n < 0 || k < 0) ? ZERO_IDX : OFF_W6 + n * H + k;
+        });
+    for (int mt = 0; mt < 3; ++mt)
+        for (int i = 0; i < 4; ++i)
+            b2.frag([&](int g, int) {
+                int n = nmap_hidden(mt, 4 * g + i);
+                return n < 0 ? ZERO_IDX : OFF_B4 + n;
+            });
+    for (int mt = 0; mt < 3; ++mt)
+        for (int i = 0; i < 4; ++i)
+            b2.frag([&](int g, int) {
+                int n = nmap_hidden(mt, 4 * g + i);
+                return n < 0 ? ZERO_IDX : OFF_B5 + n;
+            });
+    for (int i = 0; i < 4; ++i)
+        b2.frag([&](int g, int) {
+            int n = nmap_out(4 * g + i);
+            return n < 0 ? ZERO_IDX : OFF_B6 + n;
+        });
+
+    // accumulation order = k-step major, lane group (the MFMA's k index) minor
+    for (int s = 0; s < nk1; ++s)
+        for (int g = 0; g < 4; ++g) {
+            int col = kmap_input(nk1, s, g);
+            if (col == COL_PAD) continue;
+            if (col == COL_BIAS) { T.order[0].push_back(-1); continue; }
+            if (dropped(col)) continue;
+            T.order[0].push_back(col);
+        }
+    for (int ks = 0; ks < NKH; ++ks)
+        for (int g = 0; g < 4; ++g) {
+            int k = kmap_hidden(ks, g);
+            if (k < 0) continue;
+            T.order[1].push_back(k);
+            T.order[2].push_back(k);
+            T.order[4].push_back(k);
+            T.order[5].push_back(k);
+        }
+    for (int ks = 0; ks < 10; ++ks)
+        for (int g = 0; g < 4; ++g) T.order[3].push_back(kmap_summary(ks, g));
+    return T;
+}
+
+}  // namespace bnn

@@ -1,0 +1,23 @@
+// bnn_tables.h -- host-side construction of the MFMA operand gather tables.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "bnn_layout.h"
+
+namespace bnn {
+
+// Entry [f * 64 + lane] = index into the LDS-resident flat parameter vector (ZERO_IDX for padding)
+// that lane `lane` loads into fragment register f.
+struct Tables {
+    int nk1;                   // layer-1 k-steps: 8 (v50 mask) or 11 (any mask / all 41 columns)
+    std::vector<int16_t> f1;   // nf1(nk1) * 64: feature_nn fragments + C-init biases
+    std::vector<int16_t> f2;   // NF2 * 64: regress_nn fragments + C-init biases
+    std::vector<int32_t> order[6];  // accumulation order per Linear layer (input index or -1 = bias)
+};
+
+// zero_mask: columns whose weights are dropped (their x is zeroed by the reference).
+// all_columns: keep every column's weight (noisy forward: masked columns carry pure noise).
+Tables build_tables(uint64_t zero_mask, bool all_columns);
+
+}  // namespace bnn

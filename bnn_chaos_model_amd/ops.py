@@ -1,0 +1,157 @@
+"""Tensor-level wrappers over the C ABI (include/bnn_chaos_hip.h).  Inputs/outputs are torch
+tensors on the GPU; work is enqueued on torch's current HIP stream; nothing here synchronises.
+
+Each function names the reference method it replaces (file:line in MilesCranmer/bnn_chaos_model).
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+D = 7583
+LATENT = 20
+V50_ZERO_MASK = sum(1 << c for c in (7, 3, 6, 38, 39, 40, 1, 2, 4, 5))
+
+_plans = {}
+
+
+def zero_mask_from_flags(fix_megno=False, fix_megno2=True, include_mmr=False, include_nan=False,
+                         include_eplusminus=False):
+    """Columns zeroed by zero_megno / zero_mmr / zero_nan / zero_eplusminus (spock_reg_model.py:452-500)."""
+    cols = []
+    if fix_megno or fix_megno2:
+        cols += [7]
+    if not include_mmr:
+        cols += [3, 6]
+    if not include_nan:
+        cols += [38, 39, 40]
+    if not include_eplusminus:
+        cols += [1, 2, 4, 5]
+    return sum(1 << c for c in set(cols))
+
+
+def get_plan(zero_mask=V50_ZERO_MASK, lowest_std=0.5, device=None):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (dev, int(zero_mask), float(lowest_std))
+    if key not in _plans:
+        with torch.cuda.device(dev):
+            _plans[key] = N.Plan(int(zero_mask), float(lowest_std))
+    return _plans[key]
+
+
+def _f32(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f"{name}: expected a float32 GPU tensor, got {t.dtype} on {t.device}")
+    return t.contiguous()
+
+
+def _grid(B, T, J, nchunks, spb):
+    return N.BnnGrid(int(B), int(T), int(J), int(nchunks), int(spb))
+
+
+def swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, scale=0.5, philox_seed=0, draw_id0=0, plan=None):
+    """SWAGModel.sample_weights (spock_reg_model.py:815-838) for J draws -> W[J, d].
+
+    w_avg, w2_avg [S,d]; pre_D [S,d,K]; seed_idx [J] int32; z1 [J,d] / z2 [J,K] explicit normals or None (Philox)."""
+    plan = plan or get_plan()
+    w_avg, w2_avg, pre_D = _f32(w_avg, "w_avg"), _f32(w2_avg, "w2_avg"), _f32(pre_D, "pre_D")
+    S, d, K = pre_D.shape
+    if d != plan.d or w_avg.shape != (S, d) or w2_avg.shape != (S, d):
+        raise ValueError("ensemble tensors have inconsistent shapes")
+    seed_idx = seed_idx.to(device=w_avg.device, dtype=torch.int32).contiguous()
+    J = seed_idx.numel()
+    z1, z2 = _f32(z1, "z1"), _f32(z2, "z2")
+    if z1 is not None and (z1.shape != (J, d) or z2.shape != (J, K)):
+        raise ValueError("z1 must be [J,d] and z2 [J,K]")
+    W = torch.empty((J, d), dtype=torch.float32, device=w_avg.device)
+    N.check(N.lib().bnn_swag_draw_f32(plan.handle, N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K, N.ptr(seed_idx), J,
+                                      N.ptr(z1), N.ptr(z2), float(scale), int(philox_seed), int(draw_id0), N.ptr(W),
+                                      N.stream_ptr()))
+    return W
+
+
+def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0, draw_id0=0, system_id0=0, plan=None,
+            debug=False, systems_per_block=0):
+    """VarModel.forward (spock_reg_model.py:486-528) for materialised weight vectors W[J,d] -> out[J/nchunks,B,2].
+
+    eps [R,B,2,20] = the two randn_like of compute_summary_stats (:426-427) or None (Philox);
+    eps_in [R,B,T,41] + eps_sum [R,B,40] switch on noisy_val=True (:444-450)."""
+    plan = plan or get_plan()
+    x, W = _f32(x, "x"), _f32(W, "W")
+    if x.dim() != 3 or x.shape[2] != 41:
+        raise NotImplementedError("x must be [B, T, 41]")  # figures/spock/regression.py:210-211
+    B, T, _ = x.shape
+    J = W.shape[0]
+    R = J // nchunks
+    eps, eps_in, eps_sum = _f32(eps, "eps"), _f32(eps_in, "eps_in"), _f32(eps_sum, "eps_sum")
+    if eps is not None and tuple(eps.shape) != (R, B, 2, LATENT):
+        raise ValueError(f"eps must be [{R},{B},2,{LATENT}]")
+    out = torch.empty((R, B, 2), dtype=torch.float32, device=x.device)
+    pre = torch.empty_like(out) if debug else None
+    summ = torch.empty((R, B, 2 * LATENT), dtype=torch.float32, device=x.device) if debug else None
+    g = _grid(B, T, J, nchunks, systems_per_block)
+    N.check(N.lib().bnn_forward_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(W), N.ptr(eps), N.ptr(eps_in), N.ptr(eps_sum),
+                                    int(philox_seed), int(draw_id0), int(system_id0), N.ptr(out), N.ptr(pre), N.ptr(summ),
+                                    N.stream_ptr()))
+    return (out, pre, summ) if debug else out
+
+
+def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nchunks=1, scale=0.5, philox_seed=0,
+              draw_id0=0, system_id0=0, plan=None, debug=False, systems_per_block=0, out=None):
+    """Fused SWAGModel.forward_swag_fast (spock_reg_model.py:878-908) over the MC loop of
+    figures/multiswag_5_planet.py:295-298 -> out[J/nchunks, B, 2]."""
+    plan = plan or get_plan()
+    x = _f32(x, "x")
+    if x.dim() != 3 or x.shape[2] != 41:
+        raise NotImplementedError("x must be [B, T, 41]")
+    w_avg, w2_avg, pre_D = _f32(w_avg, "w_avg"), _f32(w2_avg, "w2_avg"), _f32(pre_D, "pre_D")
+    S, d, K = pre_D.shape
+    B, T, _ = x.shape
+    seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()
+    J = seed_idx.numel()
+    R = J // nchunks
+    z1, z2, eps = _f32(z1, "z1"), _f32(z2, "z2"), _f32(eps, "eps")
+    if z1 is not None and (tuple(z1.shape) != (J, d) or tuple(z2.shape) != (J, K)):
+        raise ValueError("z1 must be [J,d] and z2 [J,K]")
+    if eps is not None and tuple(eps.shape) != (R, B, 2, LATENT):
+        raise ValueError(f"eps must be [{R},{B},2,{LATENT}]")
+    if out is None:
+        out = torch.empty((R, B, 2), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (R, B, 2) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out has the wrong shape/dtype")
+    pre = torch.empty_like(out) if debug else None
+    summ = torch.empty((R, B, 2 * LATENT), dtype=torch.float32, device=x.device) if debug else None
+    g = _grid(B, T, J, nchunks, systems_per_block)
+    N.check(N.lib().bnn_multiswag_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
+                                      N.ptr(seed_idx), N.ptr(z1), N.ptr(z2), N.ptr(eps), float(scale), int(philox_seed),
+                                      int(draw_id0), int(system_id0), N.ptr(out), N.ptr(pre), N.ptr(summ), N.stream_ptr()))
+    return (out, pre, summ) if debug else out
+
+
+def moments(samples, mom=None):
+    """samples [R,B,2] -> float64 [B,4] = sum mu, sum mu^2, sum std, sum std^2 (accumulates into `mom` if given)."""
+    samples = _f32(samples, "samples")
+    R, B, _ = samples.shape
+    acc = mom is not None
+    if mom is None:
+        mom = torch.empty((B, 4), dtype=torch.float64, device=samples.device)
+    N.check(N.lib().bnn_moments_f64(N.ptr(samples), R, B, N.ptr(mom), int(acc), N.stream_ptr()))
+    return mom
+
+
+def philox_normal(kind, philox_seed, id0, n_rows, width=0, B=0, system_id0=0, device="cuda"):
+    """The normals the kernels generate in-kernel: kind 0 -> z1[n_rows,width], 1 -> z2[n_rows,width], 2 -> eps[n_rows,B,2,20]."""
+    shape = (n_rows, B, 2, LATENT) if kind == 2 else (n_rows, width)
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    N.check(N.lib().bnn_philox_normal_f32(kind, int(philox_seed), int(id0), n_rows, B, int(system_id0), width, N.ptr(out),
+                                          N.stream_ptr()))
+    return out
+
+
+def philox_raw(ctr, key, n, device="cuda"):
+    out = torch.empty((n, 4), dtype=torch.int32, device=device)
+    N.check(N.lib().bnn_philox_raw_u32(*[int(c) for c in ctr], int(key[0]), int(key[1]), n, N.ptr(out), N.stream_ptr()))
+    return out

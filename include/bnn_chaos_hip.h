@@ -1,0 +1,132 @@
+/*
+ * bnn_chaos_hip.h -- C ABI of the MI355X (gfx950) MultiSWAG inference library.
+ *
+ * The reference (MilesCranmer/bnn_chaos_model) is pure Python: it has no FFI.  The boundary it
+ * offers for this path is the Python object surface of spock_reg_model.py.
+ * The entry points below are the native layer under that surface: one per reference method on the
+ * path, each cited.  bnn_chaos_model_amd/_native.py binds them with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes; every data pointer is a DEVICE pointer unless named host_*;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only enqueues
+ *     work on it: no allocation, no host synchronisation (plans excepted, see below);
+ *   - return value 0 = success, negative = bnn_status; bnn_last_error() returns a message for the
+ *     calling thread's most recent failure;
+ *   - all arithmetic is IEEE fp32, round-to-nearest, no fast-math.
+ *
+ * Flat parameter vector (d = 7583 floats), the reference's state_dict order
+ * (spock_reg_model.py:734-761): input_noise_logvar[41] | summary_noise_logvar[40] |
+ * feature_nn.{0,2,4}.{weight,bias} | regress_nn.{0,2,4}.{weight,bias}.
+ */
+#ifndef BNN_CHAOS_HIP_H
+#define BNN_CHAOS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BNN_ABI_VERSION 1
+
+enum bnn_status {
+    BNN_OK = 0,
+    BNN_ERR_INVALID = -1,     /* NULL pointer / negative size / inconsistent arguments            */
+    BNN_ERR_UNSUPPORTED = -2, /* architecture other than 41->40->40->20 / 40->40->40->2, T%4 != 0 */
+    BNN_ERR_HIP = -3,         /* a HIP runtime call failed (message has the hipError string)      */
+    BNN_ERR_NO_DEVICE = -4,   /* no gfx950 device visible                                         */
+    BNN_ERR_RANGE = -5        /* seed index outside the ensemble, K > 32, ...                     */
+};
+
+/* Network description, from the checkpoint's hparams (spock_reg_model.py:343-397). */
+typedef struct bnn_arch {
+    int32_t n_features; /* hparams['time_series_features'] = 41                                  */
+    int32_t hidden;     /* hparams['hidden'] = 40                                                */
+    int32_t latent;     /* hparams['latent'] = 20                                                */
+    int32_t reserved;
+    uint64_t zero_mask; /* bit f set: input column f is zeroed before feature_nn
+                           (zero_megno/zero_mmr/zero_nan/zero_eplusminus, spock_reg_model.py:452-500) */
+    float lowest_std;   /* soft_clamp floor of std: 0.5, or 0.1 with lower_std (:363-365)         */
+    float pad;
+} bnn_arch;
+
+typedef struct bnn_plan bnn_plan; /* opaque: device-resident operand tables for one bnn_arch */
+
+int bnn_abi_version(void);
+const char* bnn_last_error(void);
+int bnn_device_count(void); /* number of visible HIP devices, or negative bnn_status */
+int bnn_param_count(const bnn_arch* arch); /* d (7583), or negative */
+
+/* Plans own a few KB of device memory; create/destroy allocate and synchronise, nothing else does. */
+int bnn_plan_create(const bnn_arch* arch, bnn_plan** out);
+int bnn_plan_destroy(bnn_plan* plan);
+/* Accumulation order used by the kernels for Linear layer `layer` (0..5): `order` receives up to
+ * `cap` entries (input index, or -1 for the bias term; no -1 => accumulator starts at the bias).
+ * `noisy` selects the 41-column variant used by bnn_forward_f32 with eps_in != NULL.
+ * Returns the number of entries.  Lets a test pin a CPU model to the same order. */
+int bnn_plan_layer_order(const bnn_plan* plan, int layer, int noisy, int32_t* host_order, int cap);
+
+/* Everything one MultiSWAG evaluation needs besides the ensemble and the noise. */
+typedef struct bnn_grid {
+    int64_t B;       /* systems (rows of x)                                                        */
+    int32_t T;       /* timesteps per system (100); T % 4 == 0                                     */
+    int32_t J;       /* weight draws                                                               */
+    int32_t nchunks; /* draw e covers chunk e % nchunks of the systems (torch.chunk semantics,
+                        chunk size ceil(B/nchunks)) and writes output row e / nchunks.
+                        1 = every draw covers all systems (dense systems x draws grid).
+                        figures/multiswag_5_planet.py:295-298 is nchunks = 10.                     */
+    int32_t systems_per_block; /* 0 = choose; else a multiple of 64                                */
+} bnn_grid;
+
+/* SWAGModel.sample_weights (spock_reg_model.py:815-838), J draws at once.
+ *   w_avg, w2_avg [S,d]; pre_D [S,d,K]; seed_idx [J] int32 (which ensemble member each draw uses:
+ *   figures/spock/regression.py:78); z1 [J,d], z2 [J,K] = the reference's randn((1,d)), randn((K,1))
+ *   per draw, or both NULL to generate them in-kernel from Philox4x32-10 keyed by philox_seed
+ *   (counter = draw_id0 + e, element) -- see bnn_philox_normal_f32.  W_out [J,d]. */
+int bnn_swag_draw_f32(const bnn_plan* plan, const float* w_avg, const float* w2_avg, const float* pre_D,
+                      int32_t S, int32_t K, const int32_t* seed_idx, int32_t J, const float* z1,
+                      const float* z2, float scale, uint64_t philox_seed, int64_t draw_id0, float* W_out,
+                      void* stream);
+
+/* VarModel.forward (spock_reg_model.py:486-528) for J already-materialised weight vectors.
+ *   x [B,T,41] fp32 contiguous; W [J,d]; out [J/nchunks, B, 2] = cat(mu, std).
+ *   eps [J/nchunks, B, 2, 20]: the two randn_like draws of compute_summary_stats (:426-427), or NULL
+ *   for in-kernel Philox.  eps_in [J/nchunks,B,T,41] (:445) and eps_sum [J/nchunks,B,40] (:449):
+ *   both non-NULL = forward(noisy_val=True); both NULL = noisy_val=False / forward_swag_fast.
+ *   Optional debug outputs (may be NULL): pre_clamp [J/nchunks,B,2] = regress_nn output,
+ *   summary [J/nchunks,B,40] = compute_summary_stats output. */
+int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps,
+                    const float* eps_in, const float* eps_sum, uint64_t philox_seed, int64_t draw_id0,
+                    int64_t system_id0, float* out, float* pre_clamp, float* summary, void* stream);
+
+/* Fused SWAGModel.forward_swag_fast (spock_reg_model.py:878-908) over the MC driver loop
+ * (figures/spock/regression.py:74-92 inside figures/multiswag_5_planet.py:295-298 /
+ * figures/main_figures.py:154-156): per draw, sample the weights in the kernel prologue (same
+ * arithmetic as bnn_swag_draw_f32, bit for bit), keep them on chip, stream x once, write (mu, std).
+ * system_id0 = global index of x row 0 (Philox counters use global ids so results do not depend on
+ * how systems are sharded over GPUs). */
+int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg,
+                      const float* w2_avg, const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx,
+                      const float* z1, const float* z2, const float* eps, float scale, uint64_t philox_seed,
+                      int64_t draw_id0, int64_t system_id0, float* out, float* pre_clamp, float* summary,
+                      void* stream);
+
+/* Predictive moments over draws: samples [R,B,2] -> moments [B,4] (float64):
+ * sum mu, sum mu^2, sum std, sum std^2 over r, in r order (deterministic).  accumulate != 0 adds to
+ * the existing contents (for processing draws in slabs). */
+int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments, int32_t accumulate, void* stream);
+
+/* The normals the kernels generate when a noise pointer is NULL, written out for inspection:
+ *   kind 0: z1 [n_draws, d]   kind 1: z2 [n_draws, K]   kind 2: eps [n_draws(rows), B, 2, 20]
+ *   id0 = draw_id0 (kinds 0,1) or output-row id0 (kind 2); system_id0 only for kind 2. */
+int bnn_philox_normal_f32(int32_t kind, uint64_t philox_seed, int64_t id0, int64_t n_rows, int64_t B,
+                          int64_t system_id0, int32_t width, float* out, void* stream);
+
+/* Raw Philox4x32-10 blocks for known-answer tests: out[n][4] = philox(ctr = {c0+i, c1, c2, c3}, key). */
+int bnn_philox_raw_u32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int64_t n,
+                       uint32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNN_CHAOS_HIP_H */
