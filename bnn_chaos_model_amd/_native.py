@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede loading the HIP library)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libbnn_chaos_hip.so")
+SO_PATH = os.environ.get("BNN_CHAOS_SO") or os.path.join(_HERE, "csrc", "libbnn_chaos_hip.so")  # override: A/B builds
 
 BNN_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_RANGE = -1, -2, -3, -4, -5

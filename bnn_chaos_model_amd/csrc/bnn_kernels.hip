@@ -45,6 +45,13 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
 #define DEVINL __device__ __forceinline__
 
+#ifndef BNN_PRIO_STAGGER
+#define BNN_PRIO_STAGGER 0
+#endif
+#ifndef BNN_WAVES_PER_SIMD
+#define BNN_WAVES_PER_SIMD 2  // register budget of the main kernel: 2 -> 256 VGPRs, 3 -> 168
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11) and the normals derived from it.
 // Counters use GLOBAL draw / output-row / system ids, so results are invariant to sharding.
@@ -121,16 +128,24 @@ struct FwdParams {
     float* summary;
     const int16_t* tab_f1;
     const int16_t* tab_f2;
+    const float* rcp_tab;  // [i] = 1/(i+1), correctly rounded
     uint64_t zero_mask;
     float std_lo, std_span;
 };
 
 DEVINL f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// nn.ReLU as ONE integer max on the bit pattern: negative floats (and -0.0) are negative ints -> +0.0.
+DEVINL float relu1(float v) {
+    int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+// registers 2,3 of m-tile 2 are padding (nmap_hidden) and never consumed: NLIVE = 2 there
+template <int NLIVE = 4>
 DEVINL f32x4 relu4(f32x4 v) {
-    f32x4 o;
+    f32x4 o = v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = fmaxf(v[i], 0.0f);
+    for (int i = 0; i < NLIVE; ++i) o[i] = relu1(v[i]);
     return o;
 }
 
@@ -204,30 +219,46 @@ template <int NK1>
 struct XTile {
     float v[NK1];
 };
+// Raw loaded registers.  The selects that build the B operands are applied at USE time (xtile()), never at
+// load time: a select right after the load makes the compiler wait for the data there, which turns the
+// one-tile-ahead prefetch into a stall of a full memory latency per tile.
+template <int NK1>
+struct XRaw {
+    f32x4 a, b;
+    f32x3 c;  // NK1 == 8: c.x = column 0
+};
 
 template <int NK1>
-DEVINL XTile<NK1> load_x(const float* __restrict__ rowp, int g) {
-    XTile<NK1> t;
+DEVINL XRaw<NK1> load_x(const float* __restrict__ rowp, int g) {
+    XRaw<NK1> t;
     if constexpr (NK1 == 8) {
         const float* p = rowp + 8 + 8 * g;
-        f32x4 a = *reinterpret_cast<const f32x4u*>(p);
-        f32x4 b = *reinterpret_cast<const f32x4u*>(p + 4);  // group 3: columns 36..39, 38/39 replaced below
-        float x0 = rowp[0];
-        t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w;
-        t.v[4] = b.x; t.v[5] = b.y;
-        t.v[6] = (g == 3) ? x0 : b.z;
-        t.v[7] = (g == 3) ? 1.0f : b.w;
+        t.a = *reinterpret_cast<const f32x4u*>(p);
+        t.b = *reinterpret_cast<const f32x4u*>(p + 4);  // group 3: columns 36..39, 38/39 replaced in xtile()
+        t.c.x = rowp[0];
     } else {
         const float* p = rowp + 11 * g;
-        f32x4 a = *reinterpret_cast<const f32x4u*>(p);
-        f32x4 b = *reinterpret_cast<const f32x4u*>(p + 4);
+        t.a = *reinterpret_cast<const f32x4u*>(p);
+        t.b = *reinterpret_cast<const f32x4u*>(p + 4);
         const float* pc = (g == 3) ? rowp + 38 : p + 8;  // group 3 has no columns 41..43: stay inside the row
-        f32x3 c = *reinterpret_cast<const f32x3u*>(pc);
-        t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w;
-        t.v[4] = b.x; t.v[5] = b.y; t.v[6] = b.z; t.v[7] = b.w;
-        t.v[8] = (g == 3) ? 1.0f : c.x;  // slot 41 = bias
-        t.v[9] = (g == 3) ? 0.0f : c.y;
-        t.v[10] = (g == 3) ? 0.0f : c.z;
+        t.c = *reinterpret_cast<const f32x3u*>(pc);
+    }
+    return t;
+}
+
+template <int NK1>
+DEVINL XTile<NK1> xtile(const XRaw<NK1>& r, int g) {
+    XTile<NK1> t;
+    t.v[0] = r.a.x; t.v[1] = r.a.y; t.v[2] = r.a.z; t.v[3] = r.a.w;
+    t.v[4] = r.b.x; t.v[5] = r.b.y;
+    if constexpr (NK1 == 8) {
+        t.v[6] = (g == 3) ? r.c.x : r.b.z;   // slot (6, group 3) = column 0
+        t.v[7] = (g == 3) ? 1.0f : r.b.w;    // slot (7, group 3) = bias
+    } else {
+        t.v[6] = r.b.z; t.v[7] = r.b.w;
+        t.v[8] = (g == 3) ? 1.0f : r.c.x;    // slot 41 = bias
+        t.v[9] = (g == 3) ? 0.0f : r.c.y;
+        t.v[10] = (g == 3) ? 0.0f : r.c.z;
     }
     return t;
 }
@@ -236,12 +267,12 @@ DEVINL XTile<NK1> load_x(const float* __restrict__ rowp, int g) {
 // the fused kernel
 // ------------------------------------------------------------------------------------------------
 template <int NK1, bool NOISY, bool FUSED>
-__global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, BNN_WAVES_PER_SIMD) void bnn_multiswag_kernel(const FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot
     float* zsh = lds + FLAT_LDS;       // [MAXK]
-    float* slabs = zsh + MAXK;         // [4][SLAB] pre_D staging during a fused draw ...
-    float* f2frag = slabs;             // ... then [NF2][64] regress_nn operands in fragment order
+    float* slabs = zsh + MAXK;         // [4][SLAB] pre_D staging (FUSED only)
+    float* f2frag = lds;               // [NF2][64] regress_nn operands in fragment order: OVERWRITES flat (below)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -295,17 +326,33 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p
 #pragma unroll
     for (int f = 0; f < NF1; ++f) wf[f] = flat[p.tab_f1[f * 64 + lane]];
 
-    // regress_nn operands -> LDS in fragment order (read back with immediate offsets, once per 16 systems)
-    for (int f = wave; f < NF2; f += 4) f2frag[f * 64 + lane] = flat[p.tab_f2[f * 64 + lane]];
-    __syncthreads();
-
-    float in_scale[NOISY ? NK1 : 1];
+    float in_scale[NOISY ? NK1 : 1], sum_scale[NOISY ? 10 : 1];
     if constexpr (NOISY) {
 #pragma unroll
         for (int s = 0; s < NK1; ++s) {
             int col = 11 * g + s;
             in_scale[s] = col < F ? expf(flat[OFF_INLV + col] / 2.0f) : 0.0f;  // exp(logvar/2), :445
         }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) sum_scale[k] = expf(flat[OFF_SUMLV + kmap_summary(k, g)] / 2.0f);  // :449
+    }
+    // regress_nn operands -> LDS in fragment order (read back with immediate offsets, once per 16 systems).
+    // They replace the flat vector in place: gather to registers, barrier, write.
+    {
+        constexpr int PER = (NF2 + 3) / 4;
+        float tmp[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int f = wave + 4 * i;
+            tmp[i] = f < NF2 ? flat[p.tab_f2[f * 64 + lane]] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int f = wave + 4 * i;
+            if (f < NF2) f2frag[f * 64 + lane] = tmp[i];
+        }
+        __syncthreads();
     }
 
     const int T = p.T, ntiles = p.ntiles;
@@ -313,6 +360,11 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p
     const float half_n0 = (float)ntiles * 0.5f;
     const int64_t rowstride = (int64_t)T * F;
 
+#if BNN_PRIO_STAGGER
+    // Waves that share a SIMD run the same program and fall into lockstep (both in their VALU phase, then both
+    // wanting the matrix pipe).  Give odd hardware wave slots priority so the partner fills the gaps instead.
+    if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(BNN_PRIO_STAGGER);
+#endif
     // ---- wave-batches of 16 systems
     for (int64_t wb0 = b0 + (int64_t)wave * 16; wb0 < b1; wb0 += 64) {
         float skeep[10];
@@ -331,17 +383,12 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p
             f32x4 mean0 = {0, 0, 0, 0}, m20 = {0, 0, 0, 0};
             float mean1 = 0.0f, m21 = 0.0f;
 
-            XTile<NK1> cur = load_x<NK1>(rowp, g);
-            XTile<NK1> ncur;
-            if constexpr (NOISY) ncur = load_x<NK1>(epin, g);
-            for (int it = 0; it < ntiles; ++it) {
-                XTile<NK1> nxt = cur, nnxt;
-                if (it + 1 < ntiles) {
-                    nxt = load_x<NK1>(rowp + (int64_t)(it + 1) * 4 * F, g);
-                    if constexpr (NOISY) nnxt = load_x<NK1>(epin + (int64_t)(it + 1) * 4 * F, g);
-                }
+            // One 16-row tile: feature_nn on the matrix pipe, then the running time-pool statistics.
+            auto do_tile = [&](const XRaw<NK1>& raw, const XRaw<NK1>& nraw, const int it) {
+                XTile<NK1> cur = xtile<NK1>(raw, g);
                 if constexpr (NOISY) {
                     // masks then add_input_noise (:486-504): masked columns become pure noise
+                    XTile<NK1> ncur = xtile<NK1>(nraw, g);
 #pragma unroll
                     for (int s = 0; s < NK1; ++s) {
                         int col = 11 * g + s;
@@ -357,8 +404,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p
                 for (int s = 0; s < NK1; ++s)
 #pragma unroll
                     for (int mt = 0; mt < 3; ++mt) h[mt] = mfma(wf[s * 3 + mt], cur.v[s], h[mt]);
-#pragma unroll
-                for (int mt = 0; mt < 3; ++mt) h[mt] = relu4(h[mt]);
+                h[0] = relu4(h[0]); h[1] = relu4(h[1]); h[2] = relu4<2>(h[2]);
                 // feature_nn.2 + ReLU
                 f32x4 h2[3];
 #pragma unroll
@@ -367,8 +413,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p
                 for (int ks = 0; ks < NKH; ++ks)
 #pragma unroll
                     for (int mt = 0; mt < 3; ++mt) h2[mt] = mfma(wf[IW2 + ks * 3 + mt], h[ks >> 2][ks & 3], h2[mt]);
-#pragma unroll
-                for (int mt = 0; mt < 3; ++mt) h2[mt] = relu4(h2[mt]);
+                h2[0] = relu4(h2[0]); h2[1] = relu4(h2[1]); h2[2] = relu4<2>(h2[2]);
                 // feature_nn.4
                 f32x4 y[2];
 #pragma unroll
@@ -377,8 +422,9 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p
                 for (int ks = 0; ks < NKH; ++ks)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) y[mt] = mfma(wf[IW3 + ks * 2 + mt], h2[ks >> 2][ks & 3], y[mt]);
-                // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
-                const float rcn = 1.0f / (float)(it + 1);
+                // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps;
+                // 1/(it+1) comes correctly rounded from a table (uniform address -> scalar load)
+                const float rcn = p.rcp_tab[it];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float dl = y[0][i] - mean0[i];
@@ -392,9 +438,27 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p
                     m21 = m21 + dl * (y[1][0] - mn);
                     mean1 = mn;
                 }
-                cur = nxt;
-                if constexpr (NOISY) ncur = nnxt;
+            };
+            // Prefetch one tile ahead into a ping-pong pair of register sets (no loop-carried copies).  The empty
+            // asm with a memory clobber keeps each load where it is written: without it InstCombine folds
+            // phi(load, load) into a load of phi(addresses) in front of the first use, and the scheduler sinks it.
+            auto prefetch = [&](XRaw<NK1>& raw, XRaw<NK1>& nraw, int it) {
+                const int itc = it < ntiles ? it : ntiles - 1;  // past the end: re-read the last tile (no overrun)
+                raw = load_x<NK1>(rowp + (int64_t)itc * 4 * F, g);
+                if constexpr (NOISY) nraw = load_x<NK1>(epin + (int64_t)itc * 4 * F, g);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            XRaw<NK1> rawA, rawB, nrawA, nrawB;
+            prefetch(rawA, nrawA, 0);
+            int it = 0;
+            for (; it + 1 < ntiles; it += 2) {
+                prefetch(rawB, nrawB, it + 1);
+                do_tile(rawA, nrawA, it);
+                prefetch(rawA, nrawA, it + 2);
+                do_tile(rawB, nrawB, it + 1);
             }
+            if (it < ntiles) do_tile(rawA, nrawA, it);
 
             // merge the 4 lanes of a quad (timesteps t = 4*it + (c&3)): equal-count Chan update, symmetric
             float mean[5] = {mean0[0], mean0[1], mean0[2], mean0[3], mean1};
@@ -469,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p
 #pragma unroll
             for (int k = 0; k < 10; ++k) {
                 int n = kmap_summary(k, g);
-                skeep[k] = skeep[k] + es[n] * expf(flat[OFF_SUMLV + n] / 2.0f);
+                skeep[k] = skeep[k] + es[n] * sum_scale[k];
             }
         }
         const float* f2l = f2frag + lane;
@@ -481,16 +545,14 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag_kernel(const FwdParams p
         for (int ks = 0; ks < 10; ++ks)
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(ks * 3 + mt), skeep[ks], a4[mt]);
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt) a4[mt] = relu4(a4[mt]);
+        a4[0] = relu4(a4[0]); a4[1] = relu4(a4[1]); a4[2] = relu4<2>(a4[2]);
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) a5[mt] = (f32x4){W2f(82 + mt * 4), W2f(83 + mt * 4), W2f(84 + mt * 4), W2f(85 + mt * 4)};
 #pragma unroll
         for (int ks = 0; ks < NKH; ++ks)
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(30 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt) a5[mt] = relu4(a5[mt]);
+        a5[0] = relu4(a5[0]); a5[1] = relu4(a5[1]); a5[2] = relu4<2>(a5[2]);
         a6 = (f32x4){W2f(94), W2f(95), W2f(96), W2f(97)};
 #pragma unroll
         for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(60 + ks), a5[ks >> 2][ks & 3], a6);
@@ -569,8 +631,11 @@ struct bnn_plan {
     Tables tab[2];  // [0] = arch mask, [1] = all 41 columns (noisy forward)
     int16_t* d_f1[2] = {nullptr, nullptr};
     int16_t* d_f2[2] = {nullptr, nullptr};
+    float* d_rcp = nullptr;  // [RCP_N] 1/(i+1)
     int device = 0;
 };
+
+constexpr int RCP_N = 4096;  // supports T up to 16384 timesteps
 
 static int check_arch(const bnn_arch* a) {
     if (!a) return fail(BNN_ERR_INVALID, "arch is NULL");
@@ -618,6 +683,15 @@ int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
             return fail(BNN_ERR_HIP, "plan table upload failed");
         }
     }
+    {
+        std::vector<float> rc(RCP_N);
+        for (int i = 0; i < RCP_N; ++i) rc[i] = 1.0f / (float)(i + 1);
+        if (hipMalloc(&pl->d_rcp, RCP_N * sizeof(float)) != hipSuccess ||
+            hipMemcpy(pl->d_rcp, rc.data(), RCP_N * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            bnn_plan_destroy(pl);
+            return fail(BNN_ERR_HIP, "plan table upload failed");
+        }
+    }
     *out = pl;
     return 0;
 }
@@ -628,6 +702,7 @@ int bnn_plan_destroy(bnn_plan* pl) {
         if (pl->d_f1[v]) (void)hipFree(pl->d_f1[v]);
         if (pl->d_f2[v]) (void)hipFree(pl->d_f2[v]);
     }
+    if (pl->d_rcp) (void)hipFree(pl->d_rcp);
     delete pl;
     return 0;
 }
@@ -654,7 +729,7 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     if (!pl || !g) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
     if (g->B < 0 || g->J < 0 || g->nchunks < 1) return fail(BNN_ERR_INVALID, "negative size");
     if (g->J % g->nchunks) return fail(BNN_ERR_INVALID, "J must be a multiple of nchunks");
-    if (g->T < 8 || (g->T % 4)) return fail(BNN_ERR_UNSUPPORTED, "T must be a multiple of 4 and >= 8");
+    if (g->T < 8 || (g->T % 4) || g->T / 4 > RCP_N) return fail(BNN_ERR_UNSUPPORTED, "T must be a multiple of 4 in [8, 16384]");
     if (g->systems_per_block < 0 || (g->systems_per_block % 64)) return fail(BNN_ERR_INVALID, "systems_per_block must be a multiple of 64");
     if (g->B == 0 || g->J == 0) return 0;
     if (!p.x || !p.out) return fail(BNN_ERR_INVALID, "x/out is NULL");
@@ -664,14 +739,14 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     p.csz = (g->B + g->nchunks - 1) / g->nchunks;
     p.spc = pick_spc(g, p.csz);
     p.row_id0 = p.draw_id0 / g->nchunks;
-    p.tab_f1 = pl->d_f1[v]; p.tab_f2 = pl->d_f2[v];
+    p.tab_f1 = pl->d_f1[v]; p.tab_f2 = pl->d_f2[v]; p.rcp_tab = pl->d_rcp;
     p.zero_mask = pl->arch.zero_mask;
     p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);
     const int64_t nsub = (p.csz + p.spc - 1) / p.spc;
     const int64_t nblk = nsub * g->J;
     if (nblk > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "grid too large; split the draws");
-    const size_t shmem = sizeof(float) * (FLAT_LDS + MAXK + 4 * SLAB);
-    static_assert(NF2 * 64 <= 4 * SLAB, "regress_nn fragments alias the pre_D staging slabs");
+    const size_t shmem = sizeof(float) * (FLAT_LDS + MAXK + (fused ? 4 * SLAB : 0));
+    static_assert(NF2 * 64 <= FLAT_LDS, "regress_nn fragments overwrite the flat vector in place");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)nblk), block(256);
     const int nk1 = pl->tab[v].nk1;

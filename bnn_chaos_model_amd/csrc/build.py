@@ -26,16 +26,24 @@ def stale():
     return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not stale():
-        return SO
-    cmd = [hipcc()] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(HERE, s) for s in SRCS] + ["-o", SO + ".tmp"]
+def build(force=False, verbose=False, extra=(), out=None):
+    """extra: additional hipcc flags (e.g. -DBNN_WAVES_PER_SIMD=3); out: alternative .so name for A/B builds."""
+    so = SO if out is None else os.path.join(HERE, out)
+    if not force and out is None and not stale():
+        return so
+    cmd = [hipcc()] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(HERE, s) for s in SRCS] + ["-o", so + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=HERE)
-    os.replace(SO + ".tmp", SO)
-    return SO
+    os.replace(so + ".tmp", so)
+    return so
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    out = None
+    if "-o" in args:
+        i = args.index("-o")
+        out = args[i + 1]
+        del args[i:i + 2]
+    print(build(force=True, verbose=True, extra=args, out=out))
