@@ -50,6 +50,8 @@ def lib():
     L.bnn_plan_destroy.argtypes = [_vp]
     L.bnn_plan_layer_order.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int]
     L.bnn_param_count.argtypes = [C.POINTER(BnnArch)]
+    L.bnn_layer_order.argtypes = [C.POINTER(BnnArch), C.c_int, C.c_int, _vp, C.c_int]
+    L.bnn_fragment_table.argtypes = [C.POINTER(BnnArch), C.c_int, C.c_int, _vp, C.c_int]
     L.bnn_swag_draw_f32.argtypes = [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_float,
                                     C.c_uint64, C.c_int64, _vp, _vp]
     L.bnn_forward_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64,
@@ -67,7 +69,7 @@ def lib():
 
 
 EXPORTS = ("bnn_abi_version", "bnn_last_error", "bnn_device_count", "bnn_param_count", "bnn_plan_create",
-           "bnn_plan_destroy", "bnn_plan_layer_order", "bnn_swag_draw_f32", "bnn_forward_f32", "bnn_multiswag_f32",
+           "bnn_plan_destroy", "bnn_plan_layer_order", "bnn_layer_order", "bnn_fragment_table", "bnn_swag_draw_f32", "bnn_forward_f32", "bnn_multiswag_f32",
            "bnn_moments_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32")
 
 

@@ -715,6 +715,28 @@ int bnn_plan_layer_order(const bnn_plan* pl, int layer, int noisy, int32_t* host
     return (int)o.size();
 }
 
+int bnn_layer_order(const bnn_arch* arch, int layer, int noisy, int32_t* host_order, int cap) {
+    int rc = check_arch(arch);
+    if (rc) return rc;
+    if (layer < 0 || layer > 5) return fail(BNN_ERR_INVALID, "layer must be 0..5");
+    Tables t = build_tables(arch->zero_mask, noisy != 0);
+    const std::vector<int32_t>& o = t.order[layer];
+    if (host_order)
+        for (int i = 0; i < (int)o.size() && i < cap; ++i) host_order[i] = o[i];
+    return (int)o.size();
+}
+
+int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host_table, int cap) {
+    int rc = check_arch(arch);
+    if (rc) return rc;
+    if (which != 1 && which != 2) return fail(BNN_ERR_INVALID, "which must be 1 or 2");
+    Tables t = build_tables(arch->zero_mask, noisy != 0);
+    const std::vector<int16_t>& v = which == 1 ? t.f1 : t.f2;
+    if (host_table)
+        for (int i = 0; i < (int)v.size() && i < cap; ++i) host_table[i] = v[i];
+    return (int)v.size();
+}
+
 static int pick_spc(const bnn_grid* g, int64_t csz) {
     if (g->systems_per_block > 0) return g->systems_per_block;
     // enough workgroups to fill 256 CUs several times over, else shrink the block

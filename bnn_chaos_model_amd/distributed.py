@@ -1,0 +1,98 @@
+"""Multi-GPU MultiSWAG: shard the systems, replicate the ensemble and the draw list, gather the moments.
+
+SURVEY.md section 8(e): every (system, draw) evaluation is independent and the time pool is inside a system,
+so the path shards BY SYSTEM with no data-path collective.  Each rank evaluates the same J draws (same seed
+indices, same Philox seed and global draw / system ids) on its contiguous slice of the systems, reduces its
+samples [J, B_local, 2] to per-system predictive moments [B_local, 4] locally, and one all-gather (RCCL over
+xGMI; gloo on CPU in the tests) assembles [B, 4] on every rank.  Results are bit-identical for any world size
+because the in-kernel noise is keyed by global ids.
+
+One process per GPU: launch with torch.distributed.run; rank r uses cuda:LOCAL_RANK.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(B, world):
+    """Contiguous, balanced partition of B systems: list of (lo, hi), the first B % world shards one longer."""
+    base, rem = divmod(int(B), int(world))
+    out, lo = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((lo, lo + n))
+        lo += n
+    return out
+
+
+def all_gather_moments(local, B, group=None):
+    """local [B_r, M] (this rank's slice, in shard_bounds order) -> [B, M] on every rank.  One collective."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    bounds = shard_bounds(B, world)
+    nmax = max(hi - lo for lo, hi in bounds)
+    M = local.shape[1]
+    rank = dist.get_rank(group)
+    if local.shape[0] != bounds[rank][1] - bounds[rank][0]:
+        raise ValueError("local shard does not match shard_bounds(B, world)[rank]")
+    if all(hi - lo == nmax for lo, hi in bounds):
+        out = torch.empty((world * nmax, M), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    pad = torch.zeros((nmax, M), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * nmax, M), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(bounds)])
+
+
+def moments_to_mean_std(mom, n_draws):
+    """[B,4] sums -> dict of predictive mean/std of mu and mean of std over the draws (float64)."""
+    n = float(n_draws)
+    mean_mu = mom[:, 0] / n
+    var_mu = (mom[:, 1] / n - mean_mu ** 2).clamp_min(0)
+    return {"mean_mu": mean_mu, "std_mu": var_mu.sqrt(), "mean_std": mom[:, 2] / n, "rms_std": (mom[:, 3] / n).sqrt()}
+
+
+def sharded_predictive_moments(local_moments_fn, B, group=None):
+    """Run `local_moments_fn(lo, hi) -> [hi-lo, 4]` on this rank's slice and all-gather.
+
+    On the GPU path local_moments_fn is a closure over bnn_chaos_model_amd.ops: multiswag(x[lo:hi], ..., system_id0=lo)
+    in slabs of draws, reduced with ops.moments (see MultiSwagSharded)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(B, world)[rank]
+    return all_gather_moments(local_moments_fn(lo, hi), B, group)
+
+
+class MultiSwagSharded:
+    """Predictive moments of the dense (systems x draws) MultiSWAG grid on this rank's GPU, gathered over ranks."""
+
+    def __init__(self, w_avg, w2_avg, pre_D, zero_mask=None, lowest_std=0.5, group=None, draws_per_launch=256):
+        from . import ops
+        self.ops = ops
+        self.state = (w_avg, w2_avg, pre_D)
+        self.plan = ops.get_plan(ops.V50_ZERO_MASK if zero_mask is None else zero_mask, lowest_std)
+        self.group = group
+        self.draws_per_launch = int(draws_per_launch)
+
+    def local_moments(self, x_local, seed_idx, philox_seed, system_id0, scale=0.5):
+        """x_local [B_r,T,41] on this rank's GPU; seed_idx [J] (identical on every rank) -> float64 [B_r,4]."""
+        ops = self.ops
+        wa, w2, pd = self.state
+        J = seed_idx.numel()
+        mom = None
+        for j0 in range(0, J, self.draws_per_launch):  # slabs keep samples[J_slab, B_r, 2] small at C4 scale
+            idx = seed_idx[j0: j0 + self.draws_per_launch]
+            s = ops.multiswag(x_local, wa, w2, pd, idx, scale=scale, philox_seed=philox_seed, draw_id0=j0,
+                              system_id0=system_id0, plan=self.plan)
+            mom = ops.moments(s, mom)
+        return mom
+
+    def predictive_moments(self, x_local, B_total, seed_idx, philox_seed=0, scale=0.5):
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        lo, hi = shard_bounds(B_total, world)[rank]
+        if x_local.shape[0] != hi - lo:
+            raise ValueError(f"rank {rank} must hold systems [{lo}, {hi})")
+        return all_gather_moments(self.local_moments(x_local, seed_idx, philox_seed, lo, scale), B_total, self.group)

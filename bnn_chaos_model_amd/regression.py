@@ -1,0 +1,115 @@
+"""Drop-in for the hot-path half of figures/spock/regression.py: FeatureRegressor.__init__ (:36-72) and
+sample_full_swag (:74-92), plus a batched driver for the MC loops that call it
+(figures/multiswag_5_planet.py:295-298, figures/main_figures.py:154-156, figures/spock/regression.py:149).
+
+`FeatureRegressor.sample(sim)` / `.predict(sim)` need REBOUND N-body features upstream of the path
+ and are not built.
+"""
+import glob
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from . import spock_reg_model
+from .spock_reg_model import _gpu
+
+
+class FeatureRegressor(object):
+    def __init__(self, cuda=False, filebase="long_zero_megno_with_angles_power_v14_*_output.pkl", sort=False):
+        """filebase is resolved like the reference (relative to this file's directory + '/../'); absolute globs work too.
+        The reference's ensemble order is the unsorted glob order (regression.py:45); sort=True makes it deterministic."""
+        super(FeatureRegressor, self).__init__()
+        pwd = os.path.dirname(__file__)
+        self.cuda = cuda
+        pattern = filebase if os.path.isabs(filebase) else pwd + "/../" + filebase
+        names = glob.glob(pattern)
+        if sort:
+            names = sorted(names)
+        self.swag_ensemble = [spock_reg_model.load_swag(fname).cpu() for fname in names]
+        self.ssX = spock_reg_model.v50_scaler()  # "Assume fixed scale" (regression.py:47-71)
+        self._stacked = None
+
+    # ---- reference API -----------------------------------------------------------------------------------------
+    def sample_full_swag(self, X_sample):
+        """Pick a random model from the ensemble and sample from it (regression.py:74-92)."""
+        swag_i = np.random.randint(0, len(self.swag_ensemble))
+        swag_model = self.swag_ensemble[swag_i]
+        swag_model.eval()
+        if self.cuda:
+            # the reference shuttles the model and its SWAG state to the GPU and back per call (regression.py:81-91);
+            # here only the device of the noise draws matters (row R of SURVEY.md section 8).
+            swag_model.cuda()
+        out = swag_model.forward_swag_fast(X_sample, scale=0.5)
+        if self.cuda:
+            swag_model.cpu()
+        return out
+
+    def sample(self, sim, indices=None, samples=1000):
+        raise NotImplementedError("needs REBOUND feature generation (get_extended_tseries), upstream of the accelerated path")
+
+    def predict(self, sim, indices=None, samples=1000):
+        raise NotImplementedError("needs REBOUND feature generation (get_extended_tseries), upstream of the accelerated path")
+
+    # ---- batched driver ----------------------------------------------------------------------------------------
+    def ensemble_state(self, device=None):
+        """w_avg [S,d], w2_avg [S,d], pre_D [S,d,K] of the whole ensemble, resident on the GPU (29 MB for 30 seeds)."""
+        dev = _gpu() if device is None else torch.device(device)
+        if self._stacked is None or self._stacked[0].device != dev:
+            f = lambda name: torch.stack([getattr(m, name).detach().float().cpu() for m in self.swag_ensemble]).to(dev).contiguous()
+            self._stacked = (f("w_avg"), f("w2_avg"), f("pre_D"))
+        return self._stacked
+
+    def sample_full_swag_many(self, X, samples, chunks=1, rng="torch", philox_seed=0, draw_id0=0, system_id0=0,
+                              scale=0.5, out=None):
+        """The whole MC loop in one launch:
+
+            torch.cat([torch.cat([self.sample_full_swag(Xpart) for Xpart in torch.chunk(X, chunks)])[None]
+                       for _ in range(samples)])          # figures/multiswag_5_planet.py:295-298
+
+        -> [samples, B, 2].  rng="torch" consumes numpy's and torch's global generators exactly as that loop does
+        (one randint + randn((1,d)) + randn((K,1)) + 2 randn_like([Bc,20]) per chunk per sample);
+        rng="philox" draws the seed picks from numpy and everything else in-kernel."""
+        if X.dim() != 3 or X.shape[-1] != 41:
+            raise NotImplementedError("X must be [B, T, 41]")
+        g = _gpu()
+        wa, w2, pd = self.ensemble_state(g)
+        S, d, K = pd.shape
+        m0 = self.swag_ensemble[0]
+        plan = ops.get_plan(m0.zero_mask(), m0.lowest)
+        B = X.shape[0]
+        parts = torch.chunk(torch.arange(B), chunks) if B else []
+        nch = len(parts)  # torch.chunk may return fewer chunks than asked
+        if nch == 0:
+            return torch.empty((samples, 0, 2), device=X.device)
+        csz = -(-B // nch)
+        if any(len(pp) != min(csz, B - i * csz) for i, pp in enumerate(parts)):
+            raise NotImplementedError("unexpected torch.chunk partition")
+        J = samples * nch
+        xg = X.detach().to(g, torch.float32).contiguous()
+        noise_dev = g if self.cuda else torch.device("cpu")
+        seed_idx = np.empty(J, np.int32)
+        if rng == "torch":
+            z1 = torch.empty((J, d), device=noise_dev)
+            z2 = torch.empty((J, K), device=noise_dev)
+            eps = torch.empty((samples, B, 2, 20), device=X.device)
+            for e in range(J):
+                s_, c_ = divmod(e, nch)
+                seed_idx[e] = np.random.randint(0, S)                               # regression.py:78
+                z1[e] = torch.randn((1, d), device=noise_dev)[0]                    # spock_reg_model.py:830
+                z2[e] = torch.randn((K, 1), device=noise_dev)[:, 0]                 # :831
+                n = len(parts[c_])
+                lo = c_ * csz
+                eps[s_, lo:lo + n, 0] = torch.randn(n, 20, device=X.device)         # :426
+                eps[s_, lo:lo + n, 1] = torch.randn(n, 20, device=X.device)         # :427
+            res = ops.multiswag(xg, wa, w2, pd, torch.as_tensor(seed_idx), z1.to(g).contiguous(), z2.to(g).contiguous(),
+                                eps.to(g).contiguous(), nchunks=nch, scale=scale, plan=plan, out=out)
+        elif rng == "philox":
+            for e in range(J):
+                seed_idx[e] = np.random.randint(0, S)
+            res = ops.multiswag(xg, wa, w2, pd, torch.as_tensor(seed_idx), nchunks=nch, scale=scale, philox_seed=philox_seed,
+                                draw_id0=draw_id0, system_id0=system_id0, plan=plan, out=out)
+        else:
+            raise ValueError("rng must be 'torch' or 'philox'")
+        return res if out is not None else res.to(X.device)

@@ -1,0 +1,450 @@
+"""Drop-in inference surface of the reference's spock_reg_model.py, backed by the gfx950 kernels.
+
+Mirrors (reference file:line):
+    soft_clamp            spock_reg_model.py:295-296
+    VarModel              :339-545   forward / sample / compute_summary_stats / predict_instability / masks
+    SWAGModel             :689-908   init_params / flatten / load / sample_weights / forward_swag / forward_swag_fast
+    save_swag, load_swag  :911-967
+
+Only inference is here; the training half of the reference class is out of scope.
+The arithmetic runs on the GPU through bnn_chaos_model_amd.ops -- there is no CPU path; CPU tensors are
+copied to the GPU and results come back on the caller's device, as the reference's callers expect.
+
+RNG contract.  With `rng = "torch"` (default) every random number is drawn
+from torch's global generator with the reference's calls, shapes and order (randn((1,d)), randn((K,1)),
+randn_like(x), randn_like([B,20]) x2, randn_like([B,40])) on the device the reference would use, and handed
+to the kernels as explicit noise: after torch.manual_seed(s) the outputs match the reference run with the same
+seed to fp32 rounding.  With `rng = "philox"` the kernels generate counter-based noise themselves
+(no noise tensors in HBM); set `philox_seed` for reproducibility.
+"""
+import copy
+import random
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .checkpoint import AttributeDict, read_swag_file, write_swag_file
+
+EPSILON = 1e-5  # spock_reg_model.py:337
+
+# hard-coded v50 scaler of the reference (spock_reg_model.py:931-957)
+_V50_SCALE = np.array([2.88976974e+03, 6.10019661e-02, 4.03849732e-02, 4.81638693e+01,
+                       6.72583662e-02, 4.17939679e-02, 8.15995339e+00, 2.26871589e+01,
+                       4.73612029e-03, 7.09223721e-02, 3.06455099e-02, 7.10726478e-01,
+                       7.03392022e-01, 7.07873597e-01, 7.06030923e-01, 7.04728204e-01,
+                       7.09420909e-01, 1.90740659e-01, 4.75502285e-02, 2.77188320e-02,
+                       7.08891412e-01, 7.05214134e-01, 7.09786887e-01, 7.04371833e-01,
+                       7.04371110e-01, 7.09828420e-01, 3.33589977e-01, 5.20857790e-02,
+                       2.84763136e-02, 7.02210626e-01, 7.11815232e-01, 7.10512240e-01,
+                       7.03646004e-01, 7.08017286e-01, 7.06162814e-01, 2.12569430e-05,
+                       2.35019125e-05, 2.04211110e-05, 7.51048890e-02, 3.94254400e-01,
+                       7.11351099e-02])
+_V50_MEAN = np.array([4.95458585e+03, 5.67411891e-02, 3.83176945e-02, 2.97223474e+00,
+                      6.29733979e-02, 3.50074471e-02, 6.72845676e-01, 9.92794768e+00,
+                      9.99628430e-01, 5.39591547e-02, 2.92795061e-02, 2.12480714e-03,
+                      -1.01500319e-02, 1.82667162e-02, 1.00813201e-02, 5.74404197e-03,
+                      6.86570242e-03, 1.25316320e+00, 4.76946516e-02, 2.71326280e-02,
+                      7.02054326e-03, 9.83378673e-03, -5.70616748e-03, 5.50782881e-03,
+                      -8.44213953e-04, 2.05958338e-03, 1.57866569e+00, 4.31476211e-02,
+                      2.73316392e-02, 1.05505555e-02, 1.03922250e-02, 7.36865006e-03,
+                      -6.00523246e-04, 6.53016990e-03, -1.72038113e-03, 1.24807860e-05,
+                      1.60314173e-05, 1.21732696e-05, 5.67292645e-03, 1.92488263e-01,
+                      5.08607199e-03])
+
+
+class StandardScaler:
+    """The three attributes and one method of sklearn's StandardScaler that the evaluation scripts use."""
+
+    def __init__(self, mean_=None, scale_=None):
+        self.mean_ = None if mean_ is None else np.asarray(mean_, dtype=np.float64)
+        self.scale_ = None if scale_ is None else np.asarray(scale_, dtype=np.float64)
+        self.var_ = None if scale_ is None else self.scale_ ** 2
+
+    def transform(self, X):
+        X = np.array(X, dtype=np.float64)  # copy, float64 like sklearn
+        X -= self.mean_
+        X /= self.scale_
+        return X
+
+    def inverse_transform(self, X):
+        return np.asarray(X, dtype=np.float64) * self.scale_ + self.mean_
+
+
+def v50_scaler():
+    return StandardScaler(_V50_MEAN, _V50_SCALE)
+
+
+def soft_clamp(x, lo, high):
+    return 0.5 * (torch.tanh(x) + 1) * (high - lo) + lo
+
+
+def mlp(in_n, out_n, hidden, layers):
+    """Same module sequence as the reference's mlp() (:301-321, act='relu'); used for its state_dict layout and init."""
+    if layers == 0:
+        return nn.Linear(in_n, out_n)
+    result = [nn.Linear(in_n, hidden), nn.ReLU()]
+    for _ in range(layers):
+        result.extend([nn.Linear(hidden, hidden), nn.ReLU()])
+    result.extend([nn.Linear(hidden, out_n)])
+    return nn.Sequential(*result)
+
+
+_STATE_LAYOUT = (("input_noise_logvar", (41,)), ("summary_noise_logvar", (40,)),
+                 ("feature_nn.0.weight", (40, 41)), ("feature_nn.0.bias", (40,)),
+                 ("feature_nn.2.weight", (40, 40)), ("feature_nn.2.bias", (40,)),
+                 ("feature_nn.4.weight", (20, 40)), ("feature_nn.4.bias", (20,)),
+                 ("regress_nn.0.weight", (40, 40)), ("regress_nn.0.bias", (40,)),
+                 ("regress_nn.2.weight", (40, 40)), ("regress_nn.2.bias", (40,)),
+                 ("regress_nn.4.weight", (2, 40)), ("regress_nn.4.bias", (2,)))
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("bnn_chaos_model_amd needs an MI355X (gfx950) GPU: there is no CPU implementation")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class VarModel:
+    """Bayesian neural network predicting (mu, std) of log10 instability time (reference :339-545), inference only."""
+
+    def __init__(self, hparams):
+        hparams = AttributeDict(hparams)
+        if "seed" not in hparams:
+            hparams["seed"] = 0
+        # pl.seed_everything(hparams['seed']) (:345): part of the RNG contract
+        random.seed(hparams["seed"])
+        np.random.seed(hparams["seed"])
+        torch.manual_seed(hparams["seed"])
+        hparams["include_derivatives"] = hparams.get("include_derivatives", False)
+        if "time_series_features" not in hparams:
+            hparams["time_series_features"] = 38 + 3
+        if hparams["time_series_features"] == 82:
+            hparams["time_series_features"] = 41
+        self.fix_megno = hparams.get("fix_megno", False)
+        self.fix_megno2 = hparams.get("fix_megno2", False)
+        self.include_angles = hparams.get("include_angles", False)
+        self.n_features = hparams["time_series_features"] * (1 + int(hparams["include_derivatives"]))
+        if (self.n_features, hparams["hidden"], hparams["latent"], hparams["in"], hparams["out"]) != (41, 40, 20, 1, 1) \
+                or self.fix_megno:
+            raise NotImplementedError("only the 41->40->40->20 / 40->40->40->2 network of the pretrained ensemble "
+                                      "(in=1, out=1, fix_megno=False) is built for gfx950")
+        # reference init order (:359-362): feature_nn, regress_nn, then the two noise parameters
+        feature_nn = mlp(self.n_features, hparams["latent"], hparams["hidden"], hparams["in"])
+        regress_nn = mlp(hparams["latent"] * 2, 2, hparams["hidden"], hparams["out"])
+        self.lowest = 0.1 if hparams.get("lower_std", False) else 0.5
+        sd = OrderedDict()
+        sd["input_noise_logvar"] = torch.zeros(self.n_features) - 2
+        sd["summary_noise_logvar"] = torch.zeros(hparams["latent"] * 2) - 2
+        for k, v in feature_nn.state_dict().items():
+            sd["feature_nn." + k] = v
+        for k, v in regress_nn.state_dict().items():
+            sd["regress_nn." + k] = v
+        assert tuple((k, tuple(v.shape)) for k, v in sd.items()) == _STATE_LAYOUT
+        self._pending_draw = None
+        self._w = torch.cat([v.detach().reshape(-1) for v in sd.values()]).float().contiguous()  # flat vector [d]
+
+        self.latents = None
+        self.megno_location = 7
+        self.mmr_location = [3, 6]
+        self.nan_location = [38, 39, 40]
+        self.eplusminus_location = [1, 2, 4, 5]
+        hparams["scheduler_choice"] = "swa"
+        for k, v in (("save_freq", 25), ("eval_freq", 5), ("momentum", 0.9), ("weight_decay", 1e-4), ("noisy_val", True)):
+            hparams.setdefault(k, v)
+        self.hparams = hparams
+        self.random_sample = hparams.get("random_sample", False)
+        self.include_mmr = hparams["include_mmr"]
+        self.include_nan = hparams["include_nan"]
+        self.include_eplusminus = hparams.get("include_eplusminus", True)
+        self._summary_kl = 0.0
+        self._cur_summary = None
+        self.ssX = None
+        self.ssy = None
+        self.training = True
+        self._device = torch.device("cpu")
+        # rng policy, see module docstring
+        self.rng = "torch"
+        self.philox_seed = 0
+        self._philox_calls = 0
+
+    # ---- nn.Module-like conveniences used by the evaluation scripts --------------------------------------------
+    @property
+    def device(self):
+        return self._device
+
+    # The flat parameter vector.  forward_swag_fast samples the weights inside the fused kernel; the module's
+    # "currently loaded weights" (reference :838) are then materialised lazily, only if somebody asks for them.
+    @property
+    def _w(self):
+        if self._pending_draw is not None:
+            fn, self._pending_draw = self._pending_draw, None
+            self._w_store = fn().to(self._device)
+        return self._w_store
+
+    @_w.setter
+    def _w(self, v):
+        self._pending_draw = None
+        self._w_store = v
+
+    def to(self, device):
+        self._device = torch.device(device)
+        self._w = self._w.to(self._device)
+        return self
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def cuda(self, device=None):
+        return self.to(_gpu() if device is None else device)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def state_dict(self):
+        out, i = OrderedDict(), 0
+        for k, shp in _STATE_LAYOUT:
+            n = int(np.prod(shp))
+            out[k] = self._w[i:i + n].reshape(shp)
+            i += n
+        return out
+
+    def load_state_dict(self, sd):
+        self._w = torch.cat([sd[k].detach().reshape(-1).float() for k, _ in _STATE_LAYOUT]).to(self._device).contiguous()
+
+    def flatten(self):
+        """Convert state dict into a vector (:734-746)."""
+        return self._w.clone()
+
+    def load(self, p_vec):
+        """Load a vector into the state dict (:748-761)."""
+        p_vec = torch.as_tensor(p_vec).detach().reshape(-1)
+        if p_vec.numel() != self._w.numel():
+            raise RuntimeError(f"size mismatch: expected {self._w.numel()} parameters, got {p_vec.numel()}")
+        self._w = p_vec.to(device=self._device, dtype=torch.float32).contiguous().clone()
+
+    # ---- kernel plumbing ---------------------------------------------------------------------------------------
+    def zero_mask(self):
+        return ops.zero_mask_from_flags(self.fix_megno, self.fix_megno2, self.include_mmr, self.include_nan,
+                                        self.include_eplusminus)
+
+    def _plan(self):
+        return ops.get_plan(self.zero_mask(), self.lowest)
+
+    @staticmethod
+    def _check_x(x):
+        if x.dim() != 3 or x.shape[-1] != 41:
+            raise NotImplementedError("x must be [batch, time, 41]")  # figures/spock/regression.py:210-211
+        return x
+
+    def _next_philox_id(self, n=1):
+        i = self._philox_calls
+        self._philox_calls += n
+        return i
+
+    def _masked(self, x):
+        m = self.zero_mask()
+        cols = [c for c in range(41) if (m >> c) & 1]
+        x = x.clone()
+        x[..., cols] = 0
+        return x
+
+    def zero_megno(self, x):
+        x = x.clone(); x[..., self.megno_location] = 0; return x
+
+    def zero_mmr(self, x):
+        x = x.clone(); x[..., self.mmr_location] = 0; return x
+
+    def zero_nan(self, x):
+        x = x.clone(); x[..., self.nan_location] = 0; return x
+
+    def zero_eplusminus(self, x):
+        x = x.clone(); x[..., self.eplusminus_location] = 0; return x
+
+    def _forward_gpu(self, x, W, noisy, want_debug=False):
+        """x [B,T,41] on any device, W [1,d] -> (out[B,2] on x.device, pre, summ)."""
+        self._check_x(x)
+        dev_in = x.device
+        g = _gpu()
+        xg = x.detach().to(g, torch.float32).contiguous()
+        B, T, F = xg.shape
+        eps = eps_in = eps_sum = None
+        if self.rng == "torch":
+            # the reference's draws, in its order, on its devices (:445, :426-427, :449)
+            if noisy:
+                eps_in = torch.randn_like(x.detach().float())
+            e1 = torch.randn(B, 20, device=dev_in)
+            e2 = torch.randn(B, 20, device=dev_in)
+            if noisy:
+                eps_sum = torch.randn(B, 40, device=dev_in)
+            eps = torch.stack([e1, e2], dim=1)[None].to(g).contiguous()
+            if noisy:
+                eps_in = eps_in[None].to(g).contiguous()
+                eps_sum = eps_sum[None].to(g).contiguous()
+            res = ops.forward(xg, W.to(g), eps=eps, eps_in=eps_in, eps_sum=eps_sum, plan=self._plan(), debug=want_debug)
+        else:
+            if noisy:
+                raise NotImplementedError("rng='philox' is built for forward_swag_fast / noisy_val=False only")
+            res = ops.forward(xg, W.to(g), philox_seed=self.philox_seed, draw_id0=self._next_philox_id(),
+                              plan=self._plan(), debug=want_debug)
+        if want_debug:
+            return tuple(r[0].to(dev_in) for r in res)
+        return res[0].to(dev_in)
+
+    # ---- reference API -----------------------------------------------------------------------------------------
+    def compute_summary_stats(self, x):
+        """feature_nn -> mean/std time pool with sampled moments (:416-435).  x is used as given (no masking)."""
+        saved = (self.fix_megno2, self.include_mmr, self.include_nan, self.include_eplusminus)
+        try:  # the reference applies the masks in forward(), not here: run the kernel with an empty mask
+            self.fix_megno2, self.include_mmr, self.include_nan, self.include_eplusminus = False, True, True, True
+            _, _, summ = self._forward_gpu(x, self._w[None], noisy=False, want_debug=True)
+        finally:
+            self.fix_megno2, self.include_mmr, self.include_nan, self.include_eplusminus = saved
+        return summ
+
+    def predict_instability(self, summary_stats):
+        """regress_nn + soft_clamp (:437-442) on an explicit summary (off the hot path: plain torch ops on the GPU)."""
+        g = _gpu()
+        sd = {k: v.to(g) for k, v in self.state_dict().items() if k.startswith("regress_nn")}
+        s = summary_stats.to(g, torch.float32)
+        h = torch.relu(s @ sd["regress_nn.0.weight"].T + sd["regress_nn.0.bias"])
+        h = torch.relu(h @ sd["regress_nn.2.weight"].T + sd["regress_nn.2.bias"])
+        testy = (h @ sd["regress_nn.4.weight"].T + sd["regress_nn.4.bias"]).to(summary_stats.device)
+        mu = soft_clamp(testy[:, [0]], 4.0, 12.0)
+        std = soft_clamp(testy[:, [1]], self.lowest, 6.0)
+        return mu, std
+
+    def forward(self, x, noisy_val=True):
+        """VarModel.forward (:486-528) with the currently loaded weights -> cat(mu, std) [B,2] on x.device."""
+        if self.random_sample:
+            raise NotImplementedError("random_sample (training-time augmentation) is not part of the inference path")
+        return self._forward_gpu(x, self._w[None], noisy=bool(noisy_val))
+
+    def sample(self, x, samples=10):
+        """VarModel.sample (:530-545): mean over `samples` noisy forwards of mu + N(0,1)*std -> float64 ndarray [B]."""
+        x = x.cpu()
+        init_device = self._device
+        self.cpu()  # the reference forces CPU here, so its noise comes from the CPU generators
+        all_samp = []
+        for _ in range(samples):
+            out = self(x).detach().numpy()
+            mu, std = out[:, 0], out[:, 1]
+            all_samp.append(mu + np.random.randn(len(out)) * std)
+        self.to(init_device)
+        return np.average(all_samp, axis=0)
+
+
+class SWAGModel(VarModel):
+    """SWAG posterior over the weights (reference :689-908), inference half."""
+
+    def init_params(self, swa_params):
+        self.swa_params = swa_params
+        self.swa_params.setdefault("swa_lr", 0.001)
+        self.swa_params.setdefault("swa_start", 1000)
+        self.swa_params.setdefault("swa_recording_lr_factor", 0.5)
+        self.n_models = 0
+        self.w_avg = None
+        self.w2_avg = None
+        self.pre_D = None
+        self.K = self.swa_params.get("K", 20)
+        self.c = self.swa_params.get("c", 2)
+        self.swa_params["c"] = self.c
+        self.swa_params["K"] = self.K
+        return self
+
+    def _state_gpu(self):
+        g = _gpu()
+        if self.w_avg is None:
+            raise RuntimeError("SWAG state (w_avg, w2_avg, pre_D) is not set")
+        f = lambda t: t.detach().to(g, torch.float32).contiguous()
+        return f(self.w_avg)[None], f(self.w2_avg)[None], f(self.pre_D)[None]
+
+    def _draw_noise(self):
+        """z_1 = randn((1,d)), z_2 = randn((K,1)) on self.device (:830-831)."""
+        d = self.w_avg.shape[0]
+        z1 = torch.randn((1, d), device=self._device)
+        z2 = torch.randn((self.K, 1), device=self._device)
+        return z1, z2
+
+    def sample_weights(self, scale=1):
+        """w ~ N(w_avg, scale^2 (diag/2 + D D^T / 2(K-1))) (:815-838), loaded into the model."""
+        wa, w2, pd = self._state_gpu()
+        g = wa.device
+        idx = torch.zeros(1, dtype=torch.int32, device=g)
+        if self.rng == "torch":
+            z1, z2 = self._draw_noise()
+            W = ops.swag_draw(wa, w2, pd, idx, z1.to(g).contiguous(), z2.reshape(1, -1).to(g).contiguous(), scale=scale,
+                              plan=self._plan())
+        else:
+            W = ops.swag_draw(wa, w2, pd, idx, scale=scale, philox_seed=self.philox_seed, draw_id0=self._next_philox_id(),
+                              plan=self._plan())
+        self.load(W[0])
+
+    def forward_swag(self, x, scale=0.5):
+        """Same output as forward_swag_fast; the reference's extra `_summary_kl` bookkeeping (:866-871) is training-only."""
+        return self.forward_swag_fast(x, scale=scale)
+
+    def forward_swag_fast(self, x, scale=0.5):
+        """Sample weights, then forward without input/summary noise (:878-908), in ONE fused kernel."""
+        self._check_x(x)
+        dev_in = x.device
+        wa, w2, pd = self._state_gpu()
+        g = wa.device
+        xg = x.detach().to(g, torch.float32).contiguous()
+        B = xg.shape[0]
+        idx = torch.zeros(1, dtype=torch.int32, device=g)
+        if self.rng == "torch":
+            z1, z2 = self._draw_noise()                                  # :830-831
+            e1 = torch.randn(B, 20, device=dev_in)                       # :426
+            e2 = torch.randn(B, 20, device=dev_in)                       # :427
+            eps = torch.stack([e1, e2], dim=1)[None].to(g).contiguous()
+            z1g, z2g = z1.to(g).contiguous(), z2.reshape(1, -1).to(g).contiguous()
+            out = ops.multiswag(xg, wa, w2, pd, idx, z1g, z2g, eps, scale=scale, plan=self._plan())
+            # the reference leaves the sampled weights loaded in the module (:838)
+            plan = self._plan()
+            self._pending_draw = lambda: ops.swag_draw(wa, w2, pd, idx, z1g, z2g, scale=scale, plan=plan)[0]
+        else:
+            did, seed, plan = self._next_philox_id(), self.philox_seed, self._plan()
+            out = ops.multiswag(xg, wa, w2, pd, idx, scale=scale, philox_seed=seed, draw_id0=did, plan=plan)
+            self._pending_draw = lambda: ops.swag_draw(wa, w2, pd, idx, scale=scale, philox_seed=seed, draw_id0=did, plan=plan)[0]
+        return out[0].to(dev_in)
+
+
+def save_swag(swag_model, path):
+    """spock_reg_model.py:911-920."""
+    write_swag_file(path, swag_model.hparams, swag_model.swa_params, swag_model.w_avg, swag_model.w2_avg, swag_model.pre_D)
+
+
+def load_swag(path):
+    """spock_reg_model.py:922-967: checkpoint -> SWAGModel with w_avg / w2_avg / pre_D attached and, for 'v50' paths,
+    the hard-coded StandardScaler; otherwise `<path minus .pkl>_ssX.pkl` is read if present."""
+    items = read_swag_file(path)
+    swag_model = SWAGModel(items["hparams"]).init_params(dict(items["swa_params"]))
+    swag_model.w_avg = items["w_avg"]
+    swag_model.w2_avg = items["w2_avg"]
+    swag_model.pre_D = items["pre_D"]
+    if "v50" in str(path):
+        swag_model.ssX = v50_scaler()
+    else:
+        ssX_file = str(path)[:-4] + "_ssX.pkl"
+        try:
+            import pickle as pkl
+            with open(ssX_file, "rb") as f:
+                swag_model.ssX = pkl.load(f)  # an sklearn StandardScaler written by run_swag.py:96-97
+        except FileNotFoundError:
+            print(f"ssX file not found! {ssX_file}")
+    return swag_model
+
+
+__all__ = ["EPSILON", "VarModel", "SWAGModel", "StandardScaler", "load_swag", "save_swag", "soft_clamp", "mlp",
+           "AttributeDict", "copy"]

@@ -66,6 +66,14 @@ int bnn_plan_destroy(bnn_plan* plan);
  * Returns the number of entries.  Lets a test pin a CPU model to the same order. */
 int bnn_plan_layer_order(const bnn_plan* plan, int layer, int noisy, int32_t* host_order, int cap);
 
+/* Host-only views of the operand layout (no device needed; used by the CPU test-suite):
+ * bnn_layer_order = bnn_plan_layer_order without a plan;
+ * bnn_fragment_table: which = 1 feature_nn / 2 regress_nn gather table, entry [f*64 + lane] = index into the
+ * flat parameter vector (or d = 7583 for "zero") that lane `lane` loads into MFMA operand register f.
+ * Both return the number of entries (the required capacity) or a negative bnn_status. */
+int bnn_layer_order(const bnn_arch* arch, int layer, int noisy, int32_t* host_order, int cap);
+int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host_table, int cap);
+
 /* Everything one MultiSWAG evaluation needs besides the ensemble and the noise. */
 typedef struct bnn_grid {
     int64_t B;       /* systems (rows of x)                                                        */

@@ -194,6 +194,15 @@ def main():
              state_keys=np.array(list(m.state_dict().keys())),
              state_sizes=np.array([v.numel() for v in m.state_dict().values()]))
 
+    # ---- case I: constructor side effects (spock_reg_model.py:343-345, 359-362): seed_everything(seed) + module init.
+    # After load_swag the module holds its RANDOM init and the global generators sit in a seed-determined state.
+    mi = srm.load_swag(pretrained(3)).cpu()
+    save("case_init_v50_3.npz", seed=np.array(mi.hparams["seed"]), init_flat=mi.flatten().detach().numpy(),
+         next_torch=torch.randn(4).numpy(), next_numpy=np.random.rand(4), w_avg_head=mi.w_avg[:8].numpy(),
+         hparams_json=np.array(json.dumps({k: (v if isinstance(v, (int, float, str, bool)) else str(v))
+                                           for k, v in dict(mi.hparams).items()})),
+         swa_params_json=np.array(json.dumps(dict(mi.swa_params))))
+
     m0 = models[0]
     # constant-4 "unstable" fill (figures/multiswag_5_planet.py:214-215) after ssX, float64 transform then .float()
     raw4 = np.ones((4, 100, 41)) * 4

@@ -1,0 +1,174 @@
+"""The reference's Python surface (spock_reg_model / FeatureRegressor) on top of the HIP kernels, driven exactly
+as the evaluation scripts drive it, against outputs captured from the unmodified reference.  Needs an MI355X."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import close_report, load_golden, tape
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ckpt_dir(tmp_path_factory):
+    """The two converted pretrained seeds written back as reference-format checkpoints (names contain 'v50')."""
+    from bnn_chaos_model_amd import checkpoint
+    d = tmp_path_factory.mktemp("pretrained")
+    for i in (0, 12):
+        z = load_golden(f"swag_v50_{i}.npz")
+        checkpoint.write_swag_file(str(d / f"steps=300000_v50_{i:02d}_output.pkl"), json.loads(str(z["hparams_json"])),
+                                   json.loads(str(z["swa_params_json"])), torch.tensor(z["w_avg"]), torch.tensor(z["w2_avg"]),
+                                   torch.tensor(z["pre_D"]))
+    return d
+
+
+@pytest.fixture(scope="module")
+def models(ckpt_dir):
+    from bnn_chaos_model_amd import spock_reg_model as srm
+    return {i: srm.load_swag(str(ckpt_dir / f"steps=300000_v50_{i:02d}_output.pkl")).cpu().eval() for i in (0, 12)}
+
+
+@pytest.mark.parametrize("si", (0, 12))
+@pytest.mark.parametrize("xname", ("slow", "iid", "const4"))
+def test_forward_swag_fast_replays_reference_seed(si, xname, models, inputs):
+    """torch.manual_seed(s); model.forward_swag_fast(x, 0.5) -- same call, same seed, same numbers as the reference."""
+    z = load_golden(f"case_swagfast_v50_{si}_{xname}.npz")
+    m = models[si]
+    x = torch.tensor(inputs[xname])
+    torch.manual_seed(int(z["torch_seed"]))
+    out = m.forward_swag_fast(x, scale=0.5)
+    assert out.device == x.device and out.shape == (x.shape[0], 2) and out.dtype == torch.float32
+    nbad, mx = close_report(out.numpy(), z["out"])
+    assert nbad == 0, (nbad, mx)
+    # the sampled weights are left loaded in the module, as in the reference (:838)
+    assert np.abs(m.flatten().numpy().astype(np.float64) - z["w"]).max() <= 2e-6
+    torch.manual_seed(int(z["torch_seed"]))
+    out2 = m.forward_swag(x, scale=0.5)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("si", (0, 12))
+@pytest.mark.parametrize("noisy", (False, True))
+def test_varmodel_forward_replays_reference_seed(si, noisy, models, inputs):
+    z = load_golden(f"case_forward_v50_{si}_noisy{int(noisy)}.npz")
+    m = models[si]
+    m.load(torch.tensor(z["w"]))
+    torch.manual_seed(int(z["torch_seed"]))
+    out = m(torch.tensor(inputs["slow"]), noisy_val=noisy)
+    nbad, mx = close_report(out.numpy(), z["out"])
+    assert nbad == 0, (nbad, mx)
+
+
+def test_varmodel_sample_replays_reference_seed(models, inputs):
+    z = load_golden("case_sample_v50_0.npz")
+    m = models[0]
+    m.load(torch.tensor(z["w"]))
+    torch.manual_seed(3000)
+    np.random.seed(3000)
+    s = m.sample(torch.tensor(inputs["slow"]), samples=int(z["samples"]))
+    assert isinstance(s, np.ndarray) and s.dtype == np.float64 and s.shape == (32,)
+    nbad, mx = close_report(s, z["out"], rtol=2e-5, atol=2e-5)
+    assert nbad == 0, (nbad, mx)
+
+
+def test_sample_weights_flatten_load(models):
+    z = load_golden("case_swagfast_v50_0_slow.npz")
+    m = models[0]
+    torch.manual_seed(int(z["torch_seed"]))
+    m.sample_weights(scale=0.5)
+    assert np.abs(m.flatten().numpy().astype(np.float64) - z["w"]).max() <= 2e-6
+    m.sample_weights(scale=0)
+    assert torch.equal(m.flatten(), m.w_avg)  # scale = 0 => w == w_avg
+
+
+def test_compute_summary_stats_and_predict_instability(models, inputs):
+    z = load_golden("case_swagfast_v50_0_slow.npz")
+    tp = tape(z)
+    m = models[0]
+    m.load(torch.tensor(z["w"]))
+    x = torch.tensor(inputs["slow"])
+    xm = x.clone()
+    xm[..., [1, 2, 3, 4, 5, 6, 7, 38, 39, 40]] = 0
+    torch.manual_seed(int(z["torch_seed"]))
+    torch.randn((1, 7583)); torch.randn((30, 1))  # skip the weight-draw part of the reference's stream
+    summ = m.compute_summary_stats(xm)
+    nbad, mx = close_report(summ.numpy(), z["summary"], rtol=2e-5, atol=2e-5)
+    assert nbad == 0, (nbad, mx)
+    mu, std = m.predict_instability(torch.tensor(z["summary"]))
+    assert mu.shape == (32, 1) and std.shape == (32, 1)
+    nbad, mx = close_report(torch.cat((mu, std), 1).numpy(), z["out"], rtol=2e-5, atol=2e-5)
+    assert nbad == 0, (nbad, mx)
+
+
+def test_feature_regressor_sample_full_swag(ckpt_dir, inputs):
+    """FeatureRegressor.sample_full_swag x3 (figures/spock/regression.py:74-92) == the captured reference run."""
+    from bnn_chaos_model_amd.regression import FeatureRegressor
+    z = load_golden("case_multiswag_grid.npz")
+    fr = FeatureRegressor(cuda=False, filebase=str(ckpt_dir / "*v50*output.pkl"), sort=True)
+    assert len(fr.swag_ensemble) == 2 and fr.ssX.mean_.shape == (41,) and fr.cuda is False
+    x = torch.tensor(inputs["slow"])
+    np.random.seed(4000)
+    torch.manual_seed(4000)
+    outs = torch.cat([fr.sample_full_swag(x)[None].detach() for _ in range(3)])
+    nbad, mx = close_report(outs.numpy(), z["out"])
+    assert nbad == 0, (nbad, mx)
+    # the batched driver consumes the generators identically and gives the same numbers in one launch
+    np.random.seed(4000)
+    torch.manual_seed(4000)
+    many = fr.sample_full_swag_many(x, samples=3, chunks=1)
+    assert torch.equal(many, outs)
+    with pytest.raises(NotImplementedError):
+        fr.sample_full_swag(torch.zeros(2, 100, 40))
+
+
+def test_five_planet_mc_loop(ckpt_dir, inputs):
+    """figures/multiswag_5_planet.py:295-298, literally, and as one launch."""
+    from bnn_chaos_model_amd.regression import FeatureRegressor
+    z = load_golden("case_chunk_loop.npz")
+    model = FeatureRegressor(cuda=False, filebase=str(ckpt_dir / "*v50*output.pkl"), sort=True)
+    Xflat = torch.tensor(inputs["slow"][:30])
+    samples = int(z["samples"])
+    np.random.seed(5000)
+    torch.manual_seed(5000)
+    time = torch.cat([
+        torch.cat([model.sample_full_swag(Xpart).detach().cpu() for Xpart in torch.chunk(Xflat, chunks=10)])[None]
+        for _ in range(samples)], dim=0)
+    nbad, mx = close_report(time.numpy(), z["out"])
+    assert nbad == 0, (nbad, mx)
+    np.random.seed(5000)
+    torch.manual_seed(5000)
+    one = model.sample_full_swag_many(Xflat, samples=samples, chunks=10)
+    assert torch.equal(one, time)
+
+
+def test_philox_mode_statistics_match_torch_mode(ckpt_dir, inputs):
+    """rng='philox' draws different numbers from the same distributions: predictive moments agree statistically."""
+    from bnn_chaos_model_amd.regression import FeatureRegressor
+    fr = FeatureRegressor(cuda=False, filebase=str(ckpt_dir / "*v50*output.pkl"), sort=True)
+    x = torch.tensor(inputs["slow"])
+    np.random.seed(1); torch.manual_seed(1)
+    a = fr.sample_full_swag_many(x, samples=400, chunks=1, rng="torch")
+    np.random.seed(1)
+    b = fr.sample_full_swag_many(x, samples=400, chunks=1, rng="philox", philox_seed=7)
+    assert a.shape == b.shape == (400, 32, 2)
+    ma, mb = a[..., 0].mean(0), b[..., 0].mean(0)
+    sa = a[..., 0].std(0) + 1e-3
+    assert ((ma - mb).abs() / sa * (400 ** 0.5) < 6).all()  # means within 6 standard errors, system by system
+
+
+def test_cuda_inputs_stay_on_gpu(models, inputs):
+    m = models[0]
+    x = torch.tensor(inputs["slow"]).cuda()
+    m.cuda()
+    try:
+        out = m.forward_swag_fast(x)
+        assert out.is_cuda and out.shape == (32, 2) and torch.isfinite(out).all()
+        m.rng = "philox"
+        m.philox_seed = 11
+        o1 = m.forward_swag_fast(x)
+        assert o1.is_cuda and torch.isfinite(o1).all() and torch.isfinite(m.flatten()).all()
+    finally:
+        m.rng = "torch"
+        m.cpu()
