@@ -61,11 +61,16 @@ def synthetic_ensemble(S, device):
     return t(wa), t(w2), t(pd)
 
 
-def cpu_baseline(x_cpu, wa, w2, pd, budget_s=12.0):
-    """The oracle (oracle/bnn_oracle.c, OpenMP, all host cores) on a bounded sample of the same workload."""
+def cpu_baseline(x_cpu, wa, w2, pd, budget_s=20.0):
+    """The oracle (oracle/bnn_oracle.c: fp32 C restatement, OpenMP over systems) on a bounded sample of the same
+    workload: same synthetic inputs, same ensemble, a few draws, sized to about `budget_s` seconds of CPU work."""
     import numpy as np
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     rng = np.random.default_rng(0)
 
     def run(Bs, Js):
@@ -77,14 +82,15 @@ def cpu_baseline(x_cpu, wa, w2, pd, budget_s=12.0):
         orc.multiswag(x_cpu[:Bs], wa, w2, pd, seed_idx, z1, z2, eps)
         return time.perf_counter() - t0
 
-    Bs = min(256, x_cpu.shape[0])
-    t_probe = run(Bs, 2)
-    rate = Bs * 2 / t_probe
-    Js = 4
-    Bs = int(min(x_cpu.shape[0], max(Bs, rate * budget_s / Js)))
-    t = run(Bs, Js)
-    return {"value": Bs * Js / t, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": f"{Bs} systems x {Js} draws ({Bs * Js} evals, {t:.1f} s) of the same synthetic inputs, fp32 C oracle, OpenMP"}
+    Bmax = x_cpu.shape[0]
+    run(min(Bmax, 64 * cores), 1)                      # warm the thread pool
+    t_probe = run(min(Bmax, 64 * cores), 2)
+    rate = min(Bmax, 64 * cores) * 2 / t_probe
+    Js = max(2, int(min(300, 2.5 * rate * budget_s / Bmax)))   # the 2-draw probe under-reads the rate ~2.5x (thread ramp-up)   # whole sample = Bmax systems x Js draws
+    t = run(Bmax, Js)
+    return {"value": Bmax * Js / t, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"{Bmax} systems x {Js} draws = {Bmax * Js} evals in {t:.1f} s; same synthetic inputs and ensemble; "
+                      f"oracle/bnn_oracle.c (fp32, fmaf chains), OpenMP threads = {cores}"}
 
 
 def main():
@@ -95,7 +101,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--systems", type=int, default=0, help="systems per GPU (overrides the workload)")
     ap.add_argument("--samples", type=int, default=0)
-    ap.add_argument("--unfused", action="store_true", help="separate swag_draw kernel + forward kernel")
+    ap.add_argument("--unfused", action="store_true", help="separate ops.swag_draw + ops.forward calls")
+    ap.add_argument("--single-launch", action="store_true", help="in-kernel draw in every workgroup prologue (no workspace)")
     ap.add_argument("--spb", type=int, default=0, help="systems per workgroup (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -103,6 +110,7 @@ def main():
     import torch
     import torch.distributed as dist
     from bnn_chaos_model_amd import ops
+    from bnn_chaos_model_amd.distributed import all_gather_moments
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -128,7 +136,6 @@ def main():
     wa, w2, pd = synthetic_ensemble(S, dev)           # replicated ensemble (29 MB)
     seed_idx = (torch.arange(J, dtype=torch.int32) % S).to(dev)  # dense grid: every seed x every sample
     out = torch.empty((J, B, 2), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * B, 4), dtype=torch.float64, device=dev) if world > 1 else None
     plan = ops.get_plan()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -141,12 +148,12 @@ def main():
             o = ops.forward(x, W, philox_seed=99, draw_id0=0, system_id0=rank * B, plan=plan, systems_per_block=args.spb)
         else:
             o = ops.multiswag(x, wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, system_id0=rank * B, plan=plan, out=out,
-                              systems_per_block=args.spb)
+                              systems_per_block=args.spb, single_launch=args.single_launch)
         if timed:
             ev1[i].record()
         mom = ops.moments(o)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, mom)
+            mom = all_gather_moments(mom, world * B)  # the path's one exchange: [B,4] float64 per rank
         return mom
 
     def fence():
@@ -188,7 +195,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "systems_per_gpu": B, "seeds": S, "mc_samples": M, "draws": J, "timesteps": 100,
-                       "features": 41, "noise": "in-kernel Philox4x32-10", "kernel": "unfused draw+forward" if args.unfused else "fused draw+forward",
+                       "features": 41, "noise": "in-kernel Philox4x32-10", "kernel": "ops.swag_draw + ops.forward" if args.unfused else ("multiswag, in-kernel draw per workgroup" if args.single_launch else "multiswag, draw-once workspace + forward"),
                        "sharding": f"systems over {world} rank(s), all-gather of moments"},
             "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
@@ -197,7 +204,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(x[:4096].cpu().numpy(), wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
+                res["cpu_baseline"] = cpu_baseline(x.cpu().numpy(), wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
             except Exception as e:  # the oracle is a checker, never a dependency of the measured path
                 res["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)

@@ -57,7 +57,7 @@ def lib():
     L.bnn_forward_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64,
                                   _vp, _vp, _vp, _vp]
     L.bnn_multiswag_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp,
-                                    _vp, C.c_float, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp]
+                                    _vp, C.c_float, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp]
     L.bnn_moments_f64.argtypes = [_vp, C.c_int64, C.c_int64, _vp, C.c_int32, _vp]
     L.bnn_philox_normal_f32.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                         _vp, _vp]

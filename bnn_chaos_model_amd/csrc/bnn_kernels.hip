@@ -832,9 +832,17 @@ int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, 
 
 int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg, const float* w2_avg,
                       const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx, const float* z1, const float* z2,
-                      const float* eps, float scale, uint64_t philox_seed, int64_t draw_id0, int64_t system_id0, float* out,
-                      float* pre_clamp, float* summary, void* stream) {
+                      const float* eps, float scale, uint64_t philox_seed, int64_t draw_id0, int64_t system_id0,
+                      float* W_workspace, float* out, float* pre_clamp, float* summary, void* stream) {
     if (!w_avg || !w2_avg || !pre_D || !seed_idx) return fail(BNN_ERR_INVALID, "NULL ensemble argument");
+    if (W_workspace) {  // sample every draw once, then the forward kernel reads the materialised vectors
+        if (!grid) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
+        int rc = bnn_swag_draw_f32(plan, w_avg, w2_avg, pre_D, S, K, seed_idx, grid->J, z1, z2, scale, philox_seed, draw_id0,
+                                   W_workspace, stream);
+        if (rc) return rc;
+        return bnn_forward_f32(plan, grid, x, W_workspace, eps, nullptr, nullptr, philox_seed, draw_id0, system_id0, out, pre_clamp,
+                               summary, stream);
+    }
     if ((z1 == nullptr) != (z2 == nullptr)) return fail(BNN_ERR_INVALID, "z1 and z2 must both be given or both be NULL");
     if (S < 1) return fail(BNN_ERR_INVALID, "bad S");
     FwdParams p{};

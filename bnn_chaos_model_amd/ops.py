@@ -99,10 +99,27 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     return (out, pre, summ) if debug else out
 
 
+_workspaces = {}
+
+
+def _workspace(J, d, device):
+    """[J,d] scratch for the draws of one call, cached per device (grown, never shrunk)."""
+    key = (device.type, device.index)
+    w = _workspaces.get(key)
+    if w is None or w.shape[0] < J:
+        w = torch.empty((max(J, 64), d), dtype=torch.float32, device=device)
+        _workspaces[key] = w
+    return w
+
+
 def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nchunks=1, scale=0.5, philox_seed=0,
-              draw_id0=0, system_id0=0, plan=None, debug=False, systems_per_block=0, out=None):
+              draw_id0=0, system_id0=0, plan=None, debug=False, systems_per_block=0, out=None, single_launch=None):
     """Fused SWAGModel.forward_swag_fast (spock_reg_model.py:878-908) over the MC loop of
-    figures/multiswag_5_planet.py:295-298 -> out[J/nchunks, B, 2]."""
+    figures/multiswag_5_planet.py:295-298 -> out[J/nchunks, B, 2].
+
+    single_launch: True = every workgroup samples its draw in its prologue (no scratch memory); False = draws are
+    sampled once into a cached workspace and read by the forward kernel of the same call (same bits, faster when a
+    draw serves many workgroups).  None = choose by chunk size."""
     plan = plan or get_plan()
     x = _f32(x, "x")
     if x.dim() != 3 or x.shape[2] != 41:
@@ -125,9 +142,13 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, 2 * LATENT), dtype=torch.float32, device=x.device) if debug else None
     g = _grid(B, T, J, nchunks, systems_per_block)
+    if single_launch is None:
+        single_launch = -(-B // max(nchunks, 1)) <= 256
+    ws = None if single_launch else _workspace(J, d, x.device)
     N.check(N.lib().bnn_multiswag_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
                                       N.ptr(seed_idx), N.ptr(z1), N.ptr(z2), N.ptr(eps), float(scale), int(philox_seed),
-                                      int(draw_id0), int(system_id0), N.ptr(out), N.ptr(pre), N.ptr(summ), N.stream_ptr()))
+                                      int(draw_id0), int(system_id0), N.ptr(ws), N.ptr(out), N.ptr(pre), N.ptr(summ),
+                                      N.stream_ptr()))
     return (out, pre, summ) if debug else out
 
 

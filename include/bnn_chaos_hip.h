@@ -112,12 +112,16 @@ int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, 
  * figures/main_figures.py:154-156): per draw, sample the weights in the kernel prologue (same
  * arithmetic as bnn_swag_draw_f32, bit for bit), keep them on chip, stream x once, write (mu, std).
  * system_id0 = global index of x row 0 (Philox counters use global ids so results do not depend on
- * how systems are sharded over GPUs). */
+ * how systems are sharded over GPUs).
+ * W_workspace: NULL = every workgroup samples its draw in its own prologue (one launch, no scratch memory).
+ * Non-NULL [J,d] scratch = each draw is sampled ONCE by a draw kernel into the workspace and the forward
+ * kernel of the same call picks it up (two launches on `stream`, identical results bit for bit; faster
+ * whenever a draw is shared by many workgroups, i.e. B/nchunks above a few hundred systems). */
 int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg,
                       const float* w2_avg, const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx,
                       const float* z1, const float* z2, const float* eps, float scale, uint64_t philox_seed,
-                      int64_t draw_id0, int64_t system_id0, float* out, float* pre_clamp, float* summary,
-                      void* stream);
+                      int64_t draw_id0, int64_t system_id0, float* W_workspace, float* out, float* pre_clamp,
+                      float* summary, void* stream);
 
 /* Predictive moments over draws: samples [R,B,2] -> moments [B,4] (float64):
  * sum mu, sum mu^2, sum std, sum std^2 over r, in r order (deterministic).  accumulate != 0 adds to

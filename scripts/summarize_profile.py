@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Condenses a scripts/profile_r01.sh output directory (rocprofv3 CSVs) into profiles/: the --stats kernel table,
+per-kernel PMC averages, and pmc_traffic.json (HBM bytes per launch of the dominant kernel, corrected as
+MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half
+the bytes of wide (16 B/lane) streaming reads, so the read side is doubled)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r01"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r01"
+os.makedirs(dst, exist_ok=True)
+for mode in ("workspace", "single_launch"):
+    f = os.path.join(src, mode, "trace_kernel_stats.csv")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_{mode}.csv"))
+    b = os.path.join(src, f"{mode}_bench.json")
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(dst, f"{tag}_bench_under_rocprof_{mode}.json"))
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if name.startswith("bnn_"):
+            pmc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            pmc[name]["_grid"] = [int(r["Grid_Size"])]
+            pmc[name]["_vgpr"] = [int(r["VGPR_Count"])]
+            pmc[name]["_lds"] = [int(r["LDS_Block_Size"])]
+            pmc[name]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in pmc.items()}
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+dom = [k for k in out if "multiswag_kernel" in k]
+if dom:
+    d = out[dom[0]]
+    fetch_kib, write_kib = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)
+    bench = json.load(open(os.path.join(src, "workspace_bench.json")))
+    rec = {"workload": "c2", "systems": bench["config"]["systems_per_gpu"], "draws": bench["config"]["draws"],
+           "kernel": dom[0], "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+           "hbm_bytes_per_launch": 2.0 * fetch_kib * 1024 + write_kib * 1024,
+           "correction": "read side x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16 B/lane loads), write side x1",
+           "algorithmic_bytes_per_launch": bench["config"]["systems_per_gpu"] * bench["config"]["draws"] * 16408,
+           "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {src}"}
+    json.dump(rec, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(rec, indent=1))
+print(json.dumps(out, indent=1, sort_keys=True)[:3000])

@@ -125,16 +125,20 @@ def _grid_from_tape(tp):
     return np.array(seed_idx, np.int32), np.stack(z1), np.stack(z2), e1, e2
 
 
-@pytest.mark.parametrize("fused", (True, False))
-def test_multiswag_grid_vs_reference(fused, ops, orc, swag_states, inputs):
+MODES = ("single_launch", "workspace", "two_calls")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_multiswag_grid_vs_reference(mode, ops, orc, swag_states, inputs):
     z = load_golden("case_multiswag_grid.npz")
     tp = tape(z)
     x = inputs["slow"]
     seed_idx, z1, z2, e1, e2 = _grid_from_tape(tp)
     eps = np.stack([np.stack([a, b], axis=1) for a, b in zip(e1, e2)])
     wa, w2, pd = stack_states(swag_states, z["ensemble"])
-    if fused:
-        out = ops.multiswag(dev(x), dev(wa), dev(w2), dev(pd), torch.as_tensor(seed_idx), dev(z1), dev(z2), dev(eps))
+    if mode != "two_calls":
+        out = ops.multiswag(dev(x), dev(wa), dev(w2), dev(pd), torch.as_tensor(seed_idx), dev(z1), dev(z2), dev(eps),
+                            single_launch=(mode == "single_launch"))
     else:
         W = ops.swag_draw(dev(wa), dev(w2), dev(pd), torch.as_tensor(seed_idx), dev(z1), dev(z2))
         out = ops.forward(dev(x), W, eps=dev(eps))
@@ -145,8 +149,8 @@ def test_multiswag_grid_vs_reference(fused, ops, orc, swag_states, inputs):
     assert np.abs(out - o).max() <= 2e-6
 
 
-@pytest.mark.parametrize("fused", (True, False))
-def test_chunk_loop_vs_reference(fused, ops, orc, swag_states, inputs):
+@pytest.mark.parametrize("mode", MODES)
+def test_chunk_loop_vs_reference(mode, ops, orc, swag_states, inputs):
     """figures/multiswag_5_planet.py:295-298: samples x torch.chunk(X, 10), one (seed, draw) per chunk per sample."""
     z = load_golden("case_chunk_loop.npz")
     tp = tape(z)
@@ -160,8 +164,9 @@ def test_chunk_loop_vs_reference(fused, ops, orc, swag_states, inputs):
         eps[s, c * csz:(c + 1) * csz, 0] = e1[e]
         eps[s, c * csz:(c + 1) * csz, 1] = e2[e]
     wa, w2, pd = stack_states(swag_states, z["ensemble"])
-    if fused:
-        out = ops.multiswag(dev(x), dev(wa), dev(w2), dev(pd), torch.as_tensor(seed_idx), dev(z1), dev(z2), dev(eps), nchunks=nch)
+    if mode != "two_calls":
+        out = ops.multiswag(dev(x), dev(wa), dev(w2), dev(pd), torch.as_tensor(seed_idx), dev(z1), dev(z2), dev(eps), nchunks=nch,
+                            single_launch=(mode == "single_launch"))
     else:
         W = ops.swag_draw(dev(wa), dev(w2), dev(pd), torch.as_tensor(seed_idx), dev(z1), dev(z2))
         out = ops.forward(dev(x), W, eps=dev(eps), nchunks=nch)
@@ -190,10 +195,14 @@ def test_ragged_sizes_match_oracle(B, ops, orc, swag_states):
     z1 = rng.standard_normal((J, 7583), dtype=np.float32)
     z2 = rng.standard_normal((J, 30), dtype=np.float32)
     eps = rng.standard_normal((J, B, 2, 20), dtype=np.float32)
-    out = ops.multiswag(dev(x), dev(wa), dev(w2), dev(pd), torch.as_tensor(seed_idx), dev(z1), dev(z2), dev(eps)).cpu().numpy()
+    args = (dev(x), dev(wa), dev(w2), dev(pd), torch.as_tensor(seed_idx), dev(z1), dev(z2), dev(eps))
+    out = ops.multiswag(*args, single_launch=True).cpu().numpy()
     o = orc.multiswag(x, wa, w2, pd, seed_idx, z1, z2, eps, sched=kernel_schedule(ops, orc))
     assert np.isfinite(out).all()
     assert np.abs(out - o).max() <= 2e-6, np.abs(out - o).max()
+    # the draw-once workspace path and a forced 64-system block size give the same bits
+    assert np.array_equal(ops.multiswag(*args, single_launch=False).cpu().numpy(), out)
+    assert np.array_equal(ops.multiswag(*args, single_launch=True, systems_per_block=64).cpu().numpy(), out)
 
 
 def test_philox_mode_is_the_explicit_mode_on_generated_noise(ops, swag_states):
@@ -202,7 +211,8 @@ def test_philox_mode_is_the_explicit_mode_on_generated_noise(ops, swag_states):
     x = dev(_synthetic(B).numpy())
     wa, w2, pd = (dev(a) for a in stack_states(swag_states, (0, 12)))
     seed_idx = torch.tensor([0, 1, 0, 1], dtype=torch.int32)
-    a = ops.multiswag(x, wa, w2, pd, seed_idx, philox_seed=seed, draw_id0=8, system_id0=100)
+    a = ops.multiswag(x, wa, w2, pd, seed_idx, philox_seed=seed, draw_id0=8, system_id0=100, single_launch=True)
+    assert torch.equal(a, ops.multiswag(x, wa, w2, pd, seed_idx, philox_seed=seed, draw_id0=8, system_id0=100, single_launch=False))
     z1 = ops.philox_normal(0, seed, 8, J, width=7583)
     z2 = ops.philox_normal(1, seed, 8, J, width=30)
     eps = ops.philox_normal(2, seed, 8, J, B=B, system_id0=100)
