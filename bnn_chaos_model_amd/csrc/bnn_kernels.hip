@@ -48,6 +48,9 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 #ifndef BNN_PRIO_STAGGER
 #define BNN_PRIO_STAGGER 0
 #endif
+#ifndef BNN_TWO_STREAMS
+#define BNN_TWO_STREAMS 0  // interleave two tiles per wave through the layers (0 = one tile at a time)
+#endif
 #ifndef BNN_WAVES_PER_SIMD
 #define BNN_WAVES_PER_SIMD 2  // register budget of the main kernel: 2 -> 256 VGPRs, 3 -> 168
 #endif
@@ -383,8 +386,8 @@ __global__ __launch_bounds__(256, BNN_WAVES_PER_SIMD) void bnn_multiswag_kernel(
             f32x4 mean0 = {0, 0, 0, 0}, m20 = {0, 0, 0, 0};
             float mean1 = 0.0f, m21 = 0.0f;
 
-            // One 16-row tile: feature_nn on the matrix pipe, then the running time-pool statistics.
-            auto do_tile = [&](const XRaw<NK1>& raw, const XRaw<NK1>& nraw, const int it) {
+            // ---- building blocks of one 16-row tile ----------------------------------------------------------
+            auto make_cur = [&](const XRaw<NK1>& raw, const XRaw<NK1>& nraw) {
                 XTile<NK1> cur = xtile<NK1>(raw, g);
                 if constexpr (NOISY) {
                     // masks then add_input_noise (:486-504): masked columns become pure noise
@@ -398,67 +401,121 @@ __global__ __launch_bounds__(256, BNN_WAVES_PER_SIMD) void bnn_multiswag_kernel(
                         }
                     }
                 }
-                // feature_nn.0 + ReLU
-                f32x4 h[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                return cur;
+            };
+            struct H3 { f32x4 m[3]; };
+            struct H2 { f32x4 m[2]; };
+            auto layer1 = [&](const XTile<NK1>& cur) {  // feature_nn.0 (bias rides in a k slot)
+                H3 h = {{{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}};
 #pragma unroll
                 for (int s = 0; s < NK1; ++s)
 #pragma unroll
-                    for (int mt = 0; mt < 3; ++mt) h[mt] = mfma(wf[s * 3 + mt], cur.v[s], h[mt]);
-                h[0] = relu4(h[0]); h[1] = relu4(h[1]); h[2] = relu4<2>(h[2]);
-                // feature_nn.2 + ReLU
-                f32x4 h2[3];
+                    for (int mt = 0; mt < 3; ++mt) h.m[mt] = mfma(wf[s * 3 + mt], cur.v[s], h.m[mt]);
+                return h;
+            };
+            auto relu3 = [&](H3 h) {
+                h.m[0] = relu4(h.m[0]); h.m[1] = relu4(h.m[1]); h.m[2] = relu4<2>(h.m[2]);
+                return h;
+            };
+            auto layer2 = [&](const H3& h) {  // feature_nn.2
+                H3 o;
 #pragma unroll
-                for (int mt = 0; mt < 3; ++mt) h2[mt] = (f32x4){wf[IB2 + mt * 4], wf[IB2 + mt * 4 + 1], wf[IB2 + mt * 4 + 2], wf[IB2 + mt * 4 + 3]};
-#pragma unroll
-                for (int ks = 0; ks < NKH; ++ks)
-#pragma unroll
-                    for (int mt = 0; mt < 3; ++mt) h2[mt] = mfma(wf[IW2 + ks * 3 + mt], h[ks >> 2][ks & 3], h2[mt]);
-                h2[0] = relu4(h2[0]); h2[1] = relu4(h2[1]); h2[2] = relu4<2>(h2[2]);
-                // feature_nn.4
-                f32x4 y[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) y[mt] = (f32x4){wf[IB3 + mt * 4], wf[IB3 + mt * 4 + 1], wf[IB3 + mt * 4 + 2], wf[IB3 + mt * 4 + 3]};
+                for (int mt = 0; mt < 3; ++mt) o.m[mt] = (f32x4){wf[IB2 + mt * 4], wf[IB2 + mt * 4 + 1], wf[IB2 + mt * 4 + 2], wf[IB2 + mt * 4 + 3]};
 #pragma unroll
                 for (int ks = 0; ks < NKH; ++ks)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) y[mt] = mfma(wf[IW3 + ks * 2 + mt], h2[ks >> 2][ks & 3], y[mt]);
-                // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps;
-                // 1/(it+1) comes correctly rounded from a table (uniform address -> scalar load)
+                    for (int mt = 0; mt < 3; ++mt) o.m[mt] = mfma(wf[IW2 + ks * 3 + mt], h.m[ks >> 2][ks & 3], o.m[mt]);
+                return o;
+            };
+            auto layer3 = [&](const H3& h2) {  // feature_nn.4
+                H2 y;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) y.m[mt] = (f32x4){wf[IB3 + mt * 4], wf[IB3 + mt * 4 + 1], wf[IB3 + mt * 4 + 2], wf[IB3 + mt * 4 + 3]};
+#pragma unroll
+                for (int ks = 0; ks < NKH; ++ks)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) y.m[mt] = mfma(wf[IW3 + ks * 2 + mt], h2.m[ks >> 2][ks & 3], y.m[mt]);
+                return y;
+            };
+            // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps, in tile order;
+            // 1/(it+1) comes correctly rounded from a table
+            auto pool = [&](const H2& y, const int it) {
                 const float rcn = p.rcp_tab[it];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float dl = y[0][i] - mean0[i];
+                    float dl = y.m[0][i] - mean0[i];
                     float mn = mean0[i] + dl * rcn;
-                    m20[i] = m20[i] + dl * (y[0][i] - mn);
+                    m20[i] = m20[i] + dl * (y.m[0][i] - mn);
                     mean0[i] = mn;
                 }
                 {
-                    float dl = y[1][0] - mean1;
+                    float dl = y.m[1][0] - mean1;
                     float mn = mean1 + dl * rcn;
-                    m21 = m21 + dl * (y[1][0] - mn);
+                    m21 = m21 + dl * (y.m[1][0] - mn);
                     mean1 = mn;
                 }
             };
-            // Prefetch one tile ahead into a ping-pong pair of register sets (no loop-carried copies).  The empty
-            // asm with a memory clobber keeps each load where it is written: without it InstCombine folds
-            // phi(load, load) into a load of phi(addresses) in front of the first use, and the scheduler sinks it.
+            // Loads stay where they are written: without the may-write barrier InstCombine folds phi(load, load) into a
+            // load of phi(addresses) in front of the first use, and the machine scheduler sinks it further.
             auto prefetch = [&](XRaw<NK1>& raw, XRaw<NK1>& nraw, int it) {
                 const int itc = it < ntiles ? it : ntiles - 1;  // past the end: re-read the last tile (no overrun)
                 raw = load_x<NK1>(rowp + (int64_t)itc * 4 * F, g);
                 if constexpr (NOISY) nraw = load_x<NK1>(epin + (int64_t)itc * 4 * F, g);
+            };
+            auto pin_loads = [&]() {
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             };
+
             XRaw<NK1> rawA, rawB, nrawA, nrawB;
-            prefetch(rawA, nrawA, 0);
             int it = 0;
-            for (; it + 1 < ntiles; it += 2) {
-                prefetch(rawB, nrawB, it + 1);
-                do_tile(rawA, nrawA, it);
-                prefetch(rawA, nrawA, it + 2);
-                do_tile(rawB, nrawB, it + 1);
+            if constexpr (BNN_TWO_STREAMS && !NOISY) {
+                // Two consecutive tiles travel through the layers together: while one stream's MFMAs occupy the
+                // matrix pipe, the other stream's dependent ReLU / pool VALU work issues in their shadow, so the
+                // pipe never waits on a layer boundary.  Pool order stays tile order (bit-identical results).
+                prefetch(rawA, nrawA, 0);
+                prefetch(rawB, nrawB, 1);
+                pin_loads();
+                for (; it + 1 < ntiles; it += 2) {
+                    XTile<NK1> curA = make_cur(rawA, nrawA), curB = make_cur(rawB, nrawB);
+                    prefetch(rawA, nrawA, it + 2);   // one pair ahead, into the registers just consumed
+                    prefetch(rawB, nrawB, it + 3);
+                    pin_loads();
+                    H3 hA = layer1(curA);
+                    H3 hB = layer1(curB);
+                    hA = relu3(hA);
+                    H3 gA = layer2(hA);
+                    hB = relu3(hB);
+                    H3 gB = layer2(hB);
+                    gA = relu3(gA);
+                    H2 yA = layer3(gA);
+                    gB = relu3(gB);
+                    H2 yB = layer3(gB);
+                    pool(yA, it);
+                    pool(yB, it + 1);
+                }
+                if (it < ntiles) {  // odd tile count: rawA already holds the last tile
+                    H2 y = layer3(relu3(layer2(relu3(layer1(make_cur(rawA, nrawA))))));
+                    pool(y, it);
+                }
+            } else {
+                // one tile at a time, next tile prefetched into a ping-pong pair of register sets
+                auto do_tile = [&](const XRaw<NK1>& raw, const XRaw<NK1>& nraw, const int t) {
+                    H2 y = layer3(relu3(layer2(relu3(layer1(make_cur(raw, nraw))))));
+                    pool(y, t);
+                };
+                prefetch(rawA, nrawA, 0);
+                pin_loads();
+                for (; it + 1 < ntiles; it += 2) {
+                    prefetch(rawB, nrawB, it + 1);
+                    pin_loads();
+                    do_tile(rawA, nrawA, it);
+                    prefetch(rawA, nrawA, it + 2);
+                    pin_loads();
+                    do_tile(rawB, nrawB, it + 1);
+                }
+                if (it < ntiles) do_tile(rawA, nrawA, it);
             }
-            if (it < ntiles) do_tile(rawA, nrawA, it);
 
             // merge the 4 lanes of a quad (timesteps t = 4*it + (c&3)): equal-count Chan update, symmetric
             float mean[5] = {mean0[0], mean0[1], mean0[2], mean0[3], mean1};
@@ -488,11 +545,22 @@ __global__ __launch_bounds__(256, BNN_WAVES_PER_SIMD) void bnn_multiswag_kernel(
                 e2a = *reinterpret_cast<const f32x4*>(ep + L + 4 * g);
                 e2b = ep[L + 16 + g];
             } else {
+                // The four lanes of a quad serve the same system and need the same four Philox blocks (quads g, 4, 5+g, 9
+                // of that system's 40 normals): lane p of the quad generates block p, then the quad exchanges them
+                // through the LDS crossbar (fp32 VALU time is matrix-pipe time on this chip; shuffles are not).
                 const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + sysc;
-                e1a = philox_eps4(grow, gsys, g, p.seed);
-                e1b = philox_eps4(grow, gsys, 4, p.seed)[g];
-                e2a = philox_eps4(grow, gsys, 5 + g, p.seed);
-                e2b = philox_eps4(grow, gsys, 9, p.seed)[g];
+                const int pq = c & 3;
+                const int quad = pq == 0 ? g : pq == 1 ? 4 : pq == 2 ? 5 + g : 9;
+                const f32x4 mine = philox_eps4(grow, gsys, quad, p.seed);
+                const int qb = lane & ~3;
+                const float pick = mine[g];  // lanes 1 and 3 of the quad only contribute component g
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    e1a[k] = __shfl(mine[k], qb + 0);
+                    e2a[k] = __shfl(mine[k], qb + 2);
+                }
+                e1b = __shfl(pick, qb + 1);
+                e2b = __shfl(pick, qb + 3);
             }
             float snew[10];
 #pragma unroll
