@@ -52,7 +52,7 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 #define BNN_TWO_STREAMS 0  // interleave two tiles per wave through the layers (0 = one tile at a time)
 #endif
 #ifndef BNN_WAVES_PER_SIMD
-#define BNN_WAVES_PER_SIMD 2  // register budget of the main kernel: 2 -> 256 VGPRs, 3 -> 168
+#define BNN_WAVES_PER_SIMD 3  // register budget of the 16x16x4 kernel: 2 -> 256 VGPRs, 3 -> 168 (+3 % measured)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -188,6 +188,28 @@ DEVINL float draw_row(const float* __restrict__ w_avg_s, const float* __restrict
 
 constexpr int SLAB = 64 * MAXK;  // floats per wave
 
+// Slab-free variant for the single-launch prologue: thread-per-element, the K-term row read straight from L2.
+// Same operation sequence as draw_row, hence the same bits.
+DEVINL float draw_row_direct(const float* __restrict__ w_avg_s, const float* __restrict__ w2_avg_s,
+                             const float* __restrict__ pre_D_s, int i, int K, const float* zsh, float z1v, float c1, float c2,
+                             float scale) {
+    float wa = w_avg_s[i], w2 = w2_avg_s[i];
+    float sq = wa * wa;
+    float var = w2 - sq;
+    float sd = sqrtf(fabsf(var));
+    float t1 = (c1 * z1v) * sd;
+    float w = wa + t1;
+    float dot = 0.0f;
+    const float* row = pre_D_s + (int64_t)i * K;
+#pragma unroll 6
+    for (int k = 0; k < K; ++k) {
+        float Dk = row[k] - wa;
+        dot = fmaf(Dk, zsh[k], dot);
+    }
+    float t2 = (scale * dot) / c2;
+    return w + t2;
+}
+
 __global__ __launch_bounds__(256) void bnn_swag_draw_kernel(const float* __restrict__ w_avg, const float* __restrict__ w2_avg,
                                                             const float* __restrict__ pre_D, int S, int K,
                                                             const int32_t* __restrict__ seed_idx, const float* __restrict__ z1,
@@ -270,11 +292,10 @@ DEVINL XTile<NK1> xtile(const XRaw<NK1>& r, int g) {
 // the fused kernel
 // ------------------------------------------------------------------------------------------------
 template <int NK1, bool NOISY, bool FUSED>
-__global__ __launch_bounds__(256, BNN_WAVES_PER_SIMD) void bnn_multiswag_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, (NOISY || NK1 != 8) ? 2 : BNN_WAVES_PER_SIMD) void bnn_multiswag_kernel(const FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot
     float* zsh = lds + FLAT_LDS;       // [MAXK]
-    float* slabs = zsh + MAXK;         // [4][SLAB] pre_D staging (FUSED only)
     float* f2frag = lds;               // [NF2][64] regress_nn operands in fragment order: OVERWRITES flat (below)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -304,17 +325,10 @@ __global__ __launch_bounds__(256, BNN_WAVES_PER_SIMD) void bnn_multiswag_kernel(
         const float* wa = p.w_avg + (int64_t)s * D;
         const float* w2 = p.w2_avg + (int64_t)s * D;
         const float* pd = p.pre_D + (int64_t)s * D * K;
-        float* slab = slabs + wave * SLAB;
-        for (int step = 0; step * 256 < D; ++step) {
-            const int i0 = (step * 4 + wave) * 64;
-            if (i0 < D) draw_stage(pd, i0, K, lane, slab);
-            __syncthreads();
-            const int i = i0 + lane;
-            if (i < D) {
-                float z1v = p.z1 ? p.z1[(int64_t)e * D + i] : philox_z(TAG_Z1, p.draw_id0 + e, i, p.seed);
-                flat[i] = draw_row(wa, w2, i, K, lane, slab, zsh, z1v, p.c1, p.c2, p.scale);
-            }
-            __syncthreads();
+        __syncthreads();  // zsh
+        for (int i = tid; i < D; i += 256) {
+            float z1v = p.z1 ? p.z1[(int64_t)e * D + i] : philox_z(TAG_Z1, p.draw_id0 + e, i, p.seed);
+            flat[i] = draw_row_direct(wa, w2, pd, i, K, zsh, z1v, p.c1, p.c2, p.scale);
         }
     } else {
         const float* We = p.W + (int64_t)e * D;
@@ -835,7 +849,7 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     const int64_t nsub = (p.csz + p.spc - 1) / p.spc;
     const int64_t nblk = nsub * g->J;
     if (nblk > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "grid too large; split the draws");
-    const size_t shmem = sizeof(float) * (FLAT_LDS + MAXK + (fused ? 4 * SLAB : 0));
+    const size_t shmem = sizeof(float) * (FLAT_LDS + MAXK);
     static_assert(NF2 * 64 <= FLAT_LDS, "regress_nn fragments overwrite the flat vector in place");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)nblk), block(256);

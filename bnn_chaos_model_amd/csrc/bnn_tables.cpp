@@ -106,6 +106,27 @@ Tables build_tables(uint64_t zero_mask, bool all_columns) {
             return n < 0 ? ZERO_IDX : OFF_B6 + n;
         });
 
+    // 4x4x1 image (only the v50 mask has the 31-column load pattern built into the kernel)
+    if (v50) {
+        T.f4.assign(W4_PAD, (int16_t)ZERO_IDX);
+        auto img = [&](int base, int K, int M, int off_w, int ld, int n_out, bool input_cols) {
+            for (int k = 0; k < K; ++k)
+                for (int m = 0; m < M; ++m)
+                    for (int i = 0; i < 4; ++i)
+                        for (int j = 0; j < 4; ++j) {
+                            int neuron = 4 * (4 * m + j) + i;
+                            int col = input_cols ? col4(k) : k;
+                            T.f4[base + ((k * M + m) * 4 + i) * 4 + j] = (int16_t)(neuron < n_out ? off_w + neuron * ld + col : ZERO_IDX);
+                        }
+        };
+        img(W4_L1, NLIVE4, 3, OFF_W1, F, H, true);
+        img(W4_L2, H, 3, OFF_W2, H, H, false);
+        img(W4_L3, H, 2, OFF_W3, H, L, false);
+        for (int n = 0; n < H; ++n) T.f4[W4_B1 + n] = (int16_t)(OFF_B1 + n);
+        for (int n = 0; n < H; ++n) T.f4[W4_B2 + n] = (int16_t)(OFF_B2 + n);
+        for (int n = 0; n < L; ++n) T.f4[W4_B3 + n] = (int16_t)(OFF_B3 + n);
+    }
+
     // accumulation order = k-step major, lane group (the MFMA's k index) minor
     for (int s = 0; s < nk1; ++s)
         for (int g = 0; g < 4; ++g) {
