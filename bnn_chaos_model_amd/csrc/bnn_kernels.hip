@@ -25,6 +25,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -47,6 +48,9 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
 #ifndef BNN_PRIO_STAGGER
 #define BNN_PRIO_STAGGER 0
+#endif
+#ifndef BNN_LDS_AHEAD
+#define BNN_LDS_AHEAD 2  // 4x4x1 kernel: k-steps between an LDS operand read and its MFMAs
 #endif
 #ifndef BNN_TWO_STREAMS
 #define BNN_TWO_STREAMS 0  // interleave two tiles per wave through the layers (0 = one tile at a time)
@@ -131,6 +135,7 @@ struct FwdParams {
     float* summary;
     const int16_t* tab_f1;
     const int16_t* tab_f2;
+    const int16_t* tab_f4;  // 4x4x1 image gather table (v50 mask) or nullptr
     const float* rcp_tab;  // [i] = 1/(i+1), correctly rounded
     uint64_t zero_mask;
     float std_lo, std_span;
@@ -652,6 +657,344 @@ __global__ __launch_bounds__(256, (NOISY || NK1 != 8) ? 2 : BNN_WAVES_PER_SIMD) 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Second feature_nn engine: v_mfma_f32_4x4x1_16b_f32 (bnn_layout.h, "second operand layout").
+// lane = row, so there is no padding anywhere: 310 + 400 + 200 = 910 MFMAs of 8 cycles per 64 rows (113.75 pipe
+// cycles per row against 148 for the 16x16x4 tiling).  Weights stream from an LDS image with broadcast
+// ds_read_b128 (one read feeds four MFMAs; LDS reads do not occupy the fp32 pipe), activations never leave
+// registers: a layer's accumulator registers are the next layer's B operands as they stand.
+// A wave owns 16 systems at a time: lane l = system l>>2, timestep phase l&3; tile `it` = timesteps 4it..4it+3.
+// Accumulation order per output = bias, then inputs in ascending order: the oracle's natural order.
+// Built for the v50 column mask (31 live columns), quiet forward.  Everything after the time pool (sampled
+// moments, regress_nn on the 16x16x4 path, soft_clamp) is shared with the first kernel.
+// ------------------------------------------------------------------------------------------------
+DEVINL f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+template <int CTRL>
+DEVINL float quad_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+DEVINL void load_row31(const float* __restrict__ rp, float (&xv)[NLIVE4]) {
+    xv[0] = rp[0];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4u*>(rp + 8 + 4 * q);
+        xv[1 + 4 * q] = v.x; xv[2 + 4 * q] = v.y; xv[3 + 4 * q] = v.z; xv[4 + 4 * q] = v.w;
+    }
+    f32x2 t = *reinterpret_cast<const f32x2u*>(rp + 36);
+    xv[29] = t.x; xv[30] = t.y;
+}
+
+constexpr int SCR4 = 2 * 16 * S2;  // floats of LDS scratch per wave: Philox normals + summaries of 16 systems
+
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot, later ...
+    float* f2frag = lds;               // ... [NF2][64] regress_nn operands in fragment order
+    float* zsh = lds + FLAT_LDS;       // [MAXK]
+    float* wl = zsh + MAXK;            // [W4_PAD] feature_nn image for the 4x4x1 operands
+    float* scr = wl + W4_PAD;          // [4][SCR4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;   // regress_nn (16x16x4) coordinates
+    const int sl = lane >> 2, ph = lane & 3;  // feature_nn (4x4x1) coordinates: system in the wave-batch, timestep phase
+
+    const int64_t id = blockIdx.x;
+    const int e = (int)(id % p.J);
+    const int64_t sub = id / p.J;
+    const int ch = e % p.nch;
+    const int64_t r = e / p.nch;
+    const int64_t seg0 = (int64_t)ch * p.csz;
+    const int64_t seg1 = (seg0 + p.csz < p.B) ? seg0 + p.csz : p.B;
+    const int64_t b0 = seg0 + sub * p.spc;
+    const int64_t b1 = (b0 + p.spc < seg1) ? b0 + p.spc : seg1;
+    if (b0 >= b1) return;
+
+    bool bad_seed = false;
+    if constexpr (FUSED) {
+        int s = p.seed_idx[e];
+        bad_seed = (s < 0 || s >= p.S);
+        if (bad_seed) s = 0;
+        const int K = p.K;
+        if (tid < K) zsh[tid] = p.z2 ? p.z2[(int64_t)e * K + tid] : philox_z(TAG_Z2, p.draw_id0 + e, tid, p.seed);
+        const float* wa = p.w_avg + (int64_t)s * D;
+        const float* w2 = p.w2_avg + (int64_t)s * D;
+        const float* pd = p.pre_D + (int64_t)s * D * K;
+        __syncthreads();
+        for (int i = tid; i < D; i += 256) {
+            float z1v = p.z1 ? p.z1[(int64_t)e * D + i] : philox_z(TAG_Z1, p.draw_id0 + e, i, p.seed);
+            flat[i] = draw_row_direct(wa, w2, pd, i, K, zsh, z1v, p.c1, p.c2, p.scale);
+        }
+    } else {
+        const float* We = p.W + (int64_t)e * D;
+        for (int i = tid; i < D; i += 256) flat[i] = We[i];
+    }
+    if (tid == 0) flat[ZERO_IDX] = 0.0f;
+    __syncthreads();
+    for (int i = tid; i < W4_PAD; i += 256) wl[i] = flat[p.tab_f4[i]];
+    {
+        constexpr int PER = (NF2 + 3) / 4;
+        float tmp[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int f = wave + 4 * i;
+            tmp[i] = f < NF2 ? flat[p.tab_f2[f * 64 + lane]] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int f = wave + 4 * i;
+            if (f < NF2) f2frag[f * 64 + lane] = tmp[i];
+        }
+        __syncthreads();
+    }
+
+    const int T = p.T, ntiles = p.ntiles;
+    const float nm1 = (float)(T - 1), nT = (float)T;
+    const float half_n0 = (float)ntiles * 0.5f;
+    const int64_t rowstride = (int64_t)T * F;
+    const f32x4* wq1 = reinterpret_cast<const f32x4*>(wl + W4_L1) + ph;
+    const f32x4* wq2 = reinterpret_cast<const f32x4*>(wl + W4_L2) + ph;
+    const f32x4* wq3 = reinterpret_cast<const f32x4*>(wl + W4_L3) + ph;
+    const f32x4* bq1 = reinterpret_cast<const f32x4*>(wl + W4_B1);
+    const f32x4* bq2 = reinterpret_cast<const f32x4*>(wl + W4_B2);
+    const f32x4* bq3 = reinterpret_cast<const f32x4*>(wl + W4_B3);
+    float* epsscr = scr + wave * SCR4;
+    float* sumscr = epsscr + 16 * S2;
+
+    for (int64_t wb0 = b0 + (int64_t)wave * 16; wb0 < b1; wb0 += 64) {
+        const int64_t sys = wb0 + sl;
+        const bool valid = sys < b1;
+        const int64_t sysc = valid ? sys : b1 - 1;
+        const float* rowp = p.x + sysc * rowstride + (int64_t)ph * F;
+
+        f32x4 mean[5], m2[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) { mean[n] = (f32x4){0, 0, 0, 0}; m2[n] = (f32x4){0, 0, 0, 0}; }
+
+        float xv[NLIVE4];
+        load_row31(rowp, xv);
+        asm volatile("" ::: "memory");
+        for (int it = 0; it < ntiles; ++it) {
+            // A operands are read BNN_LDS_AHEAD k-steps ahead of their MFMAs and the order is pinned with
+            // sched_group_barrier (3 LDS reads, then 10 MFMAs): left alone, the scheduler issues each read one or two
+            // MFMAs before its use and the LDS latency lands on the matrix pipe.
+            constexpr int AH = BNN_LDS_AHEAD;
+            // feature_nn.0 + ReLU
+            f32x4 h[10];
+            {
+                f32x4 q[NLIVE4][3];
+#pragma unroll
+                for (int n = 0; n < 10; ++n) h[n] = bq1[n];
+#pragma unroll
+                for (int k = 0; k < AH; ++k)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) q[k][m] = wq1[(k * 3 + m) * 4];
+                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 3 * AH, 0);
+#pragma unroll
+                for (int k = 0; k < NLIVE4; ++k) {
+                    if (k + AH < NLIVE4) {
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) q[k + AH][m] = wq1[((k + AH) * 3 + m) * 4];
+                    }
+                    const float b = xv[k];
+                    h[0] = mfma4(q[k][0].x, b, h[0]); h[1] = mfma4(q[k][0].y, b, h[1]); h[2] = mfma4(q[k][0].z, b, h[2]); h[3] = mfma4(q[k][0].w, b, h[3]);
+                    h[4] = mfma4(q[k][1].x, b, h[4]); h[5] = mfma4(q[k][1].y, b, h[5]); h[6] = mfma4(q[k][1].z, b, h[6]); h[7] = mfma4(q[k][1].w, b, h[7]);
+                    h[8] = mfma4(q[k][2].x, b, h[8]); h[9] = mfma4(q[k][2].y, b, h[9]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 10; ++n) h[n] = relu4(h[n]);
+            // x of this tile is dead: fetch the next tile's rows into the same registers (one tile of work to land)
+            {
+                const int itn = (it + 1 < ntiles) ? it + 1 : it;
+                load_row31(rowp + (int64_t)itn * 4 * F, xv);
+                asm volatile("" ::: "memory");
+            }
+            // feature_nn.2 + ReLU
+            f32x4 h2[10];
+            {
+                f32x4 q[H][3];
+#pragma unroll
+                for (int n = 0; n < 10; ++n) h2[n] = bq2[n];
+#pragma unroll
+                for (int k = 0; k < AH; ++k)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) q[k][m] = wq2[(k * 3 + m) * 4];
+                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 3 * AH, 0);
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+                    if (k + AH < H) {
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) q[k + AH][m] = wq2[((k + AH) * 3 + m) * 4];
+                    }
+                    const float b = h[k >> 2][k & 3];
+                    h2[0] = mfma4(q[k][0].x, b, h2[0]); h2[1] = mfma4(q[k][0].y, b, h2[1]); h2[2] = mfma4(q[k][0].z, b, h2[2]); h2[3] = mfma4(q[k][0].w, b, h2[3]);
+                    h2[4] = mfma4(q[k][1].x, b, h2[4]); h2[5] = mfma4(q[k][1].y, b, h2[5]); h2[6] = mfma4(q[k][1].z, b, h2[6]); h2[7] = mfma4(q[k][1].w, b, h2[7]);
+                    h2[8] = mfma4(q[k][2].x, b, h2[8]); h2[9] = mfma4(q[k][2].y, b, h2[9]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 10; ++n) h2[n] = relu4(h2[n]);
+            // feature_nn.4
+            f32x4 y[5];
+            {
+                f32x4 q[H][2];
+#pragma unroll
+                for (int n = 0; n < 5; ++n) y[n] = bq3[n];
+#pragma unroll
+                for (int k = 0; k < 2 * AH; ++k)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) q[k][m] = wq3[(k * 2 + m) * 4];
+                __builtin_amdgcn_sched_group_barrier(0x100, 5 + 4 * AH, 0);
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+                    if (k + 2 * AH < H) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) q[k + 2 * AH][m] = wq3[((k + 2 * AH) * 2 + m) * 4];
+                    }
+                    const float b = h2[k >> 2][k & 3];
+                    y[0] = mfma4(q[k][0].x, b, y[0]); y[1] = mfma4(q[k][0].y, b, y[1]); y[2] = mfma4(q[k][0].z, b, y[2]); y[3] = mfma4(q[k][0].w, b, y[3]);
+                    y[4] = mfma4(q[k][1].x, b, y[4]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                }
+            }
+            // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
+            const float rcn = p.rcp_tab[it];
+#pragma unroll
+            for (int n = 0; n < 5; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float dl = y[n][i] - mean[n][i];
+                    float mn = mean[n][i] + dl * rcn;
+                    m2[n][i] = m2[n][i] + dl * (y[n][i] - mn);
+                    mean[n][i] = mn;
+                }
+        }
+
+        // merge the 4 lanes of a quad: equal-count Chan update, symmetric (all four lanes end with the same bits)
+        {
+            float half_n = half_n0;
+#pragma unroll
+            for (int n = 0; n < 5; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float om = quad_perm<0xB1>(mean[n][i]), o2 = quad_perm<0xB1>(m2[n][i]);
+                    float dl = om - mean[n][i];
+                    float mm = (mean[n][i] + om) * 0.5f;
+                    m2[n][i] = (m2[n][i] + o2) + (dl * dl) * half_n;
+                    mean[n][i] = mm;
+                }
+            half_n = half_n * 2.0f;
+#pragma unroll
+            for (int n = 0; n < 5; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float om = quad_perm<0x4E>(mean[n][i]), o2 = quad_perm<0x4E>(m2[n][i]);
+                    float dl = om - mean[n][i];
+                    float mm = (mean[n][i] + om) * 0.5f;
+                    m2[n][i] = (m2[n][i] + o2) + (dl * dl) * half_n;
+                    mean[n][i] = mm;
+                }
+        }
+        // The quad now holds four copies of the 20 pooled (mean, M2) pairs of its system: lane `ph` finishes
+        // neurons 5ph..5ph+4 (compute_summary_stats :420-431), so the sqrt/divide sequences run once, not four times.
+        float mymean[5], mym2[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float a0 = mean[j >> 2][j & 3], a1 = mean[(5 + j) >> 2][(5 + j) & 3], a2 = mean[(10 + j) >> 2][(10 + j) & 3],
+                  a3 = mean[(15 + j) >> 2][(15 + j) & 3];
+            float c0 = m2[j >> 2][j & 3], c1 = m2[(5 + j) >> 2][(5 + j) & 3], c2 = m2[(10 + j) >> 2][(10 + j) & 3],
+                  c3 = m2[(15 + j) >> 2][(15 + j) & 3];
+            mymean[j] = ph == 0 ? a0 : ph == 1 ? a1 : ph == 2 ? a2 : a3;
+            mym2[j] = ph == 0 ? c0 : ph == 1 ? c1 : ph == 2 ? c2 : c3;
+        }
+        float e1[5], e2[5];
+        if (p.eps) {
+            const float* ep = p.eps + (r * p.B + sysc) * S2 + 5 * ph;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { e1[j] = ep[j]; e2[j] = ep[L + j]; }
+        } else {
+            // the system's 40 normals are ten Philox blocks: lane ph generates blocks ph, ph+4, ph+8 into LDS
+            const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + sysc;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int qd = ph + 4 * t;
+                if (qd < 10) *reinterpret_cast<f32x4*>(epsscr + sl * S2 + 4 * qd) = philox_eps4(grow, gsys, qd, p.seed);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { e1[j] = epsscr[sl * S2 + 5 * ph + j]; e2[j] = epsscr[sl * S2 + L + 5 * ph + j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float sample_mu = mymean[j];
+            float sd = sqrtf(mym2[j] / nm1);   // torch.std (unbiased)
+            float sample_var = sd * sd;        // **2
+            float std_in_mu = sqrtf(sample_var / nT);
+            float std_in_var = sqrtf((2.0f * (sample_var * sample_var)) / nm1);
+            float mu_s = e1[j] * std_in_mu + sample_mu;
+            float var_s = e2[j] * std_in_var + sample_var;
+            float sd_s = sqrtf(fabsf(var_s) + 1e-5f);  // EPSILON (:337)
+            sumscr[sl * S2 + 5 * ph + j] = mu_s;
+            sumscr[sl * S2 + L + 5 * ph + j] = sd_s;
+            if (p.summary && valid) {
+                float* sp = p.summary + (r * p.B + sys) * S2 + 5 * ph + j;
+                sp[0] = mu_s;
+                sp[L] = sd_s;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- regress_nn on the 16 systems of this wave-batch (16x16x4 path): column c <-> system wb0 + c
+        const int64_t sysb = wb0 + c;
+        const bool validb = sysb < b1;
+        float skeep[10];
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) skeep[ks] = sumscr[c * S2 + kmap_summary(ks, g)];
+        const float* f2l = f2frag + lane;
+        auto W2f = [&](int f) { return f2l[f * 64]; };
+        f32x4 a4[3], a5[3], a6;
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a4[mt] = (f32x4){W2f(70 + mt * 4), W2f(71 + mt * 4), W2f(72 + mt * 4), W2f(73 + mt * 4)};
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(ks * 3 + mt), skeep[ks], a4[mt]);
+        a4[0] = relu4(a4[0]); a4[1] = relu4(a4[1]); a4[2] = relu4<2>(a4[2]);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a5[mt] = (f32x4){W2f(82 + mt * 4), W2f(83 + mt * 4), W2f(84 + mt * 4), W2f(85 + mt * 4)};
+#pragma unroll
+        for (int ks = 0; ks < NKH; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(30 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
+        a5[0] = relu4(a5[0]); a5[1] = relu4(a5[1]); a5[2] = relu4<2>(a5[2]);
+        a6 = (f32x4){W2f(94), W2f(95), W2f(96), W2f(97)};
+#pragma unroll
+        for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(60 + ks), a5[ks >> 2][ks & 3], a6);
+        if (g == 0 && validb) {
+            // predict_instability + soft_clamp (:295-296, :437-442)
+            float r0 = a6[0], r1 = a6[1];
+            float mu = (0.5f * (tanhf(r0) + 1.0f)) * 8.0f + 4.0f;
+            float sd = (0.5f * (tanhf(r1) + 1.0f)) * p.std_span + p.std_lo;
+            if (bad_seed) mu = sd = __builtin_nanf("");
+            const int64_t o = (r * p.B + sysb) * 2;
+            *reinterpret_cast<f32x2*>(p.out + o) = (f32x2){mu, sd};
+            if (p.pre_clamp) *reinterpret_cast<f32x2*>(p.pre_clamp + o) = (f32x2){r0, r1};
+        }
+        __builtin_amdgcn_wave_barrier();  // scratch is reused by the next wave-batch
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
@@ -713,6 +1056,8 @@ struct bnn_plan {
     Tables tab[2];  // [0] = arch mask, [1] = all 41 columns (noisy forward)
     int16_t* d_f1[2] = {nullptr, nullptr};
     int16_t* d_f2[2] = {nullptr, nullptr};
+    int16_t* d_f4 = nullptr;  // 4x4x1 image table (v50 mask only)
+    bool use_v4 = false;      // feature_nn on the 4x4x1 engine (v50 mask, quiet forward)
     float* d_rcp = nullptr;  // [RCP_N] 1/(i+1)
     int device = 0;
 };
@@ -765,6 +1110,15 @@ int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
             return fail(BNN_ERR_HIP, "plan table upload failed");
         }
     }
+    if (!pl->tab[0].f4.empty()) {
+        size_t n4 = pl->tab[0].f4.size() * sizeof(int16_t);
+        if (hipMalloc(&pl->d_f4, n4) != hipSuccess || hipMemcpy(pl->d_f4, pl->tab[0].f4.data(), n4, hipMemcpyHostToDevice) != hipSuccess) {
+            bnn_plan_destroy(pl);
+            return fail(BNN_ERR_HIP, "plan table upload failed");
+        }
+        const char* kv = getenv("BNN_CHAOS_KERNEL");  // "16x16" forces the first engine (A/B runs)
+        pl->use_v4 = !(kv && std::string(kv) == "16x16");
+    }
     {
         std::vector<float> rc(RCP_N);
         for (int i = 0; i < RCP_N; ++i) rc[i] = 1.0f / (float)(i + 1);
@@ -785,13 +1139,19 @@ int bnn_plan_destroy(bnn_plan* pl) {
         if (pl->d_f2[v]) (void)hipFree(pl->d_f2[v]);
     }
     if (pl->d_rcp) (void)hipFree(pl->d_rcp);
+    if (pl->d_f4) (void)hipFree(pl->d_f4);
     delete pl;
     return 0;
 }
 
 int bnn_plan_layer_order(const bnn_plan* pl, int layer, int noisy, int32_t* host_order, int cap) {
     if (!pl || layer < 0 || layer > 5) return fail(BNN_ERR_INVALID, "bad plan/layer");
-    const std::vector<int32_t>& o = pl->tab[noisy ? 1 : 0].order[layer];
+    std::vector<int32_t> o = pl->tab[noisy ? 1 : 0].order[layer];
+    if (!noisy && pl->use_v4 && layer < 3) {  // 4x4x1 engine: bias first, then inputs in ascending order
+        o.clear();
+        for (int k = 0; k < (layer == 0 ? F : H); ++k)
+            if (layer != 0 || !((pl->arch.zero_mask >> k) & 1ull)) o.push_back(k);
+    }
     if (host_order)
         for (int i = 0; i < (int)o.size() && i < cap; ++i) host_order[i] = o[i];
     return (int)o.size();
@@ -843,7 +1203,7 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     p.csz = (g->B + g->nchunks - 1) / g->nchunks;
     p.spc = pick_spc(g, p.csz);
     p.row_id0 = p.draw_id0 / g->nchunks;
-    p.tab_f1 = pl->d_f1[v]; p.tab_f2 = pl->d_f2[v]; p.rcp_tab = pl->d_rcp;
+    p.tab_f1 = pl->d_f1[v]; p.tab_f2 = pl->d_f2[v]; p.tab_f4 = pl->d_f4; p.rcp_tab = pl->d_rcp;
     p.zero_mask = pl->arch.zero_mask;
     p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);
     const int64_t nsub = (p.csz + p.spc - 1) / p.spc;
@@ -863,7 +1223,20 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
         });                                                                                                        \
         hipLaunchKernelGGL((bnn_multiswag_kernel<NK, NZ, FU>), grid, block, shmem, st, p);                         \
     } while (0)
-    if (noisy) {
+    if (!noisy && nk1 == 8 && pl->use_v4) {
+        const size_t shmem4 = sizeof(float) * (FLAT_LDS + MAXK + W4_PAD + 4 * SCR4);
+#define LAUNCH4(FU)                                                                                                \
+    do {                                                                                                           \
+        static std::once_flag once;                                                                                \
+        std::call_once(once, [] {                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag4_kernel<FU>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+        });                                                                                                        \
+        hipLaunchKernelGGL((bnn_multiswag4_kernel<FU>), grid, block, shmem4, st, p);                               \
+    } while (0)
+        if (fused) LAUNCH4(true); else LAUNCH4(false);
+#undef LAUNCH4
+    } else if (noisy) {
         LAUNCH(11, true, false);
     } else if (nk1 == 8) {
         if (fused) LAUNCH(8, false, true); else LAUNCH(8, false, false);
