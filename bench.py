@@ -61,7 +61,7 @@ def synthetic_ensemble(S, device):
     return t(wa), t(w2), t(pd)
 
 
-def cpu_baseline(x_cpu, wa, w2, pd, budget_s=20.0):
+def cpu_baseline(x_cpu, wa, w2, pd, budget_s=15.0):
     """The oracle (oracle/bnn_oracle.c: fp32 C restatement, OpenMP over systems) on a bounded sample of the same
     workload: same synthetic inputs, same ensemble, a few draws, sized to about `budget_s` seconds of CPU work."""
     import numpy as np
@@ -83,10 +83,9 @@ def cpu_baseline(x_cpu, wa, w2, pd, budget_s=20.0):
         return time.perf_counter() - t0
 
     Bmax = x_cpu.shape[0]
-    run(min(Bmax, 64 * cores), 1)                      # warm the thread pool
-    t_probe = run(min(Bmax, 64 * cores), 2)
-    rate = min(Bmax, 64 * cores) * 2 / t_probe
-    Js = max(2, int(min(300, 2.5 * rate * budget_s / Bmax)))   # the 2-draw probe under-reads the rate ~2.5x (thread ramp-up)   # whole sample = Bmax systems x Js draws
+    run(Bmax, 1)                                        # warm the thread pool
+    t_probe = run(Bmax, 8)
+    Js = max(8, int(min(1000, 8 * budget_s / t_probe)))  # whole sample = Bmax systems x Js draws, about budget_s seconds
     t = run(Bmax, Js)
     return {"value": Bmax * Js / t, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": f"{Bmax} systems x {Js} draws = {Bmax * Js} evals in {t:.1f} s; same synthetic inputs and ensemble; "

@@ -49,6 +49,9 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 #ifndef BNN_PRIO_STAGGER
 #define BNN_PRIO_STAGGER 0
 #endif
+#ifndef BNN_EXP
+#define BNN_EXP 0  // timing experiments (wrong results when non-zero)
+#endif
 #ifndef BNN_LDS_AHEAD
 #define BNN_LDS_AHEAD 2  // 4x4x1 kernel: k-steps between an LDS operand read and its MFMAs
 #endif
@@ -812,11 +815,13 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
 #pragma unroll
             for (int n = 0; n < 10; ++n) h[n] = relu4(h[n]);
             // x of this tile is dead: fetch the next tile's rows into the same registers (one tile of work to land)
+#if !(BNN_EXP & 2)  // timing experiment 2: no further x loads
             {
                 const int itn = (it + 1 < ntiles) ? it + 1 : it;
                 load_row31(rowp + (int64_t)itn * 4 * F, xv);
                 asm volatile("" ::: "memory");
             }
+#endif
             // feature_nn.2 + ReLU
             f32x4 h2[10];
             {
@@ -870,6 +875,13 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
             }
             // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
             const float rcn = p.rcp_tab[it];
+#if BNN_EXP & 1  // timing experiment: pool replaced by integer ops (co-issue with the matrix pipe)
+#pragma unroll
+            for (int n = 0; n < 5; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    mean[n][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, mean[n][i]) ^ __builtin_bit_cast(int, y[n][i]));
+#else
 #pragma unroll
             for (int n = 0; n < 5; ++n)
 #pragma unroll
@@ -879,6 +891,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
                     m2[n][i] = m2[n][i] + dl * (y[n][i] - mn);
                     mean[n][i] = mn;
                 }
+#endif
         }
 
         // merge the 4 lanes of a quad: equal-count Chan update, symmetric (all four lanes end with the same bits)
@@ -1181,8 +1194,9 @@ int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host
 
 static int pick_spc(const bnn_grid* g, int64_t csz) {
     if (g->systems_per_block > 0) return g->systems_per_block;
-    // enough workgroups to fill 256 CUs several times over, else shrink the block
-    for (int spc : {256, 128}) {
+    // The per-workgroup prologue (flat vector -> LDS operand images) is amortised over the block: prefer big blocks
+    // (512 systems: +1.7 % over 256 at configs[1]) as long as the grid still fills 256 CUs x 2 several times over.
+    for (int spc : {512, 256, 128}) {
         int64_t nsub = (csz + spc - 1) / spc;
         if (nsub * (int64_t)g->J >= 4096) return spc;
     }

@@ -34,7 +34,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv
             pmc[name]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in pmc.items()}
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
-dom = [k for k in out if "multiswag_kernel" in k]
+dom = [k for k in out if "multiswag" in k]
 if dom:
     d = out[dom[0]]
     fetch_kib, write_kib = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)
