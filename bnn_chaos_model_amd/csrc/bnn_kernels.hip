@@ -1272,6 +1272,7 @@ static int draw_consts(int K, float scale, float* c1, float* c2) {
 int bnn_swag_draw_f32(const bnn_plan* plan, const float* w_avg, const float* w2_avg, const float* pre_D, int32_t S, int32_t K,
                       const int32_t* seed_idx, int32_t J, const float* z1, const float* z2, float scale, uint64_t philox_seed,
                       int64_t draw_id0, float* W_out, void* stream) {
+    if (J == 0) return 0;
     if (!plan || !w_avg || !w2_avg || !pre_D || !seed_idx || !W_out) return fail(BNN_ERR_INVALID, "NULL argument");
     if ((z1 == nullptr) != (z2 == nullptr)) return fail(BNN_ERR_INVALID, "z1 and z2 must both be given or both be NULL");
     if (S < 1 || J < 0) return fail(BNN_ERR_INVALID, "bad S/J");
@@ -1289,6 +1290,7 @@ int bnn_swag_draw_f32(const bnn_plan* plan, const float* w_avg, const float* w2_
 int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps, const float* eps_in,
                     const float* eps_sum, uint64_t philox_seed, int64_t draw_id0, int64_t system_id0, float* out, float* pre_clamp,
                     float* summary, void* stream) {
+    if (grid && (grid->B == 0 || grid->J == 0)) return 0;
     if (!W) return fail(BNN_ERR_INVALID, "W is NULL");
     if ((eps_in == nullptr) != (eps_sum == nullptr)) return fail(BNN_ERR_INVALID, "eps_in and eps_sum must both be given or both be NULL");
     if (eps_in && !eps) return fail(BNN_ERR_UNSUPPORTED, "noisy forward needs explicit eps as well (in-kernel input noise is not built yet)");
@@ -1303,6 +1305,8 @@ int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x
                       const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx, const float* z1, const float* z2,
                       const float* eps, float scale, uint64_t philox_seed, int64_t draw_id0, int64_t system_id0,
                       float* W_workspace, float* out, float* pre_clamp, float* summary, void* stream) {
+    if (!plan || !grid) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
+    if (grid->B == 0 || grid->J == 0) return 0;  // nothing to do (empty tensors have NULL data pointers)
     if (!w_avg || !w2_avg || !pre_D || !seed_idx) return fail(BNN_ERR_INVALID, "NULL ensemble argument");
     if (W_workspace) {  // sample every draw once, then the forward kernel reads the materialised vectors
         if (!grid) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
