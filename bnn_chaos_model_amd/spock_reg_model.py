@@ -30,29 +30,20 @@ from .checkpoint import AttributeDict, read_swag_file, write_swag_file
 
 EPSILON = 1e-5  # spock_reg_model.py:337
 
-# hard-coded v50 scaler of the reference (spock_reg_model.py:931-957)
-_V50_SCALE = np.array([2.88976974e+03, 6.10019661e-02, 4.03849732e-02, 4.81638693e+01,
-                       6.72583662e-02, 4.17939679e-02, 8.15995339e+00, 2.26871589e+01,
-                       4.73612029e-03, 7.09223721e-02, 3.06455099e-02, 7.10726478e-01,
-                       7.03392022e-01, 7.07873597e-01, 7.06030923e-01, 7.04728204e-01,
-                       7.09420909e-01, 1.90740659e-01, 4.75502285e-02, 2.77188320e-02,
-                       7.08891412e-01, 7.05214134e-01, 7.09786887e-01, 7.04371833e-01,
-                       7.04371110e-01, 7.09828420e-01, 3.33589977e-01, 5.20857790e-02,
-                       2.84763136e-02, 7.02210626e-01, 7.11815232e-01, 7.10512240e-01,
-                       7.03646004e-01, 7.08017286e-01, 7.06162814e-01, 2.12569430e-05,
-                       2.35019125e-05, 2.04211110e-05, 7.51048890e-02, 3.94254400e-01,
-                       7.11351099e-02])
-_V50_MEAN = np.array([4.95458585e+03, 5.67411891e-02, 3.83176945e-02, 2.97223474e+00,
-                      6.29733979e-02, 3.50074471e-02, 6.72845676e-01, 9.92794768e+00,
-                      9.99628430e-01, 5.39591547e-02, 2.92795061e-02, 2.12480714e-03,
-                      -1.01500319e-02, 1.82667162e-02, 1.00813201e-02, 5.74404197e-03,
-                      6.86570242e-03, 1.25316320e+00, 4.76946516e-02, 2.71326280e-02,
-                      7.02054326e-03, 9.83378673e-03, -5.70616748e-03, 5.50782881e-03,
-                      -8.44213953e-04, 2.05958338e-03, 1.57866569e+00, 4.31476211e-02,
-                      2.73316392e-02, 1.05505555e-02, 1.03922250e-02, 7.36865006e-03,
-                      -6.00523246e-04, 6.53016990e-03, -1.72038113e-03, 1.24807860e-05,
-                      1.60314173e-05, 1.21732696e-05, 5.67292645e-03, 1.92488263e-01,
-                      5.08607199e-03])
+# The reference attaches one fixed StandardScaler to every 'v50' checkpoint (spock_reg_model.py:931-957); its 2 x 41
+# float64 constants live in data/v50_ssx.json.
+_V50 = None
+
+
+def _v50_constants():
+    global _V50
+    if _V50 is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "v50_ssx.json")) as f:
+            d = json.load(f)
+        _V50 = (np.array(d["mean_"], dtype=np.float64), np.array(d["scale_"], dtype=np.float64))
+    return _V50
 
 
 class StandardScaler:
@@ -74,7 +65,8 @@ class StandardScaler:
 
 
 def v50_scaler():
-    return StandardScaler(_V50_MEAN, _V50_SCALE)
+    mean_, scale_ = _v50_constants()
+    return StandardScaler(mean_.copy(), scale_.copy())
 
 
 def soft_clamp(x, lo, high):
