@@ -66,7 +66,7 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 // Philox4x32-10 (Salmon et al., SC'11) and the normals derived from it.
 // Counters use GLOBAL draw / output-row / system ids, so results are invariant to sharding.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t TAG_Z1 = 0x10000000u, TAG_Z2 = 0x20000000u, TAG_EPS = 0x30000000u;
+constexpr uint32_t TAG_Z1 = 0x10000000u, TAG_Z2 = 0x20000000u, TAG_EPS = 0x30000000u, TAG_IN = 0x40000000u, TAG_SUM = 0x50000000u;
 
 DEVINL uint4 philox4x32_10(uint4 c, uint2 k) {
 #pragma unroll
@@ -104,10 +104,13 @@ DEVINL float philox_z(uint32_t tag, int64_t draw, int elem, uint64_t seed) {
     return n[elem & 3];
 }
 // eps[row][sys][kind][n], quad = (kind*20 + n) / 4: counter = (tag | quad, sys lo, sys hi16 | row hi16 << 16, row lo)
-DEVINL f32x4 philox_eps4(int64_t row, int64_t sys, int quad, uint64_t seed) {
+DEVINL f32x4 philox_sys4(uint32_t tag, int64_t row, int64_t sys, int quad, uint64_t seed) {
     uint32_t c2 = (uint32_t)(((uint64_t)sys >> 32) & 0xffffu) | ((uint32_t)(((uint64_t)row >> 32) & 0xffffu) << 16);
-    return philox_normal4(TAG_EPS | (uint32_t)quad, (uint32_t)sys, c2, (uint32_t)row, seed);
+    return philox_normal4(tag | (uint32_t)quad, (uint32_t)sys, c2, (uint32_t)row, seed);
 }
+DEVINL f32x4 philox_eps4(int64_t row, int64_t sys, int quad, uint64_t seed) { return philox_sys4(TAG_EPS, row, sys, quad, seed); }
+// input noise eps_in[row][sys][t][col] (:445): quad = t*11 + col/4 (rows padded to 44 so quads align with 4-column groups);
+// summary noise eps_sum[row][sys][n] (:449): quad = n/4.
 
 // ------------------------------------------------------------------------------------------------
 // kernel parameters
@@ -403,17 +406,37 @@ __global__ __launch_bounds__(256, (NOISY || NK1 != 8) ? 2 : BNN_WAVES_PER_SIMD) 
             const int64_t sysc = valid ? sys : b1 - 1;
             const float* rowp = p.x + sysc * rowstride + (int64_t)(c & 3) * F;
             const float* epin = nullptr;
-            if constexpr (NOISY) epin = p.eps_in + (r * p.B + sysc) * rowstride + (int64_t)(c & 3) * F;
+            if constexpr (NOISY) {
+                if (p.eps_in) epin = p.eps_in + (r * p.B + sysc) * rowstride + (int64_t)(c & 3) * F;
+            }
 
             f32x4 mean0 = {0, 0, 0, 0}, m20 = {0, 0, 0, 0};
             float mean1 = 0.0f, m21 = 0.0f;
 
             // ---- building blocks of one 16-row tile ----------------------------------------------------------
-            auto make_cur = [&](const XRaw<NK1>& raw, const XRaw<NK1>& nraw) {
+            auto make_cur = [&](const XRaw<NK1>& raw, const XRaw<NK1>& nraw, const int it_cur) {
                 XTile<NK1> cur = xtile<NK1>(raw, g);
                 if constexpr (NOISY) {
                     // masks then add_input_noise (:486-504): masked columns become pure noise
-                    XTile<NK1> ncur = xtile<NK1>(nraw, g);
+                    XTile<NK1> ncur;
+                    if (p.eps_in) {
+                        ncur = xtile<NK1>(nraw, g);
+                    } else {
+                        // this lane's 11 columns 11g..11g+10 sit in Philox quads q0..q0+3 of row t (q0 = 11g/4)
+                        const int t = 4 * it_cur + (c & 3);
+                        const int q0 = (11 * g) >> 2, off = 11 * g - 4 * q0;
+                        float f16[16];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            f32x4 n4 = philox_sys4(TAG_IN, p.row_id0 + r, p.sys_id0 + sysc, t * 11 + q0 + b, p.seed);
+                            f16[4 * b] = n4.x; f16[4 * b + 1] = n4.y; f16[4 * b + 2] = n4.z; f16[4 * b + 3] = n4.w;
+                        }
+#pragma unroll
+                        for (int s = 0; s < NK1; ++s) {
+                            float v0 = f16[s], v1 = f16[s + 1], v2 = f16[s + 2], v3 = f16[s + 3];
+                            ncur.v[s] = off == 0 ? v0 : off == 1 ? v1 : off == 2 ? v2 : v3;
+                        }
+                    }
 #pragma unroll
                     for (int s = 0; s < NK1; ++s) {
                         int col = 11 * g + s;
@@ -482,7 +505,9 @@ __global__ __launch_bounds__(256, (NOISY || NK1 != 8) ? 2 : BNN_WAVES_PER_SIMD) 
             auto prefetch = [&](XRaw<NK1>& raw, XRaw<NK1>& nraw, int it) {
                 const int itc = it < ntiles ? it : ntiles - 1;  // past the end: re-read the last tile (no overrun)
                 raw = load_x<NK1>(rowp + (int64_t)itc * 4 * F, g);
-                if constexpr (NOISY) nraw = load_x<NK1>(epin + (int64_t)itc * 4 * F, g);
+                if constexpr (NOISY) {
+                    if (p.eps_in) nraw = load_x<NK1>(epin + (int64_t)itc * 4 * F, g);
+                }
             };
             auto pin_loads = [&]() {
                 asm volatile("" ::: "memory");
@@ -499,7 +524,7 @@ __global__ __launch_bounds__(256, (NOISY || NK1 != 8) ? 2 : BNN_WAVES_PER_SIMD) 
                 prefetch(rawB, nrawB, 1);
                 pin_loads();
                 for (; it + 1 < ntiles; it += 2) {
-                    XTile<NK1> curA = make_cur(rawA, nrawA), curB = make_cur(rawB, nrawB);
+                    XTile<NK1> curA = make_cur(rawA, nrawA, it), curB = make_cur(rawB, nrawB, it + 1);
                     prefetch(rawA, nrawA, it + 2);   // one pair ahead, into the registers just consumed
                     prefetch(rawB, nrawB, it + 3);
                     pin_loads();
@@ -517,13 +542,13 @@ __global__ __launch_bounds__(256, (NOISY || NK1 != 8) ? 2 : BNN_WAVES_PER_SIMD) 
                     pool(yB, it + 1);
                 }
                 if (it < ntiles) {  // odd tile count: rawA already holds the last tile
-                    H2 y = layer3(relu3(layer2(relu3(layer1(make_cur(rawA, nrawA))))));
+                    H2 y = layer3(relu3(layer2(relu3(layer1(make_cur(rawA, nrawA, it))))));
                     pool(y, it);
                 }
             } else {
                 // one tile at a time, next tile prefetched into a ping-pong pair of register sets
                 auto do_tile = [&](const XRaw<NK1>& raw, const XRaw<NK1>& nraw, const int t) {
-                    H2 y = layer3(relu3(layer2(relu3(layer1(make_cur(raw, nraw))))));
+                    H2 y = layer3(relu3(layer2(relu3(layer1(make_cur(raw, nraw, t))))));
                     pool(y, t);
                 };
                 prefetch(rawA, nrawA, 0);
@@ -619,11 +644,20 @@ __global__ __launch_bounds__(256, (NOISY || NK1 != 8) ? 2 : BNN_WAVES_PER_SIMD) 
         if constexpr (NOISY) {
             // add_summary_noise (:448-450)
             const int64_t sc = validb ? sysb : b1 - 1;
-            const float* es = p.eps_sum + (r * p.B + sc) * S2;
+            if (p.eps_sum) {
+                const float* es = p.eps_sum + (r * p.B + sc) * S2;
 #pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                int n = kmap_summary(k, g);
-                skeep[k] = skeep[k] + es[n] * sum_scale[k];
+                for (int k = 0; k < 10; ++k) skeep[k] = skeep[k] + es[kmap_summary(k, g)] * sum_scale[k];
+            } else {
+                const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + sc;
+#pragma unroll
+                for (int kind = 0; kind < 2; ++kind) {
+                    f32x4 a4n = philox_sys4(TAG_SUM, grow, gsys, kind * 5 + g, p.seed);
+                    float bn = philox_sys4(TAG_SUM, grow, gsys, kind * 5 + 4, p.seed)[g];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) skeep[kind * 5 + rr] = skeep[kind * 5 + rr] + a4n[rr] * sum_scale[kind * 5 + rr];
+                    skeep[kind * 5 + 4] = skeep[kind * 5 + 4] + bn * sum_scale[kind * 5 + 4];
+                }
             }
         }
         const float* f2l = f2frag + lane;
@@ -1033,12 +1067,19 @@ __global__ void bnn_philox_fill_kernel(int kind, uint64_t seed, int64_t id0, int
         int64_t row = i / width;
         int el = (int)(i % width);
         out[i] = philox_z(kind == 0 ? TAG_Z1 : TAG_Z2, id0 + row, el, seed);
-    } else {
+    } else if (kind == 2 || kind == 4) {
         int64_t total = n_rows * B * S2;
         if (i >= total) return;
         int el = (int)(i % S2);
         int64_t sys = (i / S2) % B, row = i / (S2 * B);
-        out[i] = philox_eps4(id0 + row, sys0 + sys, el >> 2, seed)[el & 3];
+        out[i] = philox_sys4(kind == 2 ? TAG_EPS : TAG_SUM, id0 + row, sys0 + sys, el >> 2, seed)[el & 3];
+    } else {  // kind 3: eps_in [n_rows, B, T = width, 41]
+        const int T = width;
+        int64_t per = (int64_t)T * F, total = n_rows * B * per;
+        if (i >= total) return;
+        int col = (int)(i % F), t = (int)((i / F) % T);
+        int64_t sys = (i / per) % B, row = i / (per * B);
+        out[i] = philox_sys4(TAG_IN, id0 + row, sys0 + sys, t * 11 + (col >> 2), seed)[col & 3];
     }
 }
 
@@ -1293,12 +1334,14 @@ int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, 
     if (grid && (grid->B == 0 || grid->J == 0)) return 0;
     if (!W) return fail(BNN_ERR_INVALID, "W is NULL");
     if ((eps_in == nullptr) != (eps_sum == nullptr)) return fail(BNN_ERR_INVALID, "eps_in and eps_sum must both be given or both be NULL");
-    if (eps_in && !eps) return fail(BNN_ERR_UNSUPPORTED, "noisy forward needs explicit eps as well (in-kernel input noise is not built yet)");
+    if (eps_in && !eps) return fail(BNN_ERR_INVALID, "explicit noise is all-or-nothing: eps_in/eps_sum need eps as well");
+    const bool noisy = eps_in != nullptr || (grid && grid->noisy);
+    if (noisy && !eps_in && eps) return fail(BNN_ERR_INVALID, "explicit noise is all-or-nothing: grid.noisy with eps but no eps_in/eps_sum");
     FwdParams p{};
     p.x = x; p.W = W; p.eps = eps; p.eps_in = eps_in; p.eps_sum = eps_sum;
     p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
     p.out = out; p.pre_clamp = pre_clamp; p.summary = summary;
-    return launch_forward(plan, grid, p, false, eps_in != nullptr, stream);
+    return launch_forward(plan, grid, p, false, noisy, stream);
 }
 
 int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg, const float* w2_avg,
@@ -1339,8 +1382,8 @@ int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments,
 
 int bnn_philox_normal_f32(int32_t kind, uint64_t philox_seed, int64_t id0, int64_t n_rows, int64_t B, int64_t system_id0, int32_t width,
                           float* out, void* stream) {
-    if (!out || kind < 0 || kind > 2 || n_rows < 0) return fail(BNN_ERR_INVALID, "bad argument");
-    int64_t total = (kind == 2) ? n_rows * B * S2 : n_rows * (int64_t)width;
+    if (!out || kind < 0 || kind > 4 || n_rows < 0) return fail(BNN_ERR_INVALID, "bad argument");
+    int64_t total = (kind == 2 || kind == 4) ? n_rows * B * S2 : kind == 3 ? n_rows * B * (int64_t)width * F : n_rows * (int64_t)width;
     if (total == 0) return 0;
     hipLaunchKernelGGL(bnn_philox_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind, philox_seed,
                        id0, n_rows, B, system_id0, width, out);

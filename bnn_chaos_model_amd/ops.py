@@ -48,8 +48,8 @@ def _f32(t, name):
     return t.contiguous()
 
 
-def _grid(B, T, J, nchunks, spb):
-    return N.BnnGrid(int(B), int(T), int(J), int(nchunks), int(spb))
+def _grid(B, T, J, nchunks, spb, noisy=False):
+    return N.BnnGrid(int(B), int(T), int(J), int(nchunks), int(spb), int(bool(noisy)), 0)
 
 
 def swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, scale=0.5, philox_seed=0, draw_id0=0, plan=None):
@@ -74,11 +74,12 @@ def swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, scale=0.5, philo
 
 
 def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0, draw_id0=0, system_id0=0, plan=None,
-            debug=False, systems_per_block=0):
+            debug=False, systems_per_block=0, noisy=False):
     """VarModel.forward (spock_reg_model.py:486-528) for materialised weight vectors W[J,d] -> out[J/nchunks,B,2].
 
     eps [R,B,2,20] = the two randn_like of compute_summary_stats (:426-427) or None (Philox);
-    eps_in [R,B,T,41] + eps_sum [R,B,40] switch on noisy_val=True (:444-450)."""
+    eps_in [R,B,T,41] + eps_sum [R,B,40] switch on noisy_val=True (:444-450); noisy=True with no noise tensors at all
+    is noisy_val=True with every normal generated in-kernel (Philox)."""
     plan = plan or get_plan()
     x, W = _f32(x, "x"), _f32(W, "W")
     if x.dim() != 3 or x.shape[2] != 41:
@@ -92,7 +93,7 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     out = torch.empty((R, B, 2), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, 2 * LATENT), dtype=torch.float32, device=x.device) if debug else None
-    g = _grid(B, T, J, nchunks, systems_per_block)
+    g = _grid(B, T, J, nchunks, systems_per_block, noisy)
     N.check(N.lib().bnn_forward_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(W), N.ptr(eps), N.ptr(eps_in), N.ptr(eps_sum),
                                     int(philox_seed), int(draw_id0), int(system_id0), N.ptr(out), N.ptr(pre), N.ptr(summ),
                                     N.stream_ptr()))
@@ -164,8 +165,9 @@ def moments(samples, mom=None):
 
 
 def philox_normal(kind, philox_seed, id0, n_rows, width=0, B=0, system_id0=0, device="cuda"):
-    """The normals the kernels generate in-kernel: kind 0 -> z1[n_rows,width], 1 -> z2[n_rows,width], 2 -> eps[n_rows,B,2,20]."""
-    shape = (n_rows, B, 2, LATENT) if kind == 2 else (n_rows, width)
+    """The normals the kernels generate in-kernel: kind 0 -> z1[n_rows,width], 1 -> z2[n_rows,width], 2 -> eps[n_rows,B,2,20],
+    3 -> eps_in[n_rows,B,T=width,41], 4 -> eps_sum[n_rows,B,40]."""
+    shape = {2: (n_rows, B, 2, LATENT), 3: (n_rows, B, width, 41), 4: (n_rows, B, 2 * LATENT)}.get(kind, (n_rows, width))
     out = torch.empty(shape, dtype=torch.float32, device=device)
     N.check(N.lib().bnn_philox_normal_f32(kind, int(philox_seed), int(id0), n_rows, B, int(system_id0), width, N.ptr(out),
                                           N.stream_ptr()))

@@ -285,10 +285,8 @@ class VarModel:
                 eps_sum = eps_sum[None].to(g).contiguous()
             res = ops.forward(xg, W.to(g), eps=eps, eps_in=eps_in, eps_sum=eps_sum, plan=self._plan(), debug=want_debug)
         else:
-            if noisy:
-                raise NotImplementedError("rng='philox' is built for forward_swag_fast / noisy_val=False only")
             res = ops.forward(xg, W.to(g), philox_seed=self.philox_seed, draw_id0=self._next_philox_id(),
-                              plan=self._plan(), debug=want_debug)
+                              plan=self._plan(), debug=want_debug, noisy=noisy)
         if want_debug:
             return tuple(r[0].to(dev_in) for r in res)
         return res[0].to(dev_in)

@@ -84,6 +84,9 @@ typedef struct bnn_grid {
                         1 = every draw covers all systems (dense systems x draws grid).
                         figures/multiswag_5_planet.py:295-298 is nchunks = 10.                     */
     int32_t systems_per_block; /* 0 = choose; else a multiple of 64                                */
+    int32_t noisy;   /* bnn_forward_f32 only: 1 = forward(noisy_val=True) with ALL noise generated in-kernel
+                        (eps, eps_in, eps_sum all NULL); explicit eps_in/eps_sum imply noisy regardless          */
+    int32_t reserved;
 } bnn_grid;
 
 /* SWAGModel.sample_weights (spock_reg_model.py:815-838), J draws at once.
@@ -129,8 +132,9 @@ int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x
 int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments, int32_t accumulate, void* stream);
 
 /* The normals the kernels generate when a noise pointer is NULL, written out for inspection:
- *   kind 0: z1 [n_draws, d]   kind 1: z2 [n_draws, K]   kind 2: eps [n_draws(rows), B, 2, 20]
- *   id0 = draw_id0 (kinds 0,1) or output-row id0 (kind 2); system_id0 only for kind 2. */
+ *   kind 0: z1 [n_draws, d]   kind 1: z2 [n_draws, K]   kind 2: eps [rows, B, 2, 20]
+ *   kind 3: eps_in [rows, B, T = width, 41]   kind 4: eps_sum [rows, B, 40]
+ *   id0 = draw_id0 (kinds 0,1) or output-row id0 (kinds 2-4); system_id0 only for kinds 2-4. */
 int bnn_philox_normal_f32(int32_t kind, uint64_t philox_seed, int64_t id0, int64_t n_rows, int64_t B,
                           int64_t system_id0, int32_t width, float* out, void* stream);
 

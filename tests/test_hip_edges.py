@@ -174,3 +174,44 @@ def test_both_engines_agree_with_the_reference_fixture():
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(ROOT, "tests", "test_hip_parity.py")],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_noisy_forward_in_kernel_noise_equals_explicit(ops, swag_states):
+    """forward(noisy_val=True) with every normal generated in-kernel == the same call fed the generated normals explicitly."""
+    B, R, seed = 37, 3, 77
+    x = dev(synth(B, 100, 8))
+    W = dev(np.stack([swag_states[0]["w_avg"], swag_states[12]["w_avg"], swag_states[0]["w_avg"]]))
+    a = ops.forward(x, W, philox_seed=seed, draw_id0=4, system_id0=1000, noisy=True)
+    eps = ops.philox_normal(2, seed, 4, R, B=B, system_id0=1000)
+    e_in = ops.philox_normal(3, seed, 4, R, width=100, B=B, system_id0=1000)
+    e_sum = ops.philox_normal(4, seed, 4, R, B=B, system_id0=1000)
+    b = ops.forward(x, W, eps=eps, eps_in=e_in, eps_sum=e_sum)
+    assert torch.equal(a, b)
+    # sharding invariance and plausibility of the input-noise normals
+    c = ops.forward(x[20:].contiguous(), W, philox_seed=seed, draw_id0=4, system_id0=1020, noisy=True)
+    assert torch.equal(a[:, 20:], c)
+    n = e_in.flatten().double().cpu().numpy()
+    assert abs(n.mean()) < 0.01 and abs(n.std() - 1) < 0.01
+    quiet = ops.forward(x, W, philox_seed=seed, draw_id0=4, system_id0=1000)
+    assert not torch.equal(a, quiet)
+
+
+def test_sample_with_philox_rng(swag_states, tmp_path):
+    """VarModel.sample with rng='philox': same estimator, in-kernel noise; agrees statistically with the torch-rng path."""
+    import json
+    from bnn_chaos_model_amd import checkpoint, spock_reg_model as srm
+    from conftest import load_golden
+    z = load_golden("swag_v50_0.npz")
+    p = tmp_path / "m_v50_0_output.pkl"
+    checkpoint.write_swag_file(str(p), json.loads(str(z["hparams_json"])), json.loads(str(z["swa_params_json"])),
+                               torch.tensor(z["w_avg"]), torch.tensor(z["w2_avg"]), torch.tensor(z["pre_D"]))
+    m = srm.load_swag(str(p))
+    m.load(m.w_avg)
+    x = torch.tensor(synth(16, 100, 4))
+    torch.manual_seed(0); np.random.seed(0)
+    a = m.sample(x, samples=200)
+    m.rng, m.philox_seed = "philox", 5
+    np.random.seed(1)
+    b = m.sample(x, samples=200)
+    assert a.shape == b.shape == (16,)
+    assert np.abs(a - b).max() < 2.0  # means of 200 draws with std up to 6: SE of the difference <= 0.6
