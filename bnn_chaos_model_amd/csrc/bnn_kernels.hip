@@ -49,11 +49,24 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 #ifndef BNN_PRIO_STAGGER
 #define BNN_PRIO_STAGGER 0
 #endif
+#ifndef BNN_STAMPS
+#define BNN_STAMPS 0  // diagnostic build: wave 0 of each workgroup of the 4x4x1 kernel sums s_memtime deltas per phase
+#endif                // into the pre_clamp buffer (as uint64 [block][12]); never enabled in the shipped library
+#if BNN_STAMPS
+#define STAMP(i)                                                                 \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        unsigned long long _t;                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); \
+        st_acc[i] += _t - st_prev;                                               \
+        st_prev = _t;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 #ifndef BNN_EXP
 #define BNN_EXP 0  // timing experiments (wrong results when non-zero)
-#endif
-#ifndef BNN_LDS_AHEAD
-#define BNN_LDS_AHEAD 2  // 4x4x1 kernel: k-steps between an LDS operand read and its MFMAs
 #endif
 #ifndef BNN_TWO_STREAMS
 #define BNN_TWO_STREAMS 0  // interleave two tiles per wave through the layers (0 = one tile at a time)
@@ -751,6 +764,10 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
     const int64_t b1 = (b0 + p.spc < seg1) ? b0 + p.spc : seg1;
     if (b0 >= b1) return;
 
+#if BNN_STAMPS
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
     bool bad_seed = false;
     if constexpr (FUSED) {
         int s = p.seed_idx[e];
@@ -790,13 +807,17 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
         __syncthreads();
     }
 
+    STAMP(0);  // prologue
     const int T = p.T, ntiles = p.ntiles;
     const float nm1 = (float)(T - 1), nT = (float)T;
     const float half_n0 = (float)ntiles * 0.5f;
     const int64_t rowstride = (int64_t)T * F;
-    const f32x4* wq1 = reinterpret_cast<const f32x4*>(wl + W4_L1) + ph;
-    const f32x4* wq2 = reinterpret_cast<const f32x4*>(wl + W4_L2) + ph;
-    const f32x4* wq3 = reinterpret_cast<const f32x4*>(wl + W4_L3) + ph;
+    const f32x4* wqA1 = reinterpret_cast<const f32x4*>(wl + W4_L1A) + ph;
+    const f32x4* wqB1 = reinterpret_cast<const f32x4*>(wl + W4_L1B) + ph;
+    const f32x4* wqA2 = reinterpret_cast<const f32x4*>(wl + W4_L2A) + ph;
+    const f32x4* wqB2 = reinterpret_cast<const f32x4*>(wl + W4_L2B) + ph;
+    const f32x4* wqA3 = reinterpret_cast<const f32x4*>(wl + W4_L3A) + ph;
+    const f32x4* wqB3 = reinterpret_cast<const f32x4*>(wl + W4_L3B) + ph;
     const f32x4* bq1 = reinterpret_cast<const f32x4*>(wl + W4_B1);
     const f32x4* bq2 = reinterpret_cast<const f32x4*>(wl + W4_B2);
     const f32x4* bq3 = reinterpret_cast<const f32x4*>(wl + W4_B3);
@@ -816,36 +837,45 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
         float xv[NLIVE4];
         load_row31(rowp, xv);
         asm volatile("" ::: "memory");
+        STAMP(1);  // batch setup + first row load issue
         for (int it = 0; it < ntiles; ++it) {
-            // A operands are read BNN_LDS_AHEAD k-steps ahead of their MFMAs and the order is pinned with
-            // sched_group_barrier (3 LDS reads, then 10 MFMAs): left alone, the scheduler issues each read one or two
+            // A operands are read one group of 20 MFMAs ahead of their use and the order is pinned with
+            // sched_group_barrier (5 LDS reads, then 20 MFMAs): left alone, the scheduler issues each read one or two
             // MFMAs before its use and the LDS latency lands on the matrix pipe.
-            constexpr int AH = BNN_LDS_AHEAD;
-            // feature_nn.0 + ReLU
+            // feature_nn.0 + ReLU: pairs of input columns (k0, k1): reads A(k0,m0) A(k0,m1) A(k1,m0) A(k1,m1) B(pair)
             f32x4 h[10];
             {
-                f32x4 q[NLIVE4][3];
+                constexpr int NP = (NLIVE4 + 1) / 2;  // 16 pairs, the last one holds only k = 30
+                f32x4 q[NP][5];
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h[n] = bq1[n];
+                auto rd = [&](int kp) {
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    q[kp][0] = wqA1[(k0 * 2 + 0) * 4]; q[kp][1] = wqA1[(k0 * 2 + 1) * 4];
+                    if (k1 < NLIVE4) { q[kp][2] = wqA1[(k1 * 2 + 0) * 4]; q[kp][3] = wqA1[(k1 * 2 + 1) * 4]; }
+                    q[kp][4] = wqB1[kp * 4];
+                };
+                rd(0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
 #pragma unroll
-                for (int k = 0; k < AH; ++k)
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) q[k][m] = wq1[(k * 3 + m) * 4];
-                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 3 * AH, 0);
-#pragma unroll
-                for (int k = 0; k < NLIVE4; ++k) {
-                    if (k + AH < NLIVE4) {
-#pragma unroll
-                        for (int m = 0; m < 3; ++m) q[k + AH][m] = wq1[((k + AH) * 3 + m) * 4];
+                for (int kp = 0; kp < NP; ++kp) {
+                    if (kp + 1 < NP) rd(kp + 1);
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    const float b0 = xv[k0];
+                    h[0] = mfma4(q[kp][0].x, b0, h[0]); h[1] = mfma4(q[kp][0].y, b0, h[1]); h[2] = mfma4(q[kp][0].z, b0, h[2]); h[3] = mfma4(q[kp][0].w, b0, h[3]);
+                    h[4] = mfma4(q[kp][1].x, b0, h[4]); h[5] = mfma4(q[kp][1].y, b0, h[5]); h[6] = mfma4(q[kp][1].z, b0, h[6]); h[7] = mfma4(q[kp][1].w, b0, h[7]);
+                    h[8] = mfma4(q[kp][4].x, b0, h[8]); h[9] = mfma4(q[kp][4].y, b0, h[9]);
+                    if (k1 < NLIVE4) {
+                        const float b1v = xv[k1];
+                        h[0] = mfma4(q[kp][2].x, b1v, h[0]); h[1] = mfma4(q[kp][2].y, b1v, h[1]); h[2] = mfma4(q[kp][2].z, b1v, h[2]); h[3] = mfma4(q[kp][2].w, b1v, h[3]);
+                        h[4] = mfma4(q[kp][3].x, b1v, h[4]); h[5] = mfma4(q[kp][3].y, b1v, h[5]); h[6] = mfma4(q[kp][3].z, b1v, h[6]); h[7] = mfma4(q[kp][3].w, b1v, h[7]);
+                        h[8] = mfma4(q[kp][4].z, b1v, h[8]); h[9] = mfma4(q[kp][4].w, b1v, h[9]);
                     }
-                    const float b = xv[k];
-                    h[0] = mfma4(q[k][0].x, b, h[0]); h[1] = mfma4(q[k][0].y, b, h[1]); h[2] = mfma4(q[k][0].z, b, h[2]); h[3] = mfma4(q[k][0].w, b, h[3]);
-                    h[4] = mfma4(q[k][1].x, b, h[4]); h[5] = mfma4(q[k][1].y, b, h[5]); h[6] = mfma4(q[k][1].z, b, h[6]); h[7] = mfma4(q[k][1].w, b, h[7]);
-                    h[8] = mfma4(q[k][2].x, b, h[8]); h[9] = mfma4(q[k][2].y, b, h[9]);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
                 }
             }
+            STAMP(2);  // layer 1
 #pragma unroll
             for (int n = 0; n < 10; ++n) h[n] = relu4(h[n]);
             // x of this tile is dead: fetch the next tile's rows into the same registers (one tile of work to land)
@@ -856,57 +886,70 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
                 asm volatile("" ::: "memory");
             }
 #endif
+            STAMP(3);  // relu 1 + load issue
             // feature_nn.2 + ReLU
             f32x4 h2[10];
             {
-                f32x4 q[H][3];
+                constexpr int NP = H / 2;
+                f32x4 q[NP][5];
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h2[n] = bq2[n];
+                auto rd = [&](int kp) {
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    q[kp][0] = wqA2[(k0 * 2 + 0) * 4]; q[kp][1] = wqA2[(k0 * 2 + 1) * 4];
+                    q[kp][2] = wqA2[(k1 * 2 + 0) * 4]; q[kp][3] = wqA2[(k1 * 2 + 1) * 4];
+                    q[kp][4] = wqB2[kp * 4];
+                };
+                rd(0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
 #pragma unroll
-                for (int k = 0; k < AH; ++k)
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) q[k][m] = wq2[(k * 3 + m) * 4];
-                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 3 * AH, 0);
-#pragma unroll
-                for (int k = 0; k < H; ++k) {
-                    if (k + AH < H) {
-#pragma unroll
-                        for (int m = 0; m < 3; ++m) q[k + AH][m] = wq2[((k + AH) * 3 + m) * 4];
-                    }
-                    const float b = h[k >> 2][k & 3];
-                    h2[0] = mfma4(q[k][0].x, b, h2[0]); h2[1] = mfma4(q[k][0].y, b, h2[1]); h2[2] = mfma4(q[k][0].z, b, h2[2]); h2[3] = mfma4(q[k][0].w, b, h2[3]);
-                    h2[4] = mfma4(q[k][1].x, b, h2[4]); h2[5] = mfma4(q[k][1].y, b, h2[5]); h2[6] = mfma4(q[k][1].z, b, h2[6]); h2[7] = mfma4(q[k][1].w, b, h2[7]);
-                    h2[8] = mfma4(q[k][2].x, b, h2[8]); h2[9] = mfma4(q[k][2].y, b, h2[9]);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+                for (int kp = 0; kp < NP; ++kp) {
+                    if (kp + 1 < NP) rd(kp + 1);
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    const float b0 = h[k0 >> 2][k0 & 3], b1v = h[k1 >> 2][k1 & 3];
+                    h2[0] = mfma4(q[kp][0].x, b0, h2[0]); h2[1] = mfma4(q[kp][0].y, b0, h2[1]); h2[2] = mfma4(q[kp][0].z, b0, h2[2]); h2[3] = mfma4(q[kp][0].w, b0, h2[3]);
+                    h2[4] = mfma4(q[kp][1].x, b0, h2[4]); h2[5] = mfma4(q[kp][1].y, b0, h2[5]); h2[6] = mfma4(q[kp][1].z, b0, h2[6]); h2[7] = mfma4(q[kp][1].w, b0, h2[7]);
+                    h2[8] = mfma4(q[kp][4].x, b0, h2[8]); h2[9] = mfma4(q[kp][4].y, b0, h2[9]);
+                    h2[0] = mfma4(q[kp][2].x, b1v, h2[0]); h2[1] = mfma4(q[kp][2].y, b1v, h2[1]); h2[2] = mfma4(q[kp][2].z, b1v, h2[2]); h2[3] = mfma4(q[kp][2].w, b1v, h2[3]);
+                    h2[4] = mfma4(q[kp][3].x, b1v, h2[4]); h2[5] = mfma4(q[kp][3].y, b1v, h2[5]); h2[6] = mfma4(q[kp][3].z, b1v, h2[6]); h2[7] = mfma4(q[kp][3].w, b1v, h2[7]);
+                    h2[8] = mfma4(q[kp][4].z, b1v, h2[8]); h2[9] = mfma4(q[kp][4].w, b1v, h2[9]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
                 }
             }
+            STAMP(4);  // layer 2
 #pragma unroll
             for (int n = 0; n < 10; ++n) h2[n] = relu4(h2[n]);
-            // feature_nn.4
+            STAMP(5);  // relu 2
+            // feature_nn.4: quads of inputs: reads A(k..k+3) + B(quad)
             f32x4 y[5];
             {
-                f32x4 q[H][2];
+                constexpr int NQ = H / 4;
+                f32x4 q[NQ][5];
 #pragma unroll
                 for (int n = 0; n < 5; ++n) y[n] = bq3[n];
+                auto rd = [&](int kq) {
 #pragma unroll
-                for (int k = 0; k < 2 * AH; ++k)
+                    for (int cc = 0; cc < 4; ++cc) q[kq][cc] = wqA3[(4 * kq + cc) * 4];
+                    q[kq][4] = wqB3[kq * 4];
+                };
+                rd(0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 5 + 5, 0);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) q[k][m] = wq3[(k * 2 + m) * 4];
-                __builtin_amdgcn_sched_group_barrier(0x100, 5 + 4 * AH, 0);
+                for (int kq = 0; kq < NQ; ++kq) {
+                    if (kq + 1 < NQ) rd(kq + 1);
 #pragma unroll
-                for (int k = 0; k < H; ++k) {
-                    if (k + 2 * AH < H) {
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) q[k + 2 * AH][m] = wq3[((k + 2 * AH) * 2 + m) * 4];
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int k = 4 * kq + cc;
+                        const float b = h2[k >> 2][k & 3];
+                        y[0] = mfma4(q[kq][cc].x, b, y[0]); y[1] = mfma4(q[kq][cc].y, b, y[1]); y[2] = mfma4(q[kq][cc].z, b, y[2]); y[3] = mfma4(q[kq][cc].w, b, y[3]);
+                        y[4] = mfma4(q[kq][4][cc], b, y[4]);
                     }
-                    const float b = h2[k >> 2][k & 3];
-                    y[0] = mfma4(q[k][0].x, b, y[0]); y[1] = mfma4(q[k][0].y, b, y[1]); y[2] = mfma4(q[k][0].z, b, y[2]); y[3] = mfma4(q[k][0].w, b, y[3]);
-                    y[4] = mfma4(q[k][1].x, b, y[4]);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
                 }
             }
+            STAMP(6);  // layer 3
             // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
             const float rcn = p.rcp_tab[it];
 #if BNN_EXP & 1  // timing experiment: pool replaced by integer ops (co-issue with the matrix pipe)
@@ -926,6 +969,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
                     mean[n][i] = mn;
                 }
 #endif
+            STAMP(7);  // pool
         }
 
         // merge the 4 lanes of a quad: equal-count Chan update, symmetric (all four lanes end with the same bits)
@@ -1002,6 +1046,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
         }
         __builtin_amdgcn_wave_barrier();
 
+        STAMP(8);  // merge + noise + finish
         // ---- regress_nn on the 16 systems of this wave-batch (16x16x4 path): column c <-> system wb0 + c
         const int64_t sysb = wb0 + c;
         const bool validb = sysb < b1;
@@ -1036,10 +1081,19 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
             if (bad_seed) mu = sd = __builtin_nanf("");
             const int64_t o = (r * p.B + sysb) * 2;
             *reinterpret_cast<f32x2*>(p.out + o) = (f32x2){mu, sd};
+#if !BNN_STAMPS
             if (p.pre_clamp) *reinterpret_cast<f32x2*>(p.pre_clamp + o) = (f32x2){r0, r1};
+#endif
         }
         __builtin_amdgcn_wave_barrier();  // scratch is reused by the next wave-batch
+        STAMP(9);  // regress_nn + store
     }
+#if BNN_STAMPS
+    if (p.pre_clamp && tid == 0) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.pre_clamp) + (int64_t)blockIdx.x * 12;
+        for (int i = 0; i < 12; ++i) dst[i] = st_acc[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

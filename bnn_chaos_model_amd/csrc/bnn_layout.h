@@ -99,19 +99,25 @@ BNN_HD inline int kmap_input(int nk1, int s, int g) {
 
 // ---- second operand layout: v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 neurons x 4 rows, K = 1) -----------------
 // lane l = row (B operand), register r of neuron group n = neuron 4n + r (A operand: lane l supplies W[4n + (l&3)][k]).
-// No padding inside a layer: 40 outputs = 10 groups, 20 outputs = 5 groups.  The A operands stream from an LDS image
-//   [k][m][i][j] -> W[neuron 4*(4m+j) + i][col(k)],  one ds_read_b128 per (k, m) feeds the four groups n = 4m..4m+3,
-// biases sit behind it as [n][r] and enter as the C operand of the first MFMA of a chain.
+// No padding inside a layer: 40 outputs = 10 groups, 20 outputs = 5 groups.  The A operands stream from LDS images,
+// one broadcast ds_read_b128 per four MFMAs with every float of every read used:
+//   image A of a layer: [k][m][i][j]  -> W[neuron 4*(4m+j) + i][col(k)]   (groups 0..7 of a 40-wide layer, 0..3 of the latent)
+//   image B of a 40-wide layer: [k/2][i][2*(k&1) + j] -> groups 8, 9 (j = 0, 1) for two consecutive k
+//   image B of the latent layer: [k/4][i][k&3]         -> group 4 for four consecutive k
+// biases sit behind them as [n][r] and enter as the C operand of the first MFMA of a chain.
 constexpr int NLIVE4 = 31;                 // live columns of the v50 mask, in ascending order: 0, 8..37
 BNN_HD inline int col4(int k) { return k == 0 ? 0 : 7 + k; }
-constexpr int W4_L1 = 0;                   // [31][3][4][4]
-constexpr int W4_L2 = W4_L1 + NLIVE4 * 48;  // [40][3][4][4]
-constexpr int W4_L3 = W4_L2 + H * 48;      // [40][2][4][4]
-constexpr int W4_B1 = W4_L3 + H * 32;      // [10][4]
-constexpr int W4_B2 = W4_B1 + H;           // [10][4]
-constexpr int W4_B3 = W4_B2 + H;           // [5][4]
-constexpr int W4_N = W4_B3 + L;            // 4788
-constexpr int W4_PAD = 4800;
+constexpr int W4_L1A = 0;                        // [31][2][4][4]
+constexpr int W4_L1B = W4_L1A + NLIVE4 * 32;     // [16][4][4]
+constexpr int W4_L2A = W4_L1B + 16 * 16;         // [40][2][4][4]
+constexpr int W4_L2B = W4_L2A + H * 32;          // [20][4][4]
+constexpr int W4_L3A = W4_L2B + 20 * 16;         // [40][4][4]
+constexpr int W4_L3B = W4_L3A + H * 16;          // [10][4][4]
+constexpr int W4_B1 = W4_L3B + 10 * 16;          // [10][4]
+constexpr int W4_B2 = W4_B1 + H;                 // [10][4]
+constexpr int W4_B3 = W4_B2 + H;                 // [5][4]
+constexpr int W4_N = W4_B3 + L;                  // 3748
+constexpr int W4_PAD = 3760;
 
 // fragment table indices (see bnn_tables.cpp)
 BNN_HD inline int nf1(int nk1) { return 3 * nk1 + 30 + 20 + 12 + 8; }

@@ -106,22 +106,30 @@ Tables build_tables(uint64_t zero_mask, bool all_columns) {
             return n < 0 ? ZERO_IDX : OFF_B6 + n;
         });
 
-    // 4x4x1 image (only the v50 mask has the 31-column load pattern built into the kernel)
+    // 4x4x1 images (only the v50 mask has the 31-column load pattern built into the kernel)
     if (v50) {
         T.f4.assign(W4_PAD, (int16_t)ZERO_IDX);
-        auto img = [&](int base, int K, int M, int off_w, int ld, int n_out, bool input_cols) {
+        auto w = [&](int off_w, int ld, int n_out, int neuron, int col) { return (int16_t)(neuron < n_out ? off_w + neuron * ld + col : ZERO_IDX); };
+        auto imgA = [&](int base, int K, int M, int off_w, int ld, int n_out, bool input_cols) {
             for (int k = 0; k < K; ++k)
                 for (int m = 0; m < M; ++m)
                     for (int i = 0; i < 4; ++i)
-                        for (int j = 0; j < 4; ++j) {
-                            int neuron = 4 * (4 * m + j) + i;
-                            int col = input_cols ? col4(k) : k;
-                            T.f4[base + ((k * M + m) * 4 + i) * 4 + j] = (int16_t)(neuron < n_out ? off_w + neuron * ld + col : ZERO_IDX);
-                        }
+                        for (int j = 0; j < 4; ++j)
+                            T.f4[base + ((k * M + m) * 4 + i) * 4 + j] = w(off_w, ld, n_out, 4 * (4 * m + j) + i, input_cols ? col4(k) : k);
         };
-        img(W4_L1, NLIVE4, 3, OFF_W1, F, H, true);
-        img(W4_L2, H, 3, OFF_W2, H, H, false);
-        img(W4_L3, H, 2, OFF_W3, H, L, false);
+        auto imgB40 = [&](int base, int K, int off_w, int ld, bool input_cols) {  // groups 8, 9, two k per read
+            for (int k = 0; k < K; ++k)
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 2; ++j)
+                        T.f4[base + ((k >> 1) * 4 + i) * 4 + 2 * (k & 1) + j] = w(off_w, ld, H, 4 * (8 + j) + i, input_cols ? col4(k) : k);
+        };
+        imgA(W4_L1A, NLIVE4, 2, OFF_W1, F, H, true);
+        imgB40(W4_L1B, NLIVE4, OFF_W1, F, true);
+        imgA(W4_L2A, H, 2, OFF_W2, H, H, false);
+        imgB40(W4_L2B, H, OFF_W2, H, false);
+        imgA(W4_L3A, H, 1, OFF_W3, H, L, false);
+        for (int k = 0; k < H; ++k)  // group 4 of the latent layer, four k per read
+            for (int i = 0; i < 4; ++i) T.f4[W4_L3B + ((k >> 2) * 4 + i) * 4 + (k & 3)] = w(OFF_W3, H, L, 16 + i, k);
         for (int n = 0; n < H; ++n) T.f4[W4_B1 + n] = (int16_t)(OFF_B1 + n);
         for (int n = 0; n < H; ++n) T.f4[W4_B2 + n] = (int16_t)(OFF_B2 + n);
         for (int n = 0; n < L; ++n) T.f4[W4_B3 + n] = (int16_t)(OFF_B3 + n);
