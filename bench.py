@@ -117,11 +117,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run with N ranks")
+    # BNN_BENCH_REHEARSE=1: every rank on cuda:0 with gloo -- exercises the N>1 code path on a one-GPU box
+    rehearse = os.environ.get("BNN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     wl = dict(WORKLOADS[args.workload])
     if args.systems:

@@ -35,6 +35,8 @@ def all_gather_moments(local, B, group=None):
     rank = dist.get_rank(group)
     if local.shape[0] != bounds[rank][1] - bounds[rank][0]:
         raise ValueError("local shard does not match shard_bounds(B, world)[rank]")
+    if local.is_cuda and dist.get_backend(group) == "gloo":  # CPU rehearsal of the N>1 path: stage through host memory
+        return all_gather_moments(local.cpu(), B, group).to(local.device)
     if all(hi - lo == nmax for lo, hi in bounds):
         out = torch.empty((world * nmax, M), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
