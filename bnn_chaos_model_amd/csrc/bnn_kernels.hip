@@ -495,21 +495,21 @@ __global__ __launch_bounds__(256, (NOISY || NK1 != 8) ? 2 : BNN_WAVES_PER_SIMD) 
                     for (int mt = 0; mt < 2; ++mt) y.m[mt] = mfma(wf[IW3 + ks * 2 + mt], h2.m[ks >> 2][ks & 3], y.m[mt]);
                 return y;
             };
-            // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps, in tile order;
+            // torch.mean / torch.std over time (:418-419): Welford (fused updates) over this lane's timesteps, in tile order;
             // 1/(it+1) comes correctly rounded from a table
             auto pool = [&](const H2& y, const int it) {
                 const float rcn = p.rcp_tab[it];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float dl = y.m[0][i] - mean0[i];
-                    float mn = mean0[i] + dl * rcn;
-                    m20[i] = m20[i] + dl * (y.m[0][i] - mn);
+                    float mn = fmaf(dl, rcn, mean0[i]);
+                    m20[i] = fmaf(dl, y.m[0][i] - mn, m20[i]);
                     mean0[i] = mn;
                 }
                 {
                     float dl = y.m[1][0] - mean1;
-                    float mn = mean1 + dl * rcn;
-                    m21 = m21 + dl * (y.m[1][0] - mn);
+                    float mn = fmaf(dl, rcn, mean1);
+                    m21 = fmaf(dl, y.m[1][0] - mn, m21);
                     mean1 = mn;
                 }
             };
@@ -964,8 +964,8 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float dl = y[n][i] - mean[n][i];
-                    float mn = mean[n][i] + dl * rcn;
-                    m2[n][i] = m2[n][i] + dl * (y[n][i] - mn);
+                    float mn = fmaf(dl, rcn, mean[n][i]);
+                    m2[n][i] = fmaf(dl, y[n][i] - mn, m2[n][i]);
                     mean[n][i] = mn;
                 }
 #endif

@@ -193,14 +193,14 @@ int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, cons
                 linear_row(W2, b2, H, H, h1, h2, 1, ord[1], ordn[1]);
                 linear_row(W3, b3, L, H, h2, y, 0, ord[2], ordn[2]);
                 if (latents) memcpy(latents + ((size_t)b * T + t) * L, y, sizeof(REAL) * L);
-                /* mean / unbiased variance over t (torch.mean, torch.std: :418-419): Welford */
+                /* mean / unbiased variance over t (torch.mean, torch.std: :418-419): Welford with fused updates */
                 int p = (P == 4) ? (t & 3) : 0;
                 int cnt = (P == 4) ? (t >> 2) + 1 : t + 1;
                 REAL rc_n = (REAL)1 / (REAL)cnt;
                 for (int n = 0; n < L; ++n) {
                     REAL delta = y[n] - mean[p * L + n];
-                    REAL mnew = mean[p * L + n] + delta * rc_n;
-                    m2[p * L + n] = m2[p * L + n] + delta * (y[n] - mnew);
+                    REAL mnew = FMA(delta, rc_n, mean[p * L + n]);
+                    m2[p * L + n] = FMA(delta, y[n] - mnew, m2[p * L + n]);
                     mean[p * L + n] = mnew;
                 }
             }
