@@ -1112,6 +1112,40 @@ __global__ void bnn_moments_kernel(const float* __restrict__ samples, int64_t R,
     mom[b * 4] = s0; mom[b * 4 + 1] = s1; mom[b * 4 + 2] = s2; mom[b * 4 + 3] = s3;
 }
 
+// data_setup_kernel + StandardScaler.transform + .float(): one thread per (row, raw column j of the 32)
+__global__ void bnn_feature_pack_kernel(const double* __restrict__ ts, const double* __restrict__ mass, const double* __restrict__ Xin,
+                                        int64_t N, int T, const double* __restrict__ mean, const double* __restrict__ scale,
+                                        double* __restrict__ X64, float* __restrict__ x32) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = N * T;
+    if (Xin) {  // already packed: standardise only, one thread per element
+        if (i >= rows * F) return;
+        const int col = (int)(i % F);
+        const double v = Xin[i];
+        if (X64) X64[i] = v;
+        if (x32) x32[i] = (float)((v - mean[col]) / scale[col]);
+        return;
+    }
+    if (i >= rows * 32) return;
+    const int j = (int)(i % 32);
+    const int64_t row = i / 32, n = row / T;
+    auto raw = [&](int c) -> double { return c < 26 ? ts[row * 26 + c] : mass[n * 3 + (c - 26)]; };
+    double v;
+    if (j < 29) v = raw(j);
+    else v = (double)!isfinite(raw(j == 29 ? 3 : j == 30 ? 6 : 7));   // isnotfinite flags (regression.py:191-193)
+    if (!isfinite(v)) v = 0.0;                                         // nan_to_num(posinf=0, neginf=0) (:195)
+    // output column of raw column j: angles before it each add one column
+    const bool angle = (j >= 11 && j <= 13) || (j >= 17 && j <= 19) || (j >= 23 && j <= 25);
+    const int nbefore = (j > 11 ? (j < 14 ? j - 11 : 3) : 0) + (j > 17 ? (j < 20 ? j - 17 : 3) : 0) + (j > 23 ? (j < 26 ? j - 23 : 3) : 0);
+    const int o = j + nbefore;
+    auto put = [&](int col, double val) {
+        if (X64) X64[row * F + col] = val;
+        if (x32) x32[row * F + col] = (float)((val - mean[col]) / scale[col]);
+    };
+    if (angle) { put(o, cos(v)); put(o + 1, sin(v)); }
+    else put(o, v);
+}
+
 __global__ void bnn_philox_fill_kernel(int kind, uint64_t seed, int64_t id0, int64_t n_rows, int64_t B, int64_t sys0, int width,
                                        float* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1423,6 +1457,21 @@ int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x
     p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
     p.out = out; p.pre_clamp = pre_clamp; p.summary = summary;
     return launch_forward(plan, grid, p, true, false, stream);
+}
+
+int bnn_feature_pack_f64(const double* tseries, const double* mass, const double* X64_in, int64_t N, int32_t T, const double* mean,
+                         const double* scale, double* X64_out, float* x32_out, void* stream) {
+    if (N < 0 || T < 1) return fail(BNN_ERR_INVALID, "bad N/T");
+    if (N == 0) return 0;
+    if (!tseries && !X64_in) return fail(BNN_ERR_INVALID, "need tseries (+mass) or X64_in");
+    if (tseries && !mass) return fail(BNN_ERR_INVALID, "tseries needs mass");
+    if (!X64_out && !x32_out) return fail(BNN_ERR_INVALID, "no output requested");
+    if (x32_out && (!mean || !scale)) return fail(BNN_ERR_INVALID, "x32_out needs mean and scale");
+    const int64_t total = N * T * (tseries ? 32 : F);
+    hipLaunchKernelGGL(bnn_feature_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tseries, mass,
+                       tseries ? nullptr : X64_in, N, (int)T, mean, scale, X64_out, x32_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments, int32_t accumulate, void* stream) {

@@ -153,6 +153,26 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
     return (out, pre, summ) if debug else out
 
 
+def feature_pack(tseries=None, mass=None, X=None, mean=None, scale=None, want_x64=False):
+    """data_setup_kernel (figures/spock/regression.py:183-213) + ssX.transform + .float() on the GPU.
+
+    tseries [N,T,26] + mass [N,3] float64 (or X [N,T,41] float64 already packed) -> x [N,T,41] float32 standardised with
+    mean/scale [41] float64; want_x64 also returns the unstandardised float64 X (data_setup_kernel's return value)."""
+    f64 = lambda t: None if t is None else torch.as_tensor(t, dtype=torch.float64).cuda().contiguous()
+    tseries, mass, X, mean, scale = f64(tseries), f64(mass), f64(X), f64(mean), f64(scale)
+    src = tseries if tseries is not None else X
+    if src is None or src.dim() != 3 or src.shape[2] != (26 if tseries is not None else 41):
+        raise NotImplementedError("Need to change indexes above for angles, replace ssX.")  # regression.py:210-211
+    Nn, T = src.shape[0], src.shape[1]
+    x32 = torch.empty((Nn, T, 41), dtype=torch.float32, device=src.device) if mean is not None else None
+    x64 = torch.empty((Nn, T, 41), dtype=torch.float64, device=src.device) if (want_x64 or x32 is None) else None
+    N.check(N.lib().bnn_feature_pack_f64(N.ptr(tseries), N.ptr(mass), N.ptr(X), Nn, T, N.ptr(mean), N.ptr(scale), N.ptr(x64),
+                                         N.ptr(x32), N.stream_ptr()))
+    if x32 is None:
+        return x64
+    return (x32, x64) if want_x64 else x32
+
+
 def moments(samples, mom=None):
     """samples [R,B,2] -> float64 [B,4] = sum mu, sum mu^2, sum std, sum std^2 (accumulates into `mom` if given)."""
     samples = _f32(samples, "samples")

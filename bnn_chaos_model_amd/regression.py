@@ -16,6 +16,23 @@ from . import spock_reg_model
 from .spock_reg_model import _gpu
 
 
+def data_setup_kernel(mass_array, cur_tseries):
+    """figures/spock/regression.py:183-213 on the GPU: mass_array [3], cur_tseries [1,T,26] -> X [1,T,41] float64 ndarray.
+    (`pack_features` below is the batched, fused form that feeds the network directly.)"""
+    ts = np.asarray(cur_tseries, dtype=np.float64)
+    if ts.ndim != 3 or ts.shape[-1] != 26:
+        raise NotImplementedError("Need to change indexes above for angles, replace ssX.")
+    mass = np.tile(np.asarray(mass_array, dtype=np.float64)[None], (ts.shape[0], 1))
+    return ops.feature_pack(ts, mass).cpu().numpy()
+
+
+def pack_features(tseries, mass, ssX=None):
+    """tseries [N,T,26], mass [N,3] float64 -> standardised float32 x [N,T,41] on the GPU:
+    data_setup_kernel + ssX.transform + .float() (regression.py:143-145) in one kernel."""
+    ssX = ssX or spock_reg_model.v50_scaler()
+    return ops.feature_pack(tseries, mass, mean=ssX.mean_, scale=ssX.scale_)
+
+
 class FeatureRegressor(object):
     def __init__(self, cuda=False, filebase="long_zero_megno_with_angles_power_v14_*_output.pkl", sort=False):
         """filebase is resolved like the reference (relative to this file's directory + '/../'); absolute globs work too.

@@ -126,6 +126,17 @@ int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x
                       int64_t draw_id0, int64_t system_id0, float* W_workspace, float* out, float* pre_clamp,
                       float* summary, void* stream);
 
+/* Pre-path feature packing + standardisation:
+ * data_setup_kernel (figures/spock/regression.py:183-213): tseries [N,T,26] + mass [N,3] (float64) -> 32 raw columns
+ * (26 series + 3 masses + isnotfinite flags of columns 3, 6, 7), nan_to_num(nan, +-inf -> 0), the nine angle columns
+ * {11,12,13,17,18,19,23,24,25} expanded to (cos, sin) -> X [N,T,41] float64;
+ * then StandardScaler.transform in float64 and .float() (figures/multiswag_5_planet.py:280-287, regression.py:144-145).
+ *   X64_out [N,T,41] float64 (may be NULL) = data_setup_kernel's return value;
+ *   x32_out [N,T,41] float32 (may be NULL; needs mean/scale [41] float64) = the tensor the network consumes.
+ * tseries == NULL: X64_in [N,T,41] is taken as already packed and only standardised (mass ignored). */
+int bnn_feature_pack_f64(const double* tseries, const double* mass, const double* X64_in, int64_t N, int32_t T,
+                         const double* mean, const double* scale, double* X64_out, float* x32_out, void* stream);
+
 /* Predictive moments over draws: samples [R,B,2] -> moments [B,4] (float64):
  * sum mu, sum mu^2, sum std, sum std^2 over r, in r order (deterministic).  accumulate != 0 adds to
  * the existing contents (for processing draws in slabs). */

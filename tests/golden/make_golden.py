@@ -203,6 +203,26 @@ def main():
                                            for k, v in dict(mi.hparams).items()})),
          swa_params_json=np.array(json.dumps(dict(mi.swa_params))))
 
+    # ---- case F: feature packing.  figures/spock/regression.py is not importable here (rebound, numba, ...), but
+    # data_setup_kernel (:183-213) is pure numpy: its source is cut out of the file with ast and executed as is
+    # (the @jit decorator and numpy<1.24's np.float alias are supplied by the namespace).
+    import ast
+    src = open(f"{REF}/figures/spock/regression.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "data_setup_kernel"][0]
+    npx = types.SimpleNamespace(**{k: getattr(np, k) for k in dir(np) if not k.startswith("__")})
+    npx.float = float
+    ns = {"np": npx, "jit": lambda f: f}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "regression.py:data_setup_kernel", "exec"), ns)
+    rng = np.random.default_rng(77)
+    ts = rng.standard_normal((6, 1, 100, 26)) * 2.0
+    ts[0, 0, 5, 3] = np.nan; ts[1, 0, 7, 6] = np.inf; ts[2, 0, 9, 7] = -np.inf; ts[3, 0, 11, 12] = np.nan; ts[4, 0, 0, 0] = np.inf
+    masses = np.abs(rng.standard_normal((6, 3))) * 1e-5
+    Xs = np.stack([ns["data_setup_kernel"](masses[i], ts[i])[0] for i in range(6)])           # [6,100,41]
+    ss = models[0].ssX
+    Xp = ss.transform(Xs.reshape(-1, 41)).reshape(Xs.shape)
+    save("case_features.npz", tseries=ts[:, 0], mass=masses, X64=Xs, x32=torch.tensor(Xp).float().numpy(),
+         mean=ss.mean_, scale=ss.scale_)
+
     m0 = models[0]
     # constant-4 "unstable" fill (figures/multiswag_5_planet.py:214-215) after ssX, float64 transform then .float()
     raw4 = np.ones((4, 100, 41)) * 4

@@ -215,3 +215,25 @@ def test_sample_with_philox_rng(swag_states, tmp_path):
     b = m.sample(x, samples=200)
     assert a.shape == b.shape == (16,)
     assert np.abs(a - b).max() < 2.0  # means of 200 draws with std up to 6: SE of the difference <= 0.6
+
+
+def test_feature_pack_matches_reference(ops):
+    """data_setup_kernel + ssX.transform + .float() on the GPU vs the captured reference output."""
+    from conftest import load_golden
+    from oracle import features
+    z = load_golden("case_features.npz")
+    x32, x64 = ops.feature_pack(z["tseries"], z["mass"], mean=z["mean"], scale=z["scale"], want_x64=True)
+    x64, x32 = x64.cpu().numpy(), x32.cpu().numpy()
+    # float64: exact except cos/sin (device libm vs glibc, <= 2 ulp)
+    assert np.abs(x64 - z["X64"]).max() <= 4.5e-16
+    ang = [11, 12, 13, 14, 15, 16, 20, 21, 22, 23, 24, 25, 29, 30, 31, 32, 33, 34]
+    rest = [c for c in range(41) if c not in ang]
+    assert np.array_equal(x64[..., rest], z["X64"][..., rest])
+    # float32 network input: identical up to one rounding of those ulps
+    assert np.abs(x32.astype(np.float64) - z["x32"]).max() <= 3e-7 * max(1.0, np.abs(z["x32"]).max())
+    assert np.array_equal(x32[..., rest], z["x32"][..., rest])
+    # standardise-only entry (already packed X), and the numpy oracle
+    y32 = ops.feature_pack(X=z["X64"], mean=z["mean"], scale=z["scale"]).cpu().numpy()
+    assert np.array_equal(y32, z["x32"]) and np.array_equal(y32, features.standardize(z["X64"], z["mean"], z["scale"]))
+    with pytest.raises(NotImplementedError):
+        ops.feature_pack(np.zeros((1, 100, 25)), np.zeros((1, 3)), mean=z["mean"], scale=z["scale"])

@@ -182,3 +182,13 @@ def test_known_answer_properties(swag_states, inputs):
     perm = np.random.default_rng(1).permutation(100)
     nbad, mx = close_report(orc.forward(x[:, perm], z["w"], tp[2][1], tp[3][1]), base)
     assert nbad == 0, (nbad, mx)
+
+
+def test_feature_packing_matches_reference_function():
+    """oracle/features.py vs data_setup_kernel executed from the reference's own source (+ ssX.transform + .float())."""
+    from oracle import features
+    z = load_golden("case_features.npz")
+    X = np.stack([features.data_setup(z["mass"][i], z["tseries"][i][None])[0] for i in range(z["mass"].shape[0])])
+    assert X.shape == z["X64"].shape and np.array_equal(X, z["X64"])
+    assert np.array_equal(features.standardize(X, z["mean"], z["scale"]), z["x32"])
+    assert np.isfinite(z["X64"]).all() and (z["X64"][0, 5, 38] == 1.0) and (z["X64"][1, 7, 39] == 1.0) and (z["X64"][2, 9, 40] == 1.0)

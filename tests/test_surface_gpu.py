@@ -172,3 +172,13 @@ def test_cuda_inputs_stay_on_gpu(models, inputs):
     finally:
         m.rng = "torch"
         m.cpu()
+
+
+def test_data_setup_kernel_drop_in():
+    from bnn_chaos_model_amd import regression
+    z = load_golden("case_features.npz")
+    X = regression.data_setup_kernel(z["mass"][1], z["tseries"][1][None])
+    assert X.shape == (1, 100, 41) and X.dtype == np.float64
+    assert np.abs(X[0] - z["X64"][1]).max() <= 4.5e-16
+    x = regression.pack_features(z["tseries"], z["mass"])
+    assert x.is_cuda and x.dtype == torch.float32 and np.abs(x.cpu().numpy().astype(np.float64) - z["x32"]).max() <= 3e-6
