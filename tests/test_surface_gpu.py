@@ -182,3 +182,27 @@ def test_data_setup_kernel_drop_in():
     assert np.abs(X[0] - z["X64"][1]).max() <= 4.5e-16
     x = regression.pack_features(z["tseries"], z["mass"])
     assert x.is_cuda and x.dtype == torch.float32 and np.abs(x.cpu().numpy().astype(np.float64) - z["x32"]).max() <= 3e-6
+
+
+def test_torch_custom_ops(swag_states, inputs):
+    """torch.ops.bnn_chaos.* (torch.library custom ops) give the same bits as the python wrappers; fake impls give shapes."""
+    import bnn_chaos_model_amd.torch_ops  # noqa: F401  (registers the ops)
+    from bnn_chaos_model_amd import ops
+    st = swag_states[0]
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    wa, w2, pd = d(st["w_avg"][None]), d(st["w2_avg"][None]), d(st["pre_D"][None])
+    x = d(inputs["slow"])
+    idx = torch.zeros(3, dtype=torch.int32, device="cuda")
+    a = torch.ops.bnn_chaos.multiswag(x, wa, w2, pd, idx, None, None, None, 1, 0.5, 42, 0, 0)
+    b = ops.multiswag(x, wa, w2, pd, idx, philox_seed=42)
+    assert torch.equal(a, b)
+    W = torch.ops.bnn_chaos.swag_draw(wa, w2, pd, idx, None, None, 0.5, 42, 0)
+    c = torch.ops.bnn_chaos.forward(x, W, None, None, None, 1, False, 42, 0, 0)
+    assert torch.equal(a, c)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        fx = torch.empty((7, 100, 41), device="cuda")
+        fo = torch.ops.bnn_chaos.multiswag(fx, torch.empty((1, 7583), device="cuda"), torch.empty((1, 7583), device="cuda"),
+                                           torch.empty((1, 7583, 30), device="cuda"), torch.empty(6, dtype=torch.int32, device="cuda"),
+                                           None, None, None, 2, 0.5, 0, 0, 0)
+        assert fo.shape == (3, 7, 2)
