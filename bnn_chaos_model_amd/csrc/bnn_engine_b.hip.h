@@ -1,0 +1,391 @@
+// bnn_engine_b.hip.h -- feature_nn engine B: v_mfma_f32_4x4x1_16b_f32, no padding, weights streamed from packed
+// LDS images.  Included by bnn_kernels.hip after bnn_engine_a.hip.h (shares its tail helpers).
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// Second feature_nn engine: v_mfma_f32_4x4x1_16b_f32 (bnn_layout.h, "second operand layout").
+// lane = row, so there is no padding anywhere: 310 + 400 + 200 = 910 MFMAs of 8 cycles per 64 rows (113.75 pipe
+// cycles per row against 148 for the 16x16x4 tiling).  Weights stream from an LDS image with broadcast
+// ds_read_b128 (one read feeds four MFMAs; LDS reads do not occupy the fp32 pipe), activations never leave
+// registers: a layer's accumulator registers are the next layer's B operands as they stand.
+// A wave owns 16 systems at a time: lane l = system l>>2, timestep phase l&3; tile `it` = timesteps 4it..4it+3.
+// Accumulation order per output = bias, then inputs in ascending order: the oracle's natural order.
+// Built for the v50 column mask (31 live columns), quiet forward.  Everything after the time pool (sampled
+// moments, regress_nn on the 16x16x4 path, soft_clamp) is shared with the first kernel.
+// ------------------------------------------------------------------------------------------------
+DEVINL f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+template <int CTRL>
+DEVINL float quad_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+DEVINL void load_row31(const float* __restrict__ rp, float (&xv)[NLIVE4]) {
+    xv[0] = rp[0];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4u*>(rp + 8 + 4 * q);
+        xv[1 + 4 * q] = v.x; xv[2 + 4 * q] = v.y; xv[3 + 4 * q] = v.z; xv[4 + 4 * q] = v.w;
+    }
+    f32x2 t = *reinterpret_cast<const f32x2u*>(rp + 36);
+    xv[29] = t.x; xv[30] = t.y;
+}
+
+constexpr int SCR4 = 2 * 16 * S2;  // floats of LDS scratch per wave: Philox normals + summaries of 16 systems
+
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot, later ...
+    float* f2frag = lds;               // ... [NF2][64] regress_nn operands in fragment order
+    float* zsh = lds + FLAT_LDS;       // [MAXK]
+    float* wl = zsh + MAXK;            // [W4_PAD] feature_nn image for the 4x4x1 operands
+    float* scr = wl + W4_PAD;          // [4][SCR4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;   // regress_nn (16x16x4) coordinates
+    const int sl = lane >> 2, ph = lane & 3;  // feature_nn (4x4x1) coordinates: system in the wave-batch, timestep phase
+
+    const int64_t id = blockIdx.x;
+    const int e = (int)(id % p.J);
+    const int64_t sub = id / p.J;
+    const int ch = e % p.nch;
+    const int64_t r = e / p.nch;
+    const int64_t seg0 = (int64_t)ch * p.csz;
+    const int64_t seg1 = (seg0 + p.csz < p.B) ? seg0 + p.csz : p.B;
+    const int64_t b0 = seg0 + sub * p.spc;
+    const int64_t b1 = (b0 + p.spc < seg1) ? b0 + p.spc : seg1;
+    if (b0 >= b1) return;
+
+#if BNN_STAMPS
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+    bool bad_seed = false;
+    if constexpr (FUSED) {
+        int s = p.seed_idx[e];
+        bad_seed = (s < 0 || s >= p.S);
+        if (bad_seed) s = 0;
+        const int K = p.K;
+        if (tid < K) zsh[tid] = p.z2 ? p.z2[(int64_t)e * K + tid] : philox_z(TAG_Z2, p.draw_id0 + e, tid, p.seed);
+        const float* wa = p.w_avg + (int64_t)s * D;
+        const float* w2 = p.w2_avg + (int64_t)s * D;
+        const float* pd = p.pre_D + (int64_t)s * D * K;
+        __syncthreads();
+        for (int i = tid; i < D; i += 256) {
+            float z1v = p.z1 ? p.z1[(int64_t)e * D + i] : philox_z(TAG_Z1, p.draw_id0 + e, i, p.seed);
+            flat[i] = draw_row_direct(wa, w2, pd, i, K, zsh, z1v, p.c1, p.c2, p.scale);
+        }
+    } else {
+        const float* We = p.W + (int64_t)e * D;
+        for (int i = tid; i < D; i += 256) flat[i] = We[i];
+    }
+    if (tid == 0) flat[ZERO_IDX] = 0.0f;
+    __syncthreads();
+    for (int i = tid; i < W4_PAD; i += 256) wl[i] = flat[p.tab_f4[i]];
+    {
+        constexpr int PER = (NF2 + 3) / 4;
+        float tmp[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int f = wave + 4 * i;
+            tmp[i] = f < NF2 ? flat[p.tab_f2[f * 64 + lane]] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int f = wave + 4 * i;
+            if (f < NF2) f2frag[f * 64 + lane] = tmp[i];
+        }
+        __syncthreads();
+    }
+
+    STAMP(0);  // prologue
+    const int T = p.T, ntiles = p.ntiles;
+    const float nm1 = (float)(T - 1), nT = (float)T;
+    const float half_n0 = (float)ntiles * 0.5f;
+    const int64_t rowstride = (int64_t)T * F;
+    const f32x4* wqA1 = reinterpret_cast<const f32x4*>(wl + W4_L1A) + ph;
+    const f32x4* wqB1 = reinterpret_cast<const f32x4*>(wl + W4_L1B) + ph;
+    const f32x4* wqA2 = reinterpret_cast<const f32x4*>(wl + W4_L2A) + ph;
+    const f32x4* wqB2 = reinterpret_cast<const f32x4*>(wl + W4_L2B) + ph;
+    const f32x4* wqA3 = reinterpret_cast<const f32x4*>(wl + W4_L3A) + ph;
+    const f32x4* wqB3 = reinterpret_cast<const f32x4*>(wl + W4_L3B) + ph;
+    const f32x4* bq1 = reinterpret_cast<const f32x4*>(wl + W4_B1);
+    const f32x4* bq2 = reinterpret_cast<const f32x4*>(wl + W4_B2);
+    const f32x4* bq3 = reinterpret_cast<const f32x4*>(wl + W4_B3);
+    float* epsscr = scr + wave * SCR4;
+    float* sumscr = epsscr + 16 * S2;
+
+    for (int64_t wb0 = b0 + (int64_t)wave * 16; wb0 < b1; wb0 += 64) {
+        const int64_t sys = wb0 + sl;
+        const bool valid = sys < b1;
+        const int64_t sysc = valid ? sys : b1 - 1;
+        const float* rowp = p.x + sysc * rowstride + (int64_t)ph * F;
+
+        f32x4 mean[5], m2[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) { mean[n] = (f32x4){0, 0, 0, 0}; m2[n] = (f32x4){0, 0, 0, 0}; }
+
+        float xv[NLIVE4];
+        load_row31(rowp, xv);
+        asm volatile("" ::: "memory");
+        STAMP(1);  // batch setup + first row load issue
+        for (int it = 0; it < ntiles; ++it) {
+            // A operands are read one group of 20 MFMAs ahead of their use and the order is pinned with
+            // sched_group_barrier (5 LDS reads, then 20 MFMAs): left alone, the scheduler issues each read one or two
+            // MFMAs before its use and the LDS latency lands on the matrix pipe.
+            // feature_nn.0 + ReLU: pairs of input columns (k0, k1): reads A(k0,m0) A(k0,m1) A(k1,m0) A(k1,m1) B(pair)
+            f32x4 h[10];
+            {
+                constexpr int NP = (NLIVE4 + 1) / 2;  // 16 pairs, the last one holds only k = 30
+                f32x4 q[NP][5];
+#pragma unroll
+                for (int n = 0; n < 10; ++n) h[n] = bq1[n];
+                auto rd = [&](int kp) {
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    q[kp][0] = wqA1[(k0 * 2 + 0) * 4]; q[kp][1] = wqA1[(k0 * 2 + 1) * 4];
+                    if (k1 < NLIVE4) { q[kp][2] = wqA1[(k1 * 2 + 0) * 4]; q[kp][3] = wqA1[(k1 * 2 + 1) * 4]; }
+                    q[kp][4] = wqB1[kp * 4];
+                };
+                rd(0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
+#pragma unroll
+                for (int kp = 0; kp < NP; ++kp) {
+                    if (kp + 1 < NP) rd(kp + 1);
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    const float b0 = xv[k0];
+                    h[0] = mfma4(q[kp][0].x, b0, h[0]); h[1] = mfma4(q[kp][0].y, b0, h[1]); h[2] = mfma4(q[kp][0].z, b0, h[2]); h[3] = mfma4(q[kp][0].w, b0, h[3]);
+                    h[4] = mfma4(q[kp][1].x, b0, h[4]); h[5] = mfma4(q[kp][1].y, b0, h[5]); h[6] = mfma4(q[kp][1].z, b0, h[6]); h[7] = mfma4(q[kp][1].w, b0, h[7]);
+                    h[8] = mfma4(q[kp][4].x, b0, h[8]); h[9] = mfma4(q[kp][4].y, b0, h[9]);
+                    if (k1 < NLIVE4) {
+                        const float b1v = xv[k1];
+                        h[0] = mfma4(q[kp][2].x, b1v, h[0]); h[1] = mfma4(q[kp][2].y, b1v, h[1]); h[2] = mfma4(q[kp][2].z, b1v, h[2]); h[3] = mfma4(q[kp][2].w, b1v, h[3]);
+                        h[4] = mfma4(q[kp][3].x, b1v, h[4]); h[5] = mfma4(q[kp][3].y, b1v, h[5]); h[6] = mfma4(q[kp][3].z, b1v, h[6]); h[7] = mfma4(q[kp][3].w, b1v, h[7]);
+                        h[8] = mfma4(q[kp][4].z, b1v, h[8]); h[9] = mfma4(q[kp][4].w, b1v, h[9]);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+                }
+            }
+            STAMP(2);  // layer 1
+#pragma unroll
+            for (int n = 0; n < 10; ++n) h[n] = relu4(h[n]);
+            // x of this tile is dead: fetch the next tile's rows into the same registers (one tile of work to land)
+#if !(BNN_EXP & 2)  // timing experiment 2: no further x loads
+            {
+                const int itn = (it + 1 < ntiles) ? it + 1 : it;
+                load_row31(rowp + (int64_t)itn * 4 * F, xv);
+                asm volatile("" ::: "memory");
+            }
+#endif
+            STAMP(3);  // relu 1 + load issue
+            // feature_nn.2 + ReLU
+            f32x4 h2[10];
+            {
+                constexpr int NP = H / 2;
+                f32x4 q[NP][5];
+#pragma unroll
+                for (int n = 0; n < 10; ++n) h2[n] = bq2[n];
+                auto rd = [&](int kp) {
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    q[kp][0] = wqA2[(k0 * 2 + 0) * 4]; q[kp][1] = wqA2[(k0 * 2 + 1) * 4];
+                    q[kp][2] = wqA2[(k1 * 2 + 0) * 4]; q[kp][3] = wqA2[(k1 * 2 + 1) * 4];
+                    q[kp][4] = wqB2[kp * 4];
+                };
+                rd(0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
+#pragma unroll
+                for (int kp = 0; kp < NP; ++kp) {
+                    if (kp + 1 < NP) rd(kp + 1);
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    const float b0 = h[k0 >> 2][k0 & 3], b1v = h[k1 >> 2][k1 & 3];
+                    h2[0] = mfma4(q[kp][0].x, b0, h2[0]); h2[1] = mfma4(q[kp][0].y, b0, h2[1]); h2[2] = mfma4(q[kp][0].z, b0, h2[2]); h2[3] = mfma4(q[kp][0].w, b0, h2[3]);
+                    h2[4] = mfma4(q[kp][1].x, b0, h2[4]); h2[5] = mfma4(q[kp][1].y, b0, h2[5]); h2[6] = mfma4(q[kp][1].z, b0, h2[6]); h2[7] = mfma4(q[kp][1].w, b0, h2[7]);
+                    h2[8] = mfma4(q[kp][4].x, b0, h2[8]); h2[9] = mfma4(q[kp][4].y, b0, h2[9]);
+                    h2[0] = mfma4(q[kp][2].x, b1v, h2[0]); h2[1] = mfma4(q[kp][2].y, b1v, h2[1]); h2[2] = mfma4(q[kp][2].z, b1v, h2[2]); h2[3] = mfma4(q[kp][2].w, b1v, h2[3]);
+                    h2[4] = mfma4(q[kp][3].x, b1v, h2[4]); h2[5] = mfma4(q[kp][3].y, b1v, h2[5]); h2[6] = mfma4(q[kp][3].z, b1v, h2[6]); h2[7] = mfma4(q[kp][3].w, b1v, h2[7]);
+                    h2[8] = mfma4(q[kp][4].z, b1v, h2[8]); h2[9] = mfma4(q[kp][4].w, b1v, h2[9]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+                }
+            }
+            STAMP(4);  // layer 2
+#pragma unroll
+            for (int n = 0; n < 10; ++n) h2[n] = relu4(h2[n]);
+            STAMP(5);  // relu 2
+            // feature_nn.4: quads of inputs: reads A(k..k+3) + B(quad)
+            f32x4 y[5];
+            {
+                constexpr int NQ = H / 4;
+                f32x4 q[NQ][5];
+#pragma unroll
+                for (int n = 0; n < 5; ++n) y[n] = bq3[n];
+                auto rd = [&](int kq) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) q[kq][cc] = wqA3[(4 * kq + cc) * 4];
+                    q[kq][4] = wqB3[kq * 4];
+                };
+                rd(0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 5 + 5, 0);
+#pragma unroll
+                for (int kq = 0; kq < NQ; ++kq) {
+                    if (kq + 1 < NQ) rd(kq + 1);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int k = 4 * kq + cc;
+                        const float b = h2[k >> 2][k & 3];
+                        y[0] = mfma4(q[kq][cc].x, b, y[0]); y[1] = mfma4(q[kq][cc].y, b, y[1]); y[2] = mfma4(q[kq][cc].z, b, y[2]); y[3] = mfma4(q[kq][cc].w, b, y[3]);
+                        y[4] = mfma4(q[kq][4][cc], b, y[4]);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+                }
+            }
+            STAMP(6);  // layer 3
+            // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
+            const float rcn = p.rcp_tab[it];
+#if BNN_EXP & 1  // timing experiment: pool replaced by integer ops (co-issue with the matrix pipe)
+#pragma unroll
+            for (int n = 0; n < 5; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    mean[n][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, mean[n][i]) ^ __builtin_bit_cast(int, y[n][i]));
+#else
+#pragma unroll
+            for (int n = 0; n < 5; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float dl = y[n][i] - mean[n][i];
+                    float mn = fmaf(dl, rcn, mean[n][i]);
+                    m2[n][i] = fmaf(dl, y[n][i] - mn, m2[n][i]);
+                    mean[n][i] = mn;
+                }
+#endif
+            STAMP(7);  // pool
+        }
+
+        // merge the 4 lanes of a quad: equal-count Chan update, symmetric (all four lanes end with the same bits)
+        {
+            float half_n = half_n0;
+#pragma unroll
+            for (int n = 0; n < 5; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float om = quad_perm<0xB1>(mean[n][i]), o2 = quad_perm<0xB1>(m2[n][i]);
+                    float dl = om - mean[n][i];
+                    float mm = (mean[n][i] + om) * 0.5f;
+                    m2[n][i] = (m2[n][i] + o2) + (dl * dl) * half_n;
+                    mean[n][i] = mm;
+                }
+            half_n = half_n * 2.0f;
+#pragma unroll
+            for (int n = 0; n < 5; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float om = quad_perm<0x4E>(mean[n][i]), o2 = quad_perm<0x4E>(m2[n][i]);
+                    float dl = om - mean[n][i];
+                    float mm = (mean[n][i] + om) * 0.5f;
+                    m2[n][i] = (m2[n][i] + o2) + (dl * dl) * half_n;
+                    mean[n][i] = mm;
+                }
+        }
+        // The quad now holds four copies of the 20 pooled (mean, M2) pairs of its system: lane `ph` finishes
+        // neurons 5ph..5ph+4 (compute_summary_stats :420-431), so the sqrt/divide sequences run once, not four times.
+        float mymean[5], mym2[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float a0 = mean[j >> 2][j & 3], a1 = mean[(5 + j) >> 2][(5 + j) & 3], a2 = mean[(10 + j) >> 2][(10 + j) & 3],
+                  a3 = mean[(15 + j) >> 2][(15 + j) & 3];
+            float c0 = m2[j >> 2][j & 3], c1 = m2[(5 + j) >> 2][(5 + j) & 3], c2 = m2[(10 + j) >> 2][(10 + j) & 3],
+                  c3 = m2[(15 + j) >> 2][(15 + j) & 3];
+            mymean[j] = ph == 0 ? a0 : ph == 1 ? a1 : ph == 2 ? a2 : a3;
+            mym2[j] = ph == 0 ? c0 : ph == 1 ? c1 : ph == 2 ? c2 : c3;
+        }
+        float e1[5], e2[5];
+        if (p.eps) {
+            const float* ep = p.eps + (r * p.B + sysc) * S2 + 5 * ph;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { e1[j] = ep[j]; e2[j] = ep[L + j]; }
+        } else {
+            // the system's 40 normals are ten Philox blocks: lane ph generates blocks ph, ph+4, ph+8 into LDS
+            const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + sysc;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int qd = ph + 4 * t;
+                if (qd < 10) *reinterpret_cast<f32x4*>(epsscr + sl * S2 + 4 * qd) = philox_eps4(grow, gsys, qd, p.seed);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { e1[j] = epsscr[sl * S2 + 5 * ph + j]; e2[j] = epsscr[sl * S2 + L + 5 * ph + j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float sample_mu = mymean[j];
+            float sd = sqrtf(mym2[j] / nm1);   // torch.std (unbiased)
+            float sample_var = sd * sd;        // **2
+            float std_in_mu = sqrtf(sample_var / nT);
+            float std_in_var = sqrtf((2.0f * (sample_var * sample_var)) / nm1);
+            float mu_s = e1[j] * std_in_mu + sample_mu;
+            float var_s = e2[j] * std_in_var + sample_var;
+            float sd_s = sqrtf(fabsf(var_s) + 1e-5f);  // EPSILON (:337)
+            sumscr[sl * S2 + 5 * ph + j] = mu_s;
+            sumscr[sl * S2 + L + 5 * ph + j] = sd_s;
+            if (p.summary && valid) {
+                float* sp = p.summary + (r * p.B + sys) * S2 + 5 * ph + j;
+                sp[0] = mu_s;
+                sp[L] = sd_s;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        STAMP(8);  // merge + noise + finish
+        // ---- regress_nn on the 16 systems of this wave-batch (16x16x4 path): column c <-> system wb0 + c
+        const int64_t sysb = wb0 + c;
+        const bool validb = sysb < b1;
+        float skeep[10];
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) skeep[ks] = sumscr[c * S2 + kmap_summary(ks, g)];
+        const float* f2l = f2frag + lane;
+        auto W2f = [&](int f) { return f2l[f * 64]; };
+        f32x4 a4[3], a5[3], a6;
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a4[mt] = (f32x4){W2f(70 + mt * 4), W2f(71 + mt * 4), W2f(72 + mt * 4), W2f(73 + mt * 4)};
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(ks * 3 + mt), skeep[ks], a4[mt]);
+        a4[0] = relu4(a4[0]); a4[1] = relu4(a4[1]); a4[2] = relu4<2>(a4[2]);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a5[mt] = (f32x4){W2f(82 + mt * 4), W2f(83 + mt * 4), W2f(84 + mt * 4), W2f(85 + mt * 4)};
+#pragma unroll
+        for (int ks = 0; ks < NKH; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(30 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
+        a5[0] = relu4(a5[0]); a5[1] = relu4(a5[1]); a5[2] = relu4<2>(a5[2]);
+        a6 = (f32x4){W2f(94), W2f(95), W2f(96), W2f(97)};
+#pragma unroll
+        for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(60 + ks), a5[ks >> 2][ks & 3], a6);
+        if (g == 0 && validb) {
+            // predict_instability + soft_clamp (:295-296, :437-442)
+            float r0 = a6[0], r1 = a6[1];
+            float mu = (0.5f * (tanhf(r0) + 1.0f)) * 8.0f + 4.0f;
+            float sd = (0.5f * (tanhf(r1) + 1.0f)) * p.std_span + p.std_lo;
+            if (bad_seed) mu = sd = __builtin_nanf("");
+            const int64_t o = (r * p.B + sysb) * 2;
+            *reinterpret_cast<f32x2*>(p.out + o) = (f32x2){mu, sd};
+#if !BNN_STAMPS
+            if (p.pre_clamp) *reinterpret_cast<f32x2*>(p.pre_clamp + o) = (f32x2){r0, r1};
+#endif
+        }
+        __builtin_amdgcn_wave_barrier();  // scratch is reused by the next wave-batch
+        STAMP(9);  // regress_nn + store
+    }
+#if BNN_STAMPS
+    if (p.pre_clamp && tid == 0) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.pre_clamp) + (int64_t)blockIdx.x * 12;
+        for (int i = 0; i < 12; ++i) dst[i] = st_acc[i];
+    }
+#endif
+}
+

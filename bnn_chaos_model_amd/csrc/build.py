@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libbnn_chaos_hip.so")
 SRCS = ["bnn_kernels.hip", "bnn_tables.cpp"]
-DEPS = SRCS + ["bnn_layout.h", "bnn_tables.h", os.path.join("..", "..", "include", "bnn_chaos_hip.h")]
+DEPS = SRCS + ["bnn_layout.h", "bnn_tables.h", "bnn_common.hip.h", "bnn_engine_a.hip.h", "bnn_engine_b.hip.h", os.path.join("..", "..", "include", "bnn_chaos_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
