@@ -51,6 +51,39 @@ __global__ void bnn_moments_kernel(const float* __restrict__ samples, int64_t R,
     mom[b * 4] = s0; mom[b * 4 + 1] = s1; mom[b * 4 + 2] = s2; mom[b * 4 + 3] = s3;
 }
 
+// Per-system percentiles over the draws: one workgroup bitonic-sorts one (system, channel) column of R values in LDS.
+struct QuantParams { double q[16]; int nq; };
+__global__ __launch_bounds__(256) void bnn_quantiles_kernel(const float* __restrict__ samples, int64_t R, int64_t B, int npad, QuantParams qp,
+                                                            float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sv[];
+    const int64_t b = blockIdx.x >> 1;
+    const int ch = blockIdx.x & 1;
+    for (int i = threadIdx.x; i < npad; i += 256) sv[i] = i < R ? samples[((int64_t)i * B + b) * 2 + ch] : __builtin_inff();
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npad; i += 256) {
+                int l = i ^ j;
+                if (l > i) {
+                    float a = sv[i], c = sv[l];
+                    bool up = (i & k) == 0;
+                    if ((a > c) == up) { sv[i] = c; sv[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if ((int)threadIdx.x < qp.nq) {
+        // numpy 'linear': virtual index q/100*(R-1); lerp(a, b, t) = a + (b-a)*t, evaluated from b's side for t >= 0.5
+        double vi = qp.q[threadIdx.x] / 100.0 * (double)(R - 1);
+        int64_t lo = (int64_t)floor(vi);
+        if (lo > R - 1) lo = R - 1;
+        int64_t hi = lo + 1 < R ? lo + 1 : R - 1;
+        double t = vi - (double)lo, a = sv[lo], c = sv[hi], d = c - a;
+        double v = t >= 0.5 ? c - d * (1.0 - t) : a + d * t;
+        out[(b * 2 + ch) * qp.nq + threadIdx.x] = (float)v;
+    }
+}
+
 // data_setup_kernel + StandardScaler.transform + .float(): one thread per (row, raw column j of the 32)
 __global__ void bnn_feature_pack_kernel(const double* __restrict__ ts, const double* __restrict__ mass, const double* __restrict__ Xin,
                                         int64_t N, int T, const double* __restrict__ mean, const double* __restrict__ scale,
@@ -396,6 +429,30 @@ int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x
     p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
     p.out = out; p.pre_clamp = pre_clamp; p.summary = summary;
     return launch_forward(plan, grid, p, true, false, stream);
+}
+
+int bnn_quantiles_f32(const float* samples, int64_t R, int64_t B, const double* host_q, int32_t nq, float* out, void* stream) {
+    if (R < 0 || B < 0 || nq < 1 || nq > 16 || !host_q) return fail(BNN_ERR_INVALID, "bad argument");
+    if (B == 0) return 0;
+    if (R < 1 || R > 16384) return fail(BNN_ERR_RANGE, "quantiles need 1 <= R <= 16384 draws");
+    if (!samples || !out) return fail(BNN_ERR_INVALID, "NULL argument");
+    QuantParams qp;
+    qp.nq = nq;
+    for (int i = 0; i < nq; ++i) {
+        if (!(host_q[i] >= 0.0 && host_q[i] <= 100.0)) return fail(BNN_ERR_RANGE, "percentiles must be in [0, 100]");
+        qp.q[i] = host_q[i];
+    }
+    int npad = 2;
+    while (npad < R) npad <<= 1;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_quantiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    });
+    if (2 * B > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many systems for one launch");
+    hipLaunchKernelGGL(bnn_quantiles_kernel, dim3((unsigned)(2 * B)), dim3(256), (size_t)npad * sizeof(float), (hipStream_t)stream, samples, R,
+                       B, npad, qp, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int bnn_feature_pack_f64(const double* tseries, const double* mass, const double* X64_in, int64_t N, int32_t T, const double* mean,

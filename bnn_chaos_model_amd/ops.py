@@ -153,6 +153,18 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
     return (out, pre, summ) if debug else out
 
 
+def quantiles(samples, q=(50.0,)):
+    """Per-system percentiles over the draws, numpy 'linear' interpolation: samples [R,B,2] -> [B,2,len(q)] float32.
+    q=50 is np.median(_preds[..., c], 0) of figures/main_figures.py:277-278."""
+    import numpy as np
+    samples = _f32(samples, "samples")
+    R, B, _ = samples.shape
+    qa = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+    out = torch.empty((B, 2, qa.size), dtype=torch.float32, device=samples.device)
+    N.check(N.lib().bnn_quantiles_f32(N.ptr(samples), R, B, qa.ctypes.data, qa.size, N.ptr(out), N.stream_ptr()))
+    return out
+
+
 def feature_pack(tseries=None, mass=None, X=None, mean=None, scale=None, want_x64=False):
     """data_setup_kernel (figures/spock/regression.py:183-213) + ssX.transform + .float() on the GPU.
 

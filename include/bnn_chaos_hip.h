@@ -142,6 +142,13 @@ int bnn_feature_pack_f64(const double* tseries, const double* mass, const double
  * the existing contents (for processing draws in slabs). */
 int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments, int32_t accumulate, void* stream);
 
+/* Per-system order statistics over the draws (the deterministic part):
+ * np.median(_preds[..., 0], 0) / np.median(_preds[..., 1], 0) of figures/main_figures.py:277-278 and the
+ * np.percentile calls of figures/multiswag_5_planet.py:484-489, numpy's default linear interpolation.
+ *   samples [R,B,2] float32; q [nq] percentiles in [0,100] (host doubles, nq <= 16); out [B,2,nq] float32.
+ * R <= 16384 (one workgroup sorts one system's column in LDS). */
+int bnn_quantiles_f32(const float* samples, int64_t R, int64_t B, const double* host_q, int32_t nq, float* out, void* stream);
+
 /* The normals the kernels generate when a noise pointer is NULL, written out for inspection:
  *   kind 0: z1 [n_draws, d]   kind 1: z2 [n_draws, K]   kind 2: eps [rows, B, 2, 20]
  *   kind 3: eps_in [rows, B, T = width, 41]   kind 4: eps_sum [rows, B, 40]

@@ -237,3 +237,21 @@ def test_feature_pack_matches_reference(ops):
     assert np.array_equal(y32, z["x32"]) and np.array_equal(y32, features.standardize(z["X64"], z["mean"], z["scale"]))
     with pytest.raises(NotImplementedError):
         ops.feature_pack(np.zeros((1, 100, 25)), np.zeros((1, 3)), mean=z["mean"], scale=z["scale"])
+
+
+@pytest.mark.parametrize("R", (1, 2, 7, 100, 2000, 3000, 4097))
+def test_quantiles_match_numpy(R, ops):
+    """np.median / np.percentile over the draw axis (figures/main_figures.py:277-278, multiswag_5_planet.py:484-489)."""
+    rng = np.random.default_rng(R)
+    B = 33
+    s = rng.standard_normal((R, B, 2)).astype(np.float32)
+    s[:, 0, 0] = 4.0          # ties
+    if R > 3:
+        s[1, 1, 1] = s[2, 1, 1]
+    q = [50.0, 50 + 68 / 2, 50 - 68 / 2, 50 + 95 / 2, 50 - 95 / 2, 0.0, 100.0]
+    got = ops.quantiles(dev(s), q).cpu().numpy()
+    want = np.percentile(s.astype(np.float64), q, axis=0)            # [nq, B, 2]
+    assert np.abs(got - np.moveaxis(want, 0, -1)).max() <= 2.4e-7 * 4
+    assert np.abs(got[..., 0] - np.median(s, axis=0)).max() <= 2.4e-7 * 4
+    with pytest.raises(Exception):
+        ops.quantiles(torch.zeros((16385, 1, 2), device="cuda"))
