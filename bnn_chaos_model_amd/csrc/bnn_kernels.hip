@@ -84,6 +84,71 @@ __global__ __launch_bounds__(256) void bnn_quantiles_kernel(const float* __restr
     }
 }
 
+// fast_truncnorm, right = inf: one thread per element, candidates in float64 exactly as numpy forms them
+constexpr uint32_t TAG_TN = 0x60000000u, TAG_U = 0x70000000u;
+__global__ void bnn_truncnorm_kernel(const float* __restrict__ musd, int64_t n, const double* __restrict__ normals, int nsamp, double left,
+                                     uint64_t seed, int64_t id0, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f32x2 ms = *reinterpret_cast<const f32x2*>(musd + 2 * i);
+    const double loc = ms.x, scale = ms.y;
+    double first = 0.0, pick = 0.0;
+    bool found = false;
+    for (int s0 = 0; s0 < nsamp && !found; s0 += 4) {
+        f32x4 z4 = {0, 0, 0, 0};
+        if (!normals) {
+            const int64_t el = id0 + i;
+            z4 = philox_normal4(TAG_TN | (uint32_t)(s0 >> 2), (uint32_t)el, (uint32_t)((uint64_t)el >> 32), 0u, seed);
+        }
+        for (int k = 0; k < 4 && s0 + k < nsamp; ++k) {
+            const double z = normals ? normals[(int64_t)(s0 + k) * n + i] : (double)z4[k];
+            const double v = z * scale + loc;  // rand_out * scale + loc (:347-350); no fma (-ffp-contract=off)
+            if (s0 + k == 0) first = v;
+            if (v > left) { pick = v; found = true; break; }
+        }
+    }
+    out[i] = (float)(found ? pick : first);  // argmax of an all-False mask is 0 (:360-362)
+}
+
+// prior resampling: scipy interp1d(kind='linear') evaluated at u[rank] for every element past the threshold
+__global__ void bnn_prior_resample_kernel(float* __restrict__ vals, int64_t n, const int64_t* __restrict__ rank, const double* __restrict__ cum,
+                                          const double* __restrict__ edge, int64_t m, const double* __restrict__ u, double thr, uint64_t seed,
+                                          int64_t id0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!((double)vals[i] >= thr)) return;
+    const int64_t k = rank[i];
+    double r;
+    if (u) {
+        r = u[k];
+    } else {  // 53-bit uniform in [0,1) from one Philox block, as numpy builds its doubles: (a >> 5) * 2^26 + (b >> 6)
+        const int64_t el = id0 + k;
+        uint4 q = philox4x32_10(make_uint4(TAG_U, (uint32_t)el, (uint32_t)((uint64_t)el >> 32), 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        r = ((double)(q.x >> 5) * 67108864.0 + (double)(q.y >> 6)) / 9007199254740992.0;
+    }
+    int64_t lo = 0, hi = m;  // np.searchsorted(cum, r), side='left'
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (cum[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    int64_t idx = lo < 1 ? 1 : (lo > m - 1 ? m - 1 : lo);
+    const double xl = cum[idx - 1], xh = cum[idx], yl = edge[idx - 1], yh = edge[idx];
+    const double slope = (yh - yl) / (xh - xl);
+    vals[i] = (float)(slope * (r - xl) + yl);
+}
+
+__global__ void bnn_group_min_kernel(const float* __restrict__ vals, int64_t n, int group, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = vals[i * group];
+    for (int j = 1; j < group; ++j) {
+        float w = vals[i * group + j];
+        v = (w < v || w != w) ? w : v;  // np.min propagates NaN
+        if (v != v) break;
+    }
+    out[i] = v;
+}
+
 // data_setup_kernel + StandardScaler.transform + .float(): one thread per (row, raw column j of the 32)
 __global__ void bnn_feature_pack_kernel(const double* __restrict__ ts, const double* __restrict__ mass, const double* __restrict__ Xin,
                                         int64_t N, int T, const double* __restrict__ mean, const double* __restrict__ scale,
@@ -429,6 +494,37 @@ int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x
     p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
     p.out = out; p.pre_clamp = pre_clamp; p.summary = summary;
     return launch_forward(plan, grid, p, true, false, stream);
+}
+
+int bnn_truncnorm_f32(const float* musd, int64_t n, const double* normals, int32_t nsamp, double left, uint64_t philox_seed, int64_t id0,
+                      float* out, void* stream) {
+    if (n < 0 || nsamp < 1) return fail(BNN_ERR_INVALID, "bad n/nsamp");
+    if (n == 0) return 0;
+    if (!musd || !out) return fail(BNN_ERR_INVALID, "NULL argument");
+    hipLaunchKernelGGL(bnn_truncnorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, musd, n, normals, (int)nsamp,
+                       left, philox_seed, id0, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bnn_prior_resample_f32(float* vals, int64_t n, const int64_t* rank, const double* cum, const double* edge, int64_t m, const double* u,
+                           double threshold, uint64_t philox_seed, int64_t id0, void* stream) {
+    if (n < 0) return fail(BNN_ERR_INVALID, "bad n");
+    if (n == 0) return 0;
+    if (!vals || !rank || !cum || !edge || m < 2) return fail(BNN_ERR_INVALID, "NULL argument or table shorter than 2");
+    hipLaunchKernelGGL(bnn_prior_resample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vals, n, rank, cum, edge,
+                       m, u, threshold, philox_seed, id0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bnn_group_min_f32(const float* vals, int64_t n, int32_t group, float* out, void* stream) {
+    if (n < 0 || group < 1) return fail(BNN_ERR_INVALID, "bad n/group");
+    if (n == 0) return 0;
+    if (!vals || !out) return fail(BNN_ERR_INVALID, "NULL argument");
+    hipLaunchKernelGGL(bnn_group_min_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vals, n, (int)group, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int bnn_quantiles_f32(const float* samples, int64_t R, int64_t B, const double* host_q, int32_t nq, float* out, void* stream) {

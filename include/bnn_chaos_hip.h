@@ -149,6 +149,23 @@ int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments,
  * R <= 16384 (one workgroup sorts one system's column in LDS). */
 int bnn_quantiles_f32(const float* samples, int64_t R, int64_t B, const double* host_q, int32_t nq, float* out, void* stream);
 
+/* fast_truncnorm with right = inf (figures/multiswag_5_planet.py:306-370, figures/main_figures.py:167-227):
+ *   musd [n,2] float32 = (loc, scale) pairs -- the [R,B,2] output of the forward as it stands;
+ *   normals [nsamp, n] float64 (the reference's np.random.normal draws, element order) or NULL = in-kernel Philox;
+ *   out [n] float32 = first of the nsamp candidates loc + scale*z (float64) that exceeds `left`, else the first one. */
+int bnn_truncnorm_f32(const float* musd, int64_t n, const double* normals, int32_t nsamp, double left, uint64_t philox_seed,
+                      int64_t id0, float* out, void* stream);
+
+/* Prior resampling (figures/multiswag_5_planet.py:396-422): vals[i] >= threshold is replaced by inv_cdf(u[rank[i]]).
+ *   rank [n] int64 = number of earlier elements >= threshold (exclusive prefix count, C order);
+ *   cum, edge [m] float64 = the interp1d table, SORTED by cum (the host builds it: its size depends on the count);
+ *   u [count] float64 (np.random.rand) or NULL = in-kernel Philox uniforms.  vals is updated in place. */
+int bnn_prior_resample_f32(float* vals, int64_t n, const int64_t* rank, const double* cum, const double* edge, int64_t m,
+                           const double* u, double threshold, uint64_t philox_seed, int64_t id0, void* stream);
+
+/* np.min over the last axis of size `group` (min over trios, figures/multiswag_5_planet.py:428): vals [n,group] -> out [n]. */
+int bnn_group_min_f32(const float* vals, int64_t n, int32_t group, float* out, void* stream);
+
 /* The normals the kernels generate when a noise pointer is NULL, written out for inspection:
  *   kind 0: z1 [n_draws, d]   kind 1: z2 [n_draws, K]   kind 2: eps [rows, B, 2, 20]
  *   kind 3: eps_in [rows, B, T = width, 41]   kind 4: eps_sum [rows, B, 40]

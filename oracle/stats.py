@@ -1,0 +1,52 @@
+"""numpy restatement of the post-sampling statistics (TEST INFRASTRUCTURE, like the rest of oracle/).
+
+figures/multiswag_5_planet.py: fast_truncnorm :306-370 (same function in figures/main_figures.py:167-227), prior
+resampling of samples past 9 :396-422, min over trios :428.  Pinned by tests/golden/case_stats.npz, which
+make_golden.py produces by executing the reference's own source fragments."""
+import numpy as np
+
+
+def truncnorm_first_good(loc, scale, normals, left):
+    """fast_truncnorm with right = inf: candidates = normals * scale + loc (float64), first one > left, else the first.
+    loc, scale: any shape (float32); normals [nsamp, n] float64 in flattened element order -> samples like scale."""
+    sc = np.asarray(scale).reshape(-1)
+    lc = np.asarray(loc).reshape(-1)
+    rand_out = normals * sc[None] + lc[None]                      # :347-350
+    mask = rand_out > left                                        # :353-354
+    first_good = rand_out[mask.argmax(0), np.arange(sc.size)]     # :360-362
+    out = np.zeros_like(sc)                                       # float32 like `scale` (:329)
+    out[:] = first_good
+    return out.reshape(np.asarray(scale).shape)
+
+
+def prior_pdf(logT):
+    return 3.27086190404742 * np.exp(-0.424033970670719 * logT) - 10.8793430454878 * np.exp(-0.200351029031774 * logT ** 2)  # :400-403
+
+
+def prior_table(n_samples, normalization, top=100.0):
+    """cum_values, bin_edges of :413-417."""
+    bins = n_samples * 4
+    edges = np.linspace(9, top, num=bins)
+    cum = [0] + list(np.cumsum(prior_pdf(edges) / normalization * (edges[1] - edges[0]))) + [1]
+    return np.array(cum, dtype=np.float64), np.array([9.0] + list(edges) + [top], dtype=np.float64)
+
+
+def interp1d_linear(x, y, xn):
+    """scipy.interpolate.interp1d(x, y)(xn), kind='linear', assume_sorted=False (:418, :420)."""
+    order = np.argsort(x, kind="mergesort")
+    x, y = x[order], y[order]
+    idx = np.searchsorted(x, xn).clip(1, len(x) - 1)
+    lo, hi = idx - 1, idx
+    slope = (y[hi] - y[lo]) / (x[hi] - x[lo])
+    return slope * (xn - x[lo]) + y[lo]
+
+
+def resample_prior(samps, u, normalization, threshold=9.0):
+    """samps[samps >= 9] = inv_cdf(u), in C order (:396, :419-422)."""
+    out = samps.copy()
+    mask = out >= threshold
+    n = int(mask.sum())
+    if n:
+        cum, edges = prior_table(n, normalization)
+        out[mask] = interp1d_linear(cum, edges, u[:n])
+    return out

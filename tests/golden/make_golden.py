@@ -223,6 +223,50 @@ def main():
     save("case_features.npz", tseries=ts[:, 0], mass=masses, X64=Xs, x32=torch.tensor(Xp).float().numpy(),
          mean=ss.mean_, scale=ss.scale_)
 
+    # ---- case S: the post-sampling statistics of figures/multiswag_5_planet.py.  The script cannot
+    # run here (rebound, xgboost, ...), so the function fast_truncnorm (:306-370) and the top-level statements of the
+    # prior-resampling block (:396-422) and of the min over trios (:428) are cut out with ast and executed as they are.
+    src5 = open(f"{REF}/figures/multiswag_5_planet.py").read()
+    mod5 = ast.parse(src5)
+    ftn = [n for n in mod5.body if isinstance(n, ast.FunctionDef) and n.name == "fast_truncnorm"][0]
+    ns5 = {"np": np, "jnp": np}
+    exec(compile(ast.Module(body=[ftn], type_ignores=[]), "multiswag_5_planet.py:fast_truncnorm", "exec"), ns5)
+    rng = np.random.default_rng(99)
+    samples_, sims_ = 7, 40
+    loc = rng.uniform(3.0, 12.5, size=(samples_, sims_, 3)).astype(np.float32)   # "time[..., 0]"
+    loc[0, :5] = 3.2                                                               # hard cases: most candidates below 4
+    scale = rng.uniform(0.5, 6.0, size=(samples_, sims_, 3)).astype(np.float32)
+    scale[0, :5] = 0.05                                                            # ... and no candidate passes
+    np.random.seed(6000)
+    with Tape() as tape_tn:
+        o_normal = np.random.normal
+        def rec_normal(*a, **k):
+            r_ = o_normal(*a, **k)
+            tape_tn.items.append(("np.normal", np.asarray(r_).copy()))
+            return r_
+        np.random.normal = rec_normal
+        try:
+            samps_time = np.array(ns5["fast_truncnorm"](loc, scale, left=4, d=300, nsamp=40, seed=0))
+        finally:
+            np.random.normal = o_normal
+    assert samps_time.dtype == np.float32
+    trunc = samps_time.copy()
+    blk = [n for n in mod5.body if 396 <= n.lineno <= 422]
+    ns6 = {"np": np, "samps_time": samps_time}
+    np.random.seed(6001)
+    o_rand = np.random.rand
+    rec = []
+    np.random.rand = lambda *a: (rec.append(o_rand(*a)) or rec[-1])
+    try:
+        exec(compile(ast.Module(body=blk, type_ignores=[]), "multiswag_5_planet.py:396-422", "exec"), ns6)
+    finally:
+        np.random.rand = o_rand
+    outs_ = np.min(ns6["samps_time"], 2).T                                         # :428
+    save("case_stats.npz", loc=loc, scale=scale, left=np.array(4.0), nsamp=np.array(40), d=np.array(300),
+         truncnorm=trunc, resampled=ns6["samps_time"], u=rec[0], n_samples=np.array(int(ns6["n_samples"])),
+         normalization=np.array(ns6["normalization"]), cum_values=np.array(ns6["cum_values"], dtype=np.float64),
+         bin_edges=np.array(ns6["bin_edges"], dtype=np.float64), outs=outs_, **tape_tn.as_dict("normals"))
+
     m0 = models[0]
     # constant-4 "unstable" fill (figures/multiswag_5_planet.py:214-215) after ssX, float64 transform then .float()
     raw4 = np.ones((4, 100, 41)) * 4

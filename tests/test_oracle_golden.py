@@ -192,3 +192,23 @@ def test_feature_packing_matches_reference_function():
     assert X.shape == z["X64"].shape and np.array_equal(X, z["X64"])
     assert np.array_equal(features.standardize(X, z["mean"], z["scale"]), z["x32"])
     assert np.isfinite(z["X64"]).all() and (z["X64"][0, 5, 38] == 1.0) and (z["X64"][1, 7, 39] == 1.0) and (z["X64"][2, 9, 40] == 1.0)
+
+
+def test_statistics_epilogue_matches_reference_fragments():
+    """oracle/stats.py vs fast_truncnorm, the prior-resampling block and the min over trios executed from the reference's source."""
+    from oracle import stats
+    z = load_golden("case_stats.npz")
+    n = z["loc"].size
+    d, nsamp = int(z["d"]), int(z["nsamp"])
+    normals = np.concatenate([z[f"normals_{i:03d}"] for i in range(int(z["normals_n"]))], axis=1)  # chunks of d elements
+    assert normals.shape == (nsamp, n)
+    tn = stats.truncnorm_first_good(z["loc"], z["scale"], normals, float(z["left"]))
+    assert tn.dtype == np.float32 and np.array_equal(tn, z["truncnorm"])
+    assert (tn[0, :5] < 4).all()  # nothing passed: the first candidate is kept (argmax of an all-False mask)
+    cum, edges = stats.prior_table(int(z["n_samples"]), float(z["normalization"]))
+    assert np.array_equal(cum, z["cum_values"]) and np.array_equal(edges, z["bin_edges"])
+    rs = stats.resample_prior(z["truncnorm"], z["u"], float(z["normalization"]))
+    assert np.array_equal(rs, z["resampled"])
+    assert np.array_equal(np.min(rs, 2).T, z["outs"])
+    from scipy.integrate import quad
+    assert quad(stats.prior_pdf, a=9, b=np.inf)[0] == float(z["normalization"])

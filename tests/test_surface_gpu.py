@@ -206,3 +206,32 @@ def test_torch_custom_ops(swag_states, inputs):
                                            torch.empty((1, 7583, 30), device="cuda"), torch.empty(6, dtype=torch.int32, device="cuda"),
                                            None, None, None, 2, 0.5, 0, 0, 0)
         assert fo.shape == (3, 7, 2)
+
+
+def test_statistics_epilogue_replays_reference():
+    """fast_truncnorm -> prior resampling -> min over trios -> percentiles, with numpy's generator consumed as the
+    reference consumes it: bit-identical to the captured reference fragments (figures/multiswag_5_planet.py:306-428)."""
+    from bnn_chaos_model_amd import stats
+    z = load_golden("case_stats.npz")
+    np.random.seed(6000)
+    tn = stats.fast_truncnorm(z["loc"], z["scale"], left=4, d=int(z["d"]), nsamp=int(z["nsamp"]), seed=0)
+    assert tn.is_cuda and tn.shape == z["truncnorm"].shape and np.array_equal(tn.cpu().numpy(), z["truncnorm"])
+    assert stats.prior_normalization() == float(z["normalization"])
+    np.random.seed(6001)
+    rs = stats.resample_prior(tn)
+    assert np.array_equal(rs.cpu().numpy(), z["resampled"])
+    outs = stats.min_over_trios(rs)
+    assert np.array_equal(outs.cpu().numpy(), z["outs"])
+    q = [50.0, 50 + 68 / 2, 50 - 68 / 2, 50 + 95 / 2, 50 - 95 / 2]
+    pc = stats.percentiles(outs, q).cpu().numpy()
+    want = np.stack([np.percentile(z["outs"][i].astype(np.float64), q) for i in range(z["outs"].shape[0])])
+    assert np.abs(pc - want).max() <= 1e-6
+    # (mu, std) tensor form and in-kernel noise: same distribution (every sample > left unless nothing passes)
+    musd = torch.stack([torch.tensor(z["loc"]), torch.tensor(z["scale"])], -1)
+    ph = stats.fast_truncnorm(musd, left=4, nsamp=40, seed=3, rng="philox").cpu().numpy()
+    assert ph.shape == z["loc"].shape and (ph[1:] > 4).mean() > 0.999 and (ph[0, :5] < 4).all()
+    rp = stats.resample_prior(torch.tensor(ph), rng="philox", seed=4).cpu().numpy()
+    moved = ph >= 9
+    assert (rp[moved] >= 9).all() and (rp[moved] <= 100).all() and np.array_equal(rp[~moved], ph[~moved])
+    with pytest.raises(NotImplementedError):
+        stats.fast_truncnorm(z["loc"], z["scale"], left=4, right=12)
