@@ -33,9 +33,6 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 #ifndef BNN_EXP
 #define BNN_EXP 0  // timing experiments (wrong results when non-zero)
 #endif
-#ifndef BNN_TWO_STREAMS
-#define BNN_TWO_STREAMS 0  // interleave two tiles per wave through the layers (0 = one tile at a time)
-#endif
 #ifndef BNN_WAVES_PER_SIMD
 #define BNN_WAVES_PER_SIMD 3  // register budget of the 16x16x4 kernel: 2 -> 256 VGPRs, 3 -> 168 (+3 % measured)
 #endif

@@ -269,53 +269,22 @@ __global__ __launch_bounds__(256, (NOISY || NK1 != 8) ? 2 : BNN_WAVES_PER_SIMD) 
 
             XRaw<NK1> rawA, rawB, nrawA, nrawB;
             int it = 0;
-            if constexpr (BNN_TWO_STREAMS && !NOISY) {
-                // Two consecutive tiles travel through the layers together: while one stream's MFMAs occupy the
-                // matrix pipe, the other stream's dependent ReLU / pool VALU work issues in their shadow, so the
-                // pipe never waits on a layer boundary.  Pool order stays tile order (bit-identical results).
-                prefetch(rawA, nrawA, 0);
-                prefetch(rawB, nrawB, 1);
+            // one tile at a time, next tile prefetched into a ping-pong pair of register sets
+            auto do_tile = [&](const XRaw<NK1>& raw, const XRaw<NK1>& nraw, const int t) {
+                H2 y = layer3(relu3(layer2(relu3(layer1(make_cur(raw, nraw, t))))));
+                pool(y, t);
+            };
+            prefetch(rawA, nrawA, 0);
+            pin_loads();
+            for (; it + 1 < ntiles; it += 2) {
+                prefetch(rawB, nrawB, it + 1);
                 pin_loads();
-                for (; it + 1 < ntiles; it += 2) {
-                    XTile<NK1> curA = make_cur(rawA, nrawA, it), curB = make_cur(rawB, nrawB, it + 1);
-                    prefetch(rawA, nrawA, it + 2);   // one pair ahead, into the registers just consumed
-                    prefetch(rawB, nrawB, it + 3);
-                    pin_loads();
-                    H3 hA = layer1(curA);
-                    H3 hB = layer1(curB);
-                    hA = relu3(hA);
-                    H3 gA = layer2(hA);
-                    hB = relu3(hB);
-                    H3 gB = layer2(hB);
-                    gA = relu3(gA);
-                    H2 yA = layer3(gA);
-                    gB = relu3(gB);
-                    H2 yB = layer3(gB);
-                    pool(yA, it);
-                    pool(yB, it + 1);
-                }
-                if (it < ntiles) {  // odd tile count: rawA already holds the last tile
-                    H2 y = layer3(relu3(layer2(relu3(layer1(make_cur(rawA, nrawA, it))))));
-                    pool(y, it);
-                }
-            } else {
-                // one tile at a time, next tile prefetched into a ping-pong pair of register sets
-                auto do_tile = [&](const XRaw<NK1>& raw, const XRaw<NK1>& nraw, const int t) {
-                    H2 y = layer3(relu3(layer2(relu3(layer1(make_cur(raw, nraw, t))))));
-                    pool(y, t);
-                };
-                prefetch(rawA, nrawA, 0);
+                do_tile(rawA, nrawA, it);
+                prefetch(rawA, nrawA, it + 2);
                 pin_loads();
-                for (; it + 1 < ntiles; it += 2) {
-                    prefetch(rawB, nrawB, it + 1);
-                    pin_loads();
-                    do_tile(rawA, nrawA, it);
-                    prefetch(rawA, nrawA, it + 2);
-                    pin_loads();
-                    do_tile(rawB, nrawB, it + 1);
-                }
-                if (it < ntiles) do_tile(rawA, nrawA, it);
+                do_tile(rawB, nrawB, it + 1);
             }
+            if (it < ntiles) do_tile(rawA, nrawA, it);
 
             // merge the 4 lanes of a quad (timesteps t = 4*it + (c&3)): equal-count Chan update, symmetric
             float mean[5] = {mean0[0], mean0[1], mean0[2], mean0[3], mean1};

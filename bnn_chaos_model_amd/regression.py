@@ -64,7 +64,26 @@ class FeatureRegressor(object):
         return out
 
     def sample(self, sim, indices=None, samples=1000):
-        raise NotImplementedError("needs REBOUND feature generation (get_extended_tseries), upstream of the accelerated path")
+        raise NotImplementedError("needs REBOUND feature generation (get_extended_tseries), upstream of the accelerated path; "
+                                  "give its output to sample_tseries()")
+
+    def sample_tseries(self, tseries, mass_arrays, samples=1000, rng="torch", philox_seed=0):
+        """FeatureRegressor.sample (regression.py:110-179) downstream of the N-body integration:
+        tseries [trios, Nout, 26] (get_extended_tseries' output; every 10th step is used, :141), mass_arrays [trios, 3]
+        -> (mu, std) ndarrays [trios, samples], drawing the generators exactly like the loop at :149
+        (`samples` calls of sample_full_swag with B = 1 per trio), one launch per trio."""
+        tseries = np.asarray(tseries, dtype=np.float64)
+        alltime = []
+        for i in range(tseries.shape[0]):
+            cur_tseries = tseries[None, i, ::10]                                  # :141
+            X = pack_features(cur_tseries, np.asarray(mass_arrays[i], dtype=np.float64)[None], self.ssX)  # :143-145
+            if not self.cuda:
+                X = X.cpu()
+            time = self.sample_full_swag_many(X, samples=samples, chunks=1, rng=rng, philox_seed=philox_seed,
+                                              draw_id0=i * samples)              # :149
+            alltime.append(time.detach().cpu().numpy())
+        out = np.array(alltime)[..., 0, :]                                        # :159
+        return out[..., 0], out[..., 1]
 
     def predict(self, sim, indices=None, samples=1000):
         raise NotImplementedError("needs REBOUND feature generation (get_extended_tseries), upstream of the accelerated path")

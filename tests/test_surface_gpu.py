@@ -235,3 +235,24 @@ def test_statistics_epilogue_replays_reference():
     assert (rp[moved] >= 9).all() and (rp[moved] <= 100).all() and np.array_equal(rp[~moved], ph[~moved])
     with pytest.raises(NotImplementedError):
         stats.fast_truncnorm(z["loc"], z["scale"], left=4, right=12)
+
+
+def test_sample_tseries_equals_the_reference_loop(ckpt_dir):
+    """FeatureRegressor.sample downstream of REBOUND (regression.py:137-162): one launch per trio == the literal loop."""
+    from bnn_chaos_model_amd import regression
+    from bnn_chaos_model_amd.regression import FeatureRegressor
+    z = load_golden("case_features.npz")
+    fr = FeatureRegressor(cuda=False, filebase=str(ckpt_dir / "*v50*output.pkl"), sort=True)
+    ts = np.repeat(z["tseries"][:2], 10, axis=1)  # [2 trios, 1000, 26]: every 10th row is the fixture's series
+    np.random.seed(11); torch.manual_seed(11)
+    mu, std = fr.sample_tseries(ts, z["mass"][:2], samples=5)
+    assert mu.shape == std.shape == (2, 5)
+    np.random.seed(11); torch.manual_seed(11)
+    want = []
+    for i in range(2):  # regression.py:137-150, literally
+        X = regression.data_setup_kernel(z["mass"][i], ts[None, i, ::10])
+        X = fr.ssX.transform(X.reshape(-1, X.shape[-1])).reshape(X.shape)
+        X = torch.tensor(X).float()
+        want.append(torch.cat([fr.sample_full_swag(X)[None] for _ in range(5)], dim=0).detach().numpy())
+    want = np.array(want)[..., 0, :]
+    assert np.abs(mu - want[..., 0]).max() <= 1e-5 and np.abs(std - want[..., 1]).max() <= 1e-5
