@@ -16,6 +16,23 @@ V50_ZERO_MASK = sum(1 << c for c in (7, 3, 6, 38, 39, 40, 1, 2, 4, 5))
 _plans = {}
 
 
+def _on_device_of(argname_index=0):
+    """Run the wrapped op with the device of its first tensor argument current: torch's stream, the plan's tables and the
+    kernel launch must all belong to the same GPU (one process may drive several)."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            t = args[argname_index] if len(args) > argname_index else None
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.device.index != torch.cuda.current_device():
+                with torch.cuda.device(t.device):
+                    return fn(*args, **kwargs)
+            return fn(*args, **kwargs)
+        return wrapper
+    return deco
+
+
 def zero_mask_from_flags(fix_megno=False, fix_megno2=True, include_mmr=False, include_nan=False,
                          include_eplusminus=False):
     """Columns zeroed by zero_megno / zero_mmr / zero_nan / zero_eplusminus (spock_reg_model.py:452-500)."""
@@ -52,6 +69,7 @@ def _grid(B, T, J, nchunks, spb, noisy=False):
     return N.BnnGrid(int(B), int(T), int(J), int(nchunks), int(spb), int(bool(noisy)), 0)
 
 
+@_on_device_of(0)
 def swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, scale=0.5, philox_seed=0, draw_id0=0, plan=None):
     """SWAGModel.sample_weights (spock_reg_model.py:815-838) for J draws -> W[J, d].
 
@@ -73,6 +91,7 @@ def swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, scale=0.5, philo
     return W
 
 
+@_on_device_of(0)
 def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0, draw_id0=0, system_id0=0, plan=None,
             debug=False, systems_per_block=0, noisy=False):
     """VarModel.forward (spock_reg_model.py:486-528) for materialised weight vectors W[J,d] -> out[J/nchunks,B,2].
@@ -113,6 +132,7 @@ def _workspace(J, d, device):
     return w
 
 
+@_on_device_of(0)
 def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nchunks=1, scale=0.5, philox_seed=0,
               draw_id0=0, system_id0=0, plan=None, debug=False, systems_per_block=0, out=None, single_launch=None):
     """Fused SWAGModel.forward_swag_fast (spock_reg_model.py:878-908) over the MC loop of
@@ -153,6 +173,7 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
     return (out, pre, summ) if debug else out
 
 
+@_on_device_of(0)
 def quantiles(samples, q=(50.0,)):
     """Per-system percentiles over the draws, numpy 'linear' interpolation: samples [R,B,2] -> [B,2,len(q)] float32.
     q=50 is np.median(_preds[..., c], 0) of figures/main_figures.py:277-278."""
@@ -185,6 +206,7 @@ def feature_pack(tseries=None, mass=None, X=None, mean=None, scale=None, want_x6
     return (x32, x64) if want_x64 else x32
 
 
+@_on_device_of(0)
 def moments(samples, mom=None):
     """samples [R,B,2] -> float64 [B,4] = sum mu, sum mu^2, sum std, sum std^2 (accumulates into `mom` if given)."""
     samples = _f32(samples, "samples")

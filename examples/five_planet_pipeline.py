@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""The compute part of figures/multiswag_5_planet.py (lines 277-298 and 388-489) on the GPU, end to end, on synthetic
+N-body features (the REBOUND integration upstream of it is out of scope):
+
+    features [sims, trios, T, 26] + masses  --pack_features-->  x [sims*trios, T, 41] fp32      (:280-292, regression.py:183-213)
+    MultiSWAG MC loop, samples x 10 chunks   --sample_full_swag_many-->  time [samples, sims, trios, 2]       (:295-298)
+    fast_truncnorm(left=4, nsamp=40) -> prior resampling past 9 -> min over trios -> median / 68 % / 95 % bands (:388-489)
+
+    python examples/five_planet_pipeline.py --ckpt '/path/to/pretrained/*v50*output.pkl' [--sims 50] [--samples 100]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bnn_chaos_model_amd import regression, stats  # noqa: E402
+from bnn_chaos_model_amd.regression import FeatureRegressor  # noqa: E402
+
+
+def run(ckpt_glob, sims=50, trios=3, samples=100, rng="philox", seed=0):
+    model = FeatureRegressor(cuda=True, filebase=ckpt_glob, sort=True)
+    g = np.random.default_rng(seed)
+    tseries = g.standard_normal((sims * trios, 100, 26)) * 0.5          # stand-in for get_extended_tseries output
+    tseries[:, :, 0] = np.linspace(0, 1e4, 100)[None]
+    masses = np.abs(g.standard_normal((sims * trios, 3))) * 1e-5
+    Xflat = regression.pack_features(tseries, masses, model.ssX)         # [sims*trios, 100, 41] fp32 on the GPU
+    time = model.sample_full_swag_many(Xflat, samples=samples, chunks=10, rng=rng, philox_seed=seed)
+    time = time.reshape(samples, sims, trios, 2)
+    samps_time = stats.fast_truncnorm(time, left=4, nsamp=40, seed=seed, rng="philox" if rng == "philox" else "numpy")
+    samps_time = stats.resample_prior(samps_time, rng="philox" if rng == "philox" else "numpy", seed=seed + 1)
+    outs = stats.min_over_trios(samps_time)                              # [sims, samples]
+    q = [50.0, 50 + 68 / 2, 50 - 68 / 2, 50 + 95 / 2, 50 - 95 / 2]
+    bands = stats.percentiles(outs, q)                                   # median, l, u, ll, uu
+    return {"time": time, "samps_time": samps_time, "outs": outs, "bands": bands, "average": outs.mean(1)}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ckpt", required=True)
+    ap.add_argument("--sims", type=int, default=50)
+    ap.add_argument("--samples", type=int, default=100)
+    a = ap.parse_args()
+    r = run(a.ckpt, sims=a.sims, samples=a.samples)
+    torch.cuda.synchronize()
+    b = r["bands"].cpu().numpy()
+    for i in range(min(5, b.shape[0])):
+        print(f"sim {i}: median {b[i, 0]:.3f}  68% [{b[i, 2]:.3f}, {b[i, 1]:.3f}]  95% [{b[i, 4]:.3f}, {b[i, 3]:.3f}]")
