@@ -100,3 +100,16 @@ def test_oracle_spot_checks_at_full_size(full):
             got = f["out"][j, b].cpu().numpy()
             worst = max(worst, np.abs(got - ref).max())
     assert worst <= 2e-6, worst
+
+
+def test_multiswag_sharded_driver_single_rank(full):
+    """distributed.MultiSwagSharded (draws in slabs, moments accumulated, gather a no-op at world size 1) == one launch."""
+    from bnn_chaos_model_amd.distributed import MultiSwagSharded, moments_to_mean_std
+    f = full
+    drv = MultiSwagSharded(f["wa"], f["w2"], f["pd"], draws_per_launch=256)
+    sub = slice(0, 2000)
+    mom = drv.predictive_moments(f["x"][sub].contiguous(), 2000, f["idx"][:700], philox_seed=SEED)
+    want = f["ops"].moments(f["out"][:700, sub].contiguous())
+    assert torch.equal(mom, want)
+    st = moments_to_mean_std(mom, 700)
+    assert st["mean_mu"].min() >= 4 and st["mean_mu"].max() <= 12 and (st["std_mu"] >= 0).all()
