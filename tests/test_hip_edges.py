@@ -255,3 +255,36 @@ def test_quantiles_match_numpy(R, ops):
     assert np.abs(got[..., 0] - np.median(s, axis=0)).max() <= 2.4e-7 * 4
     with pytest.raises(Exception):
         ops.quantiles(torch.zeros((16385, 1, 2), device="cuda"))
+
+
+@pytest.mark.parametrize("kind", ("zeros", "huge", "tiny", "constant_rows", "alternating"))
+def test_degenerate_inputs_match_oracle(kind, ops, orc, swag_states):
+    """Zero variance over time, saturated clamps, denormal-scale inputs: still bit-identical to the pinned oracle."""
+    B = 18
+    rng = np.random.default_rng(3)
+    x = synth(B, 100, 12)
+    if kind == "zeros":
+        x[:] = 0
+    elif kind == "huge":
+        x *= 3e4
+    elif kind == "tiny":
+        x *= 1e-30
+    elif kind == "constant_rows":
+        x[:] = x[:, :1]
+    elif kind == "alternating":
+        x[:, ::2] += 5.0
+    wa, w2, pd = state(swag_states)
+    J = 2
+    z1 = rng.standard_normal((J, 7583), dtype=np.float32); z2 = rng.standard_normal((J, 30), dtype=np.float32)
+    eps = rng.standard_normal((J, B, 2, 20), dtype=np.float32)
+    idx = np.zeros(J, np.int32)
+    out, pre, summ = ops.multiswag(dev(x), dev(wa), dev(w2), dev(pd), torch.as_tensor(idx), dev(z1), dev(z2), dev(eps), debug=True)
+    plan = ops.get_plan()
+    sc = sched(ops, orc, plan)
+    for j in range(J):
+        w = orc.swag_draw(wa[0], w2[0], pd[0], z1[j], z2[j])
+        o, ex = orc.forward(x, w, eps[j, :, 0], eps[j, :, 1], sched=sc, extras=True)
+        assert np.array_equal(summ.cpu().numpy()[j], ex["summary"])
+        assert np.array_equal(pre.cpu().numpy()[j], ex["pre_clamp"])
+        assert np.abs(out.cpu().numpy()[j] - o).max() <= 2e-6
+    assert torch.isfinite(out).all()
