@@ -9,7 +9,7 @@
 // registers: a layer's accumulator registers are the next layer's B operands as they stand.
 // A wave owns 16 systems at a time: lane l = system l>>2, timestep phase l&3; tile `it` = timesteps 4it..4it+3.
 // Accumulation order per output = bias, then inputs in ascending order: the oracle's natural order.
-// Built for the v50 column mask (31 live columns), quiet forward.  Everything after the time pool (sampled
+// KIN = 31: the v50 column mask (31 live columns); KIN = 41: any mask (whole rows, zero weights).  Quiet forward.  Everything after the time pool (sampled
 // moments, regress_nn on the 16x16x4 path, soft_clamp) is shared with the first kernel.
 // ------------------------------------------------------------------------------------------------
 DEVINL f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
@@ -19,27 +19,38 @@ DEVINL float quad_perm(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
 
-DEVINL void load_row31(const float* __restrict__ rp, float (&xv)[NLIVE4]) {
-    xv[0] = rp[0];
+template <int KIN>
+DEVINL void load_row(const float* __restrict__ rp, float (&xv)[KIN]) {
+    if constexpr (KIN == 31) {  // v50 mask: columns 0, 8..37
+        xv[0] = rp[0];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
-        f32x4 v = *reinterpret_cast<const f32x4u*>(rp + 8 + 4 * q);
-        xv[1 + 4 * q] = v.x; xv[2 + 4 * q] = v.y; xv[3 + 4 * q] = v.z; xv[4 + 4 * q] = v.w;
+        for (int q = 0; q < 7; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4u*>(rp + 8 + 4 * q);
+            xv[1 + 4 * q] = v.x; xv[2 + 4 * q] = v.y; xv[3 + 4 * q] = v.z; xv[4 + 4 * q] = v.w;
+        }
+        f32x2 t = *reinterpret_cast<const f32x2u*>(rp + 36);
+        xv[29] = t.x; xv[30] = t.y;
+    } else {  // any mask: the whole row
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4u*>(rp + 4 * q);
+            xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
+        }
+        xv[40] = rp[40];
     }
-    f32x2 t = *reinterpret_cast<const f32x2u*>(rp + 36);
-    xv[29] = t.x; xv[30] = t.y;
 }
 
 constexpr int SCR4 = 2 * 16 * S2;  // floats of LDS scratch per wave: Philox normals + summaries of 16 systems
 
-template <bool FUSED>
+template <int KIN, bool FUSED>
 __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams p) {
+    using LY = W4<KIN>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot, later ...
     float* f2frag = lds;               // ... [NF2][64] regress_nn operands in fragment order
     float* zsh = lds + FLAT_LDS;       // [MAXK]
-    float* wl = zsh + MAXK;            // [W4_PAD] feature_nn image for the 4x4x1 operands
-    float* scr = wl + W4_PAD;          // [4][SCR4]
+    float* wl = zsh + MAXK;            // [LY::PAD] feature_nn images for the 4x4x1 operands
+    float* scr = wl + LY::PAD;          // [4][SCR4]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
     }
     if (tid == 0) flat[ZERO_IDX] = 0.0f;
     __syncthreads();
-    for (int i = tid; i < W4_PAD; i += 256) wl[i] = flat[p.tab_f4[i]];
+    for (int i = tid; i < LY::PAD; i += 256) wl[i] = flat[p.tab_f4[i]];
     {
         constexpr int PER = (NF2 + 3) / 4;
         float tmp[PER];
@@ -105,15 +116,15 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
     const float nm1 = (float)(T - 1), nT = (float)T;
     const float half_n0 = (float)ntiles * 0.5f;
     const int64_t rowstride = (int64_t)T * F;
-    const f32x4* wqA1 = reinterpret_cast<const f32x4*>(wl + W4_L1A) + ph;
-    const f32x4* wqB1 = reinterpret_cast<const f32x4*>(wl + W4_L1B) + ph;
-    const f32x4* wqA2 = reinterpret_cast<const f32x4*>(wl + W4_L2A) + ph;
-    const f32x4* wqB2 = reinterpret_cast<const f32x4*>(wl + W4_L2B) + ph;
-    const f32x4* wqA3 = reinterpret_cast<const f32x4*>(wl + W4_L3A) + ph;
-    const f32x4* wqB3 = reinterpret_cast<const f32x4*>(wl + W4_L3B) + ph;
-    const f32x4* bq1 = reinterpret_cast<const f32x4*>(wl + W4_B1);
-    const f32x4* bq2 = reinterpret_cast<const f32x4*>(wl + W4_B2);
-    const f32x4* bq3 = reinterpret_cast<const f32x4*>(wl + W4_B3);
+    const f32x4* wqA1 = reinterpret_cast<const f32x4*>(wl + LY::L1A) + ph;
+    const f32x4* wqB1 = reinterpret_cast<const f32x4*>(wl + LY::L1B) + ph;
+    const f32x4* wqA2 = reinterpret_cast<const f32x4*>(wl + LY::L2A) + ph;
+    const f32x4* wqB2 = reinterpret_cast<const f32x4*>(wl + LY::L2B) + ph;
+    const f32x4* wqA3 = reinterpret_cast<const f32x4*>(wl + LY::L3A) + ph;
+    const f32x4* wqB3 = reinterpret_cast<const f32x4*>(wl + LY::L3B) + ph;
+    const f32x4* bq1 = reinterpret_cast<const f32x4*>(wl + LY::B1);
+    const f32x4* bq2 = reinterpret_cast<const f32x4*>(wl + LY::B2);
+    const f32x4* bq3 = reinterpret_cast<const f32x4*>(wl + LY::B3);
     float* epsscr = scr + wave * SCR4;
     float* sumscr = epsscr + 16 * S2;
 
@@ -127,8 +138,8 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
 #pragma unroll
         for (int n = 0; n < 5; ++n) { mean[n] = (f32x4){0, 0, 0, 0}; m2[n] = (f32x4){0, 0, 0, 0}; }
 
-        float xv[NLIVE4];
-        load_row31(rowp, xv);
+        float xv[KIN];
+        load_row<KIN>(rowp, xv);
         asm volatile("" ::: "memory");
         STAMP(1);  // batch setup + first row load issue
         for (int it = 0; it < ntiles; ++it) {
@@ -138,14 +149,14 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
             // feature_nn.0 + ReLU: pairs of input columns (k0, k1): reads A(k0,m0) A(k0,m1) A(k1,m0) A(k1,m1) B(pair)
             f32x4 h[10];
             {
-                constexpr int NP = (NLIVE4 + 1) / 2;  // 16 pairs, the last one holds only k = 30
+                constexpr int NP = LY::NP1;  // column pairs; the last one holds a single column (KIN is odd)
                 f32x4 q[NP][5];
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h[n] = bq1[n];
                 auto rd = [&](int kp) {
                     const int k0 = 2 * kp, k1 = 2 * kp + 1;
                     q[kp][0] = wqA1[(k0 * 2 + 0) * 4]; q[kp][1] = wqA1[(k0 * 2 + 1) * 4];
-                    if (k1 < NLIVE4) { q[kp][2] = wqA1[(k1 * 2 + 0) * 4]; q[kp][3] = wqA1[(k1 * 2 + 1) * 4]; }
+                    if (k1 < KIN) { q[kp][2] = wqA1[(k1 * 2 + 0) * 4]; q[kp][3] = wqA1[(k1 * 2 + 1) * 4]; }
                     q[kp][4] = wqB1[kp * 4];
                 };
                 rd(0);
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
                     h[0] = mfma4(q[kp][0].x, b0, h[0]); h[1] = mfma4(q[kp][0].y, b0, h[1]); h[2] = mfma4(q[kp][0].z, b0, h[2]); h[3] = mfma4(q[kp][0].w, b0, h[3]);
                     h[4] = mfma4(q[kp][1].x, b0, h[4]); h[5] = mfma4(q[kp][1].y, b0, h[5]); h[6] = mfma4(q[kp][1].z, b0, h[6]); h[7] = mfma4(q[kp][1].w, b0, h[7]);
                     h[8] = mfma4(q[kp][4].x, b0, h[8]); h[9] = mfma4(q[kp][4].y, b0, h[9]);
-                    if (k1 < NLIVE4) {
+                    if (k1 < KIN) {
                         const float b1v = xv[k1];
                         h[0] = mfma4(q[kp][2].x, b1v, h[0]); h[1] = mfma4(q[kp][2].y, b1v, h[1]); h[2] = mfma4(q[kp][2].z, b1v, h[2]); h[3] = mfma4(q[kp][2].w, b1v, h[3]);
                         h[4] = mfma4(q[kp][3].x, b1v, h[4]); h[5] = mfma4(q[kp][3].y, b1v, h[5]); h[6] = mfma4(q[kp][3].z, b1v, h[6]); h[7] = mfma4(q[kp][3].w, b1v, h[7]);
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
 #if !(BNN_EXP & 2)  // timing experiment 2: no further x loads
             {
                 const int itn = (it + 1 < ntiles) ? it + 1 : it;
-                load_row31(rowp + (int64_t)itn * 4 * F, xv);
+                load_row<KIN>(rowp + (int64_t)itn * 4 * F, xv);
                 asm volatile("" ::: "memory");
             }
 #endif

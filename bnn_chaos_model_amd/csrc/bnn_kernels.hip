@@ -289,7 +289,7 @@ int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
             return fail(BNN_ERR_HIP, "plan table upload failed");
         }
     }
-    if (!pl->tab[0].f4.empty()) {
+    if (!pl->tab[0].f4.empty()) {  // always, since the 41-input form of the 4x4x1 engine serves every mask
         size_t n4 = pl->tab[0].f4.size() * sizeof(int16_t);
         if (hipMalloc(&pl->d_f4, n4) != hipSuccess || hipMemcpy(pl->d_f4, pl->tab[0].f4.data(), n4, hipMemcpyHostToDevice) != hipSuccess) {
             bnn_plan_destroy(pl);
@@ -403,18 +403,22 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
         });                                                                                                        \
         hipLaunchKernelGGL((bnn_multiswag_kernel<NK, NZ, FU>), grid, block, shmem, st, p);                         \
     } while (0)
-    if (!noisy && nk1 == 8 && pl->use_v4) {
-        const size_t shmem4 = sizeof(float) * (FLAT_LDS + MAXK + W4_PAD + 4 * SCR4);
-#define LAUNCH4(FU)                                                                                                \
+    if (!noisy && pl->use_v4) {
+#define LAUNCH4(KI, FU)                                                                                            \
     do {                                                                                                           \
         static std::once_flag once;                                                                                \
         std::call_once(once, [] {                                                                                  \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag4_kernel<FU>),                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag4_kernel<KI, FU>),               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
         });                                                                                                        \
-        hipLaunchKernelGGL((bnn_multiswag4_kernel<FU>), grid, block, shmem4, st, p);                               \
+        const size_t shmem4 = sizeof(float) * (FLAT_LDS + MAXK + W4<KI>::PAD + 4 * SCR4);                          \
+        hipLaunchKernelGGL((bnn_multiswag4_kernel<KI, FU>), grid, block, shmem4, st, p);                           \
     } while (0)
-        if (fused) LAUNCH4(true); else LAUNCH4(false);
+        if (pl->tab[0].kin4 == 31) {
+            if (fused) LAUNCH4(31, true); else LAUNCH4(31, false);
+        } else {
+            if (fused) LAUNCH4(41, true); else LAUNCH4(41, false);
+        }
 #undef LAUNCH4
     } else if (noisy) {
         LAUNCH(11, true, false);

@@ -105,19 +105,24 @@ BNN_HD inline int kmap_input(int nk1, int s, int g) {
 //   image B of a 40-wide layer: [k/2][i][2*(k&1) + j] -> groups 8, 9 (j = 0, 1) for two consecutive k
 //   image B of the latent layer: [k/4][i][k&3]         -> group 4 for four consecutive k
 // biases sit behind them as [n][r] and enter as the C operand of the first MFMA of a chain.
-constexpr int NLIVE4 = 31;                 // live columns of the v50 mask, in ascending order: 0, 8..37
-BNN_HD inline int col4(int k) { return k == 0 ? 0 : 7 + k; }
-constexpr int W4_L1A = 0;                        // [31][2][4][4]
-constexpr int W4_L1B = W4_L1A + NLIVE4 * 32;     // [16][4][4]
-constexpr int W4_L2A = W4_L1B + 16 * 16;         // [40][2][4][4]
-constexpr int W4_L2B = W4_L2A + H * 32;          // [20][4][4]
-constexpr int W4_L3A = W4_L2B + 20 * 16;         // [40][4][4]
-constexpr int W4_L3B = W4_L3A + H * 16;          // [10][4][4]
-constexpr int W4_B1 = W4_L3B + 10 * 16;          // [10][4]
-constexpr int W4_B2 = W4_B1 + H;                 // [10][4]
-constexpr int W4_B3 = W4_B2 + H;                 // [5][4]
-constexpr int W4_N = W4_B3 + L;                  // 3748
-constexpr int W4_PAD = 3760;
+// KIN = number of layer-1 inputs the kernel multiplies: 31 for the v50 mask (live columns 0, 8..37, ascending), else all 41
+// columns (weights of masked columns are zero in the image).
+BNN_HD inline int col4(int kin, int k) { return kin == F ? k : (k == 0 ? 0 : 7 + k); }
+template <int KIN>
+struct W4 {
+    static constexpr int NP1 = (KIN + 1) / 2;        // layer-1 column pairs (the last may hold one column)
+    static constexpr int L1A = 0;                    // [KIN][2][4][4]
+    static constexpr int L1B = L1A + KIN * 32;       // [NP1][4][4]
+    static constexpr int L2A = L1B + NP1 * 16;       // [40][2][4][4]
+    static constexpr int L2B = L2A + H * 32;         // [20][4][4]
+    static constexpr int L3A = L2B + 20 * 16;        // [40][4][4]
+    static constexpr int L3B = L3A + H * 16;         // [10][4][4]
+    static constexpr int B1 = L3B + 10 * 16;         // [10][4]
+    static constexpr int B2 = B1 + H;                // [10][4]
+    static constexpr int B3 = B2 + H;                // [5][4]
+    static constexpr int N = B3 + L;
+    static constexpr int PAD = (N + 15) / 16 * 16;   // 3760 (KIN = 31) / 4160 (KIN = 41)
+};
 
 // fragment table indices (see bnn_tables.cpp)
 BNN_HD inline int nf1(int nk1) { return 3 * nk1 + 30 + 20 + 12 + 8; }

@@ -106,33 +106,42 @@ Tables build_tables(uint64_t zero_mask, bool all_columns) {
             return n < 0 ? ZERO_IDX : OFF_B6 + n;
         });
 
-    // 4x4x1 images (only the v50 mask has the 31-column load pattern built into the kernel)
-    if (v50) {
-        T.f4.assign(W4_PAD, (int16_t)ZERO_IDX);
-        auto w = [&](int off_w, int ld, int n_out, int neuron, int col) { return (int16_t)(neuron < n_out ? off_w + neuron * ld + col : ZERO_IDX); };
-        auto imgA = [&](int base, int K, int M, int off_w, int ld, int n_out, bool input_cols) {
-            for (int k = 0; k < K; ++k)
-                for (int m = 0; m < M; ++m)
+    // 4x4x1 images: 31 live columns for the v50 mask, else all 41 with zero weights on the masked ones
+    T.kin4 = v50 ? 31 : F;
+    if (!all_columns) {
+        auto build4 = [&](auto lay) {
+            using LY = decltype(lay);
+            const int kin = T.kin4;
+            T.f4.assign(LY::PAD, (int16_t)ZERO_IDX);
+            auto w = [&](int off_w, int ld, int n_out, int neuron, int col, bool input) {
+                if (neuron >= n_out || (input && dropped(col))) return (int16_t)ZERO_IDX;
+                return (int16_t)(off_w + neuron * ld + col);
+            };
+            auto imgA = [&](int base, int K, int M, int off_w, int ld, int n_out, bool input) {
+                for (int k = 0; k < K; ++k)
+                    for (int m = 0; m < M; ++m)
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j)
+                                T.f4[base + ((k * M + m) * 4 + i) * 4 + j] = w(off_w, ld, n_out, 4 * (4 * m + j) + i, input ? col4(kin, k) : k, input);
+            };
+            auto imgB40 = [&](int base, int K, int off_w, int ld, bool input) {  // groups 8, 9, two k per read
+                for (int k = 0; k < K; ++k)
                     for (int i = 0; i < 4; ++i)
-                        for (int j = 0; j < 4; ++j)
-                            T.f4[base + ((k * M + m) * 4 + i) * 4 + j] = w(off_w, ld, n_out, 4 * (4 * m + j) + i, input_cols ? col4(k) : k);
+                        for (int j = 0; j < 2; ++j)
+                            T.f4[base + ((k >> 1) * 4 + i) * 4 + 2 * (k & 1) + j] = w(off_w, ld, H, 4 * (8 + j) + i, input ? col4(kin, k) : k, input);
+            };
+            imgA(LY::L1A, kin, 2, OFF_W1, F, H, true);
+            imgB40(LY::L1B, kin, OFF_W1, F, true);
+            imgA(LY::L2A, H, 2, OFF_W2, H, H, false);
+            imgB40(LY::L2B, H, OFF_W2, H, false);
+            imgA(LY::L3A, H, 1, OFF_W3, H, L, false);
+            for (int k = 0; k < H; ++k)  // group 4 of the latent layer, four k per read
+                for (int i = 0; i < 4; ++i) T.f4[LY::L3B + ((k >> 2) * 4 + i) * 4 + (k & 3)] = w(OFF_W3, H, L, 16 + i, k, false);
+            for (int n = 0; n < H; ++n) T.f4[LY::B1 + n] = (int16_t)(OFF_B1 + n);
+            for (int n = 0; n < H; ++n) T.f4[LY::B2 + n] = (int16_t)(OFF_B2 + n);
+            for (int n = 0; n < L; ++n) T.f4[LY::B3 + n] = (int16_t)(OFF_B3 + n);
         };
-        auto imgB40 = [&](int base, int K, int off_w, int ld, bool input_cols) {  // groups 8, 9, two k per read
-            for (int k = 0; k < K; ++k)
-                for (int i = 0; i < 4; ++i)
-                    for (int j = 0; j < 2; ++j)
-                        T.f4[base + ((k >> 1) * 4 + i) * 4 + 2 * (k & 1) + j] = w(off_w, ld, H, 4 * (8 + j) + i, input_cols ? col4(k) : k);
-        };
-        imgA(W4_L1A, NLIVE4, 2, OFF_W1, F, H, true);
-        imgB40(W4_L1B, NLIVE4, OFF_W1, F, true);
-        imgA(W4_L2A, H, 2, OFF_W2, H, H, false);
-        imgB40(W4_L2B, H, OFF_W2, H, false);
-        imgA(W4_L3A, H, 1, OFF_W3, H, L, false);
-        for (int k = 0; k < H; ++k)  // group 4 of the latent layer, four k per read
-            for (int i = 0; i < 4; ++i) T.f4[W4_L3B + ((k >> 2) * 4 + i) * 4 + (k & 3)] = w(OFF_W3, H, L, 16 + i, k);
-        for (int n = 0; n < H; ++n) T.f4[W4_B1 + n] = (int16_t)(OFF_B1 + n);
-        for (int n = 0; n < H; ++n) T.f4[W4_B2 + n] = (int16_t)(OFF_B2 + n);
-        for (int n = 0; n < L; ++n) T.f4[W4_B3 + n] = (int16_t)(OFF_B3 + n);
+        if (v50) build4(W4<31>{}); else build4(W4<F>{});
     }
 
     // accumulation order = k-step major, lane group (the MFMA's k index) minor
