@@ -1,0 +1,32 @@
+"""BASELINE.json configs[4] asks for a bf16-vs-fp32 tolerance sweep.  No bf16 kernel is built (the metric is fp32); this
+CPU test measures, with the pinned oracle, what rounding the inputs and/or the weights to bf16 (fp32 accumulation) does to
+the outputs, so the number is on record before a reduced-precision engine is considered."""
+import numpy as np
+
+from conftest import load_golden, tape
+from oracle import oracle as orc
+
+
+def to_bf16(a):
+    """Round-to-nearest-even to bfloat16, returned as float32."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def test_bf16_rounding_error_budget(inputs, capsys):
+    z = load_golden("case_swagfast_v50_0_slow.npz")
+    tp = tape(z)
+    x, w = inputs["slow"], z["w"]
+    e1, e2 = tp[2][1], tp[3][1]
+    ref = orc.forward(x, w, e1, e2).astype(np.float64)
+    rows = []
+    for name, xx, ww in (("x bf16", to_bf16(x), w), ("w bf16", x, to_bf16(w)), ("x and w bf16", to_bf16(x), to_bf16(w))):
+        out = orc.forward(xx, ww, e1, e2).astype(np.float64)
+        err = np.abs(out - ref)
+        rows.append((name, err[:, 0].max(), err[:, 1].max(), np.median(err[:, 0])))
+    with capsys.disabled():
+        for name, emu, esd, med in rows:
+            print(f"\n  bf16 sweep [{name:13s}] max |d mu| = {emu:.3e}   max |d std| = {esd:.3e}   median |d mu| = {med:.3e}", end="")
+    # three to four orders of magnitude above the 1e-5 parity bar: a bf16-input engine cannot be the headline path
+    assert rows[2][1] > 1e-3 and rows[2][1] < 2.0
