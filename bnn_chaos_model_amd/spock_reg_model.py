@@ -183,7 +183,8 @@ class VarModel:
 
     def to(self, device):
         self._device = torch.device(device)
-        self._w = self._w.to(self._device)
+        if self._pending_draw is None:  # a pending in-kernel draw stays pending: it lands on the new device when asked for
+            self._w_store = self._w_store.to(self._device)
         return self
 
     def cpu(self):
