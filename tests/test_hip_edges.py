@@ -288,3 +288,30 @@ def test_degenerate_inputs_match_oracle(kind, ops, orc, swag_states):
         assert np.array_equal(pre.cpu().numpy()[j], ex["pre_clamp"])
         assert np.abs(out.cpu().numpy()[j] - o).max() <= 2e-6
     assert torch.isfinite(out).all()
+
+
+def test_hip_graph_capture_and_replay(ops, swag_states):
+    """The ops only enqueue work on the current stream (no allocation, no sync once buffers exist): the two-launch
+    multiswag call can be captured in a HIP graph and replayed."""
+    wa, w2, pd = (dev(a) for a in state(swag_states))
+    x = dev(synth(700, 100, 21))
+    idx = torch.zeros(40, dtype=torch.int32, device="cuda")
+    out = torch.empty((40, 700, 2), device="cuda")
+    ref_o = ops.multiswag(x, wa, w2, pd, idx, philox_seed=9, single_launch=False).clone()   # also warms plan + workspace
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.multiswag(x, wa, w2, pd, idx, philox_seed=9, single_launch=False, out=out)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        ops.multiswag(x, wa, w2, pd, idx, philox_seed=9, single_launch=False, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_o)
+    x.mul_(1.01)  # new inputs in the same buffers, same graph
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ops.multiswag(x, wa, w2, pd, idx, philox_seed=9, single_launch=False))
