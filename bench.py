@@ -128,7 +128,18 @@ def main():
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+                probe = torch.zeros(1, dtype=torch.float64, device=dev)
+                dist.all_reduce(probe)                            # fail here, not inside the timed region
+                torch.cuda.synchronize()
+            except Exception as e:  # the one exchange of the path is 160 KB per rank: gloo via host memory still measures the job
+                print(f"[bench] RCCL unavailable ({type(e).__name__}: {e}); falling back to gloo for the moments gather", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                dist.init_process_group("gloo")
 
     wl = dict(WORKLOADS[args.workload])
     if args.systems:
@@ -202,7 +213,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "systems_per_gpu": B, "seeds": S, "mc_samples": M, "draws": J, "timesteps": 100,
                        "features": 41, "noise": "in-kernel Philox4x32-10", "kernel": "ops.swag_draw + ops.forward" if args.unfused else ("multiswag, in-kernel draw per workgroup" if args.single_launch else "multiswag, draw-once workspace + forward"),
-                       "sharding": f"systems over {world} rank(s), all-gather of moments"},
+                       "sharding": f"systems over {world} rank(s), all-gather of moments",
+                       "collective": (dist.get_backend() if world > 1 else "none")},
             "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel_ms": kern_ms, "flop_per_eval": ALG_FLOP_PER_EVAL,
