@@ -9,7 +9,7 @@
 // registers: a layer's accumulator registers are the next layer's B operands as they stand.
 // A wave owns 16 systems at a time: lane l = system l>>2, timestep phase l&3; tile `it` = timesteps 4it..4it+3.
 // Accumulation order per output = bias, then inputs in ascending order: the oracle's natural order.
-// KIN = 31: the v50 column mask (31 live columns); KIN = 41: any mask (whole rows, zero weights).  Quiet forward.  Everything after the time pool (sampled
+// KIN = 31: the v50 column mask (31 live columns); KIN = 41: any mask (whole rows, zero weights); NOISY: forward(noisy_val=True).  Everything after the time pool (sampled
 // moments, regress_nn on the 16x16x4 path, soft_clamp) is shared with the first kernel.
 // ------------------------------------------------------------------------------------------------
 DEVINL f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
@@ -42,15 +42,19 @@ DEVINL void load_row(const float* __restrict__ rp, float (&xv)[KIN]) {
 
 constexpr int SCR4 = 2 * 16 * S2;  // floats of LDS scratch per wave: Philox normals + summaries of 16 systems
 
-template <int KIN, bool FUSED>
+constexpr int NSC4 = 96;  // LDS floats for the noise scales of the noisy forward: exp(logvar/2) for 41 inputs + 40 summaries
+
+template <int KIN, bool FUSED, bool NOISY = false>
 __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams p) {
     using LY = W4<KIN>;
+    static_assert(!NOISY || (KIN == F && !FUSED), "the noisy forward multiplies all 41 columns and takes materialised weights");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot, later ...
     float* f2frag = lds;               // ... [NF2][64] regress_nn operands in fragment order
     float* zsh = lds + FLAT_LDS;       // [MAXK]
     float* wl = zsh + MAXK;            // [LY::PAD] feature_nn images for the 4x4x1 operands
     float* scr = wl + LY::PAD;          // [4][SCR4]
+    float* nsc = scr + 4 * SCR4;       // [NSC4] (NOISY only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,6 +98,9 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
     if (tid == 0) flat[ZERO_IDX] = 0.0f;
     __syncthreads();
     for (int i = tid; i < LY::PAD; i += 256) wl[i] = flat[p.tab_f4[i]];
+    if constexpr (NOISY) {  // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
+        if (tid < F + S2) nsc[tid] = expf(flat[OFF_INLV + tid] / 2.0f);
+    }
     {
         constexpr int PER = (NF2 + 3) / 4;
         float tmp[PER];
@@ -143,6 +150,30 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
         asm volatile("" ::: "memory");
         STAMP(1);  // batch setup + first row load issue
         for (int it = 0; it < ntiles; ++it) {
+            if constexpr (NOISY) {
+                // masks, then add_input_noise (:486-504): masked columns become pure noise.  This lane's row is timestep
+                // 4*it + ph of system sysc; its 41 normals are Philox quads t*11 + 0..10 (or the explicit tensor's row).
+                const int t = 4 * it + ph;
+                const float* er = p.eps_in ? p.eps_in + (r * p.B + sysc) * rowstride + (int64_t)t * F : nullptr;
+#pragma unroll
+                for (int q = 0; q < 11; ++q) {
+                    f32x4 n4;
+                    if (er) {
+                        if (q < 10) n4 = *reinterpret_cast<const f32x4u*>(er + 4 * q);
+                        else n4 = (f32x4){er[40], 0.0f, 0.0f, 0.0f};
+                    } else {
+                        n4 = philox_sys4(TAG_IN, p.row_id0 + r, p.sys_id0 + sysc, t * 11 + q, p.seed);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = 4 * q + j;
+                        if (col < F) {
+                            const float xm = ((p.zero_mask >> col) & 1ull) ? 0.0f : xv[col];
+                            xv[col] = xm + n4[j] * nsc[col];
+                        }
+                    }
+                }
+            }
             // A operands are read one group of 20 MFMAs ahead of their use and the order is pinned with
             // sched_group_barrier (5 LDS reads, then 20 MFMAs): left alone, the scheduler issues each read one or two
             // MFMAs before its use and the LDS latency lands on the matrix pipe.
@@ -357,6 +388,25 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
         float skeep[10];
 #pragma unroll
         for (int ks = 0; ks < 10; ++ks) skeep[ks] = sumscr[c * S2 + kmap_summary(ks, g)];
+        if constexpr (NOISY) {  // add_summary_noise (:448-450)
+            const int64_t sc = validb ? sysb : b1 - 1;
+            if (p.eps_sum) {
+                const float* es = p.eps_sum + (r * p.B + sc) * S2;
+#pragma unroll
+                for (int ks = 0; ks < 10; ++ks) skeep[ks] = skeep[ks] + es[kmap_summary(ks, g)] * nsc[F + kmap_summary(ks, g)];
+            } else {
+                const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + sc;
+#pragma unroll
+                for (int kind = 0; kind < 2; ++kind) {
+                    f32x4 a4n = philox_sys4(TAG_SUM, grow, gsys, kind * 5 + g, p.seed);
+                    float bn = philox_sys4(TAG_SUM, grow, gsys, kind * 5 + 4, p.seed)[g];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        skeep[kind * 5 + rr] = skeep[kind * 5 + rr] + a4n[rr] * nsc[F + kmap_summary(kind * 5 + rr, g)];
+                    skeep[kind * 5 + 4] = skeep[kind * 5 + 4] + bn * nsc[F + kmap_summary(kind * 5 + 4, g)];
+                }
+            }
+        }
         const float* f2l = f2frag + lane;
         auto W2f = [&](int f) { return f2l[f * 64]; };
         f32x4 a4[3], a5[3], a6;

@@ -235,7 +235,8 @@ struct bnn_plan {
     Tables tab[2];  // [0] = arch mask, [1] = all 41 columns (noisy forward)
     int16_t* d_f1[2] = {nullptr, nullptr};
     int16_t* d_f2[2] = {nullptr, nullptr};
-    int16_t* d_f4 = nullptr;  // 4x4x1 image table (v50 mask only)
+    int16_t* d_f4 = nullptr;   // 4x4x1 image table for the plan's mask
+    int16_t* d_f4n = nullptr;  // ... with every column live (noisy forward)
     bool use_v4 = false;      // feature_nn on the 4x4x1 engine (v50 mask, quiet forward)
     float* d_rcp = nullptr;  // [RCP_N] 1/(i+1)
     int device = 0;
@@ -295,6 +296,11 @@ int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
             bnn_plan_destroy(pl);
             return fail(BNN_ERR_HIP, "plan table upload failed");
         }
+        size_t n4n = pl->tab[1].f4.size() * sizeof(int16_t);
+        if (hipMalloc(&pl->d_f4n, n4n) != hipSuccess || hipMemcpy(pl->d_f4n, pl->tab[1].f4.data(), n4n, hipMemcpyHostToDevice) != hipSuccess) {
+            bnn_plan_destroy(pl);
+            return fail(BNN_ERR_HIP, "plan table upload failed");
+        }
         const char* kv = getenv("BNN_CHAOS_KERNEL");  // "16x16" forces the first engine (A/B runs)
         pl->use_v4 = !(kv && std::string(kv) == "16x16");
     }
@@ -319,6 +325,7 @@ int bnn_plan_destroy(bnn_plan* pl) {
     }
     if (pl->d_rcp) (void)hipFree(pl->d_rcp);
     if (pl->d_f4) (void)hipFree(pl->d_f4);
+    if (pl->d_f4n) (void)hipFree(pl->d_f4n);
     delete pl;
     return 0;
 }
@@ -326,10 +333,10 @@ int bnn_plan_destroy(bnn_plan* pl) {
 int bnn_plan_layer_order(const bnn_plan* pl, int layer, int noisy, int32_t* host_order, int cap) {
     if (!pl || layer < 0 || layer > 5) return fail(BNN_ERR_INVALID, "bad plan/layer");
     std::vector<int32_t> o = pl->tab[noisy ? 1 : 0].order[layer];
-    if (!noisy && pl->use_v4 && layer < 3) {  // 4x4x1 engine: bias first, then inputs in ascending order
+    if (pl->use_v4 && layer < 3) {  // 4x4x1 engine: bias first, then inputs in ascending order
         o.clear();
         for (int k = 0; k < (layer == 0 ? F : H); ++k)
-            if (layer != 0 || !((pl->arch.zero_mask >> k) & 1ull)) o.push_back(k);
+            if (layer != 0 || noisy || !((pl->arch.zero_mask >> k) & 1ull)) o.push_back(k);
     }
     if (host_order)
         for (int i = 0; i < (int)o.size() && i < cap; ++i) host_order[i] = o[i];
@@ -403,21 +410,24 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
         });                                                                                                        \
         hipLaunchKernelGGL((bnn_multiswag_kernel<NK, NZ, FU>), grid, block, shmem, st, p);                         \
     } while (0)
-    if (!noisy && pl->use_v4) {
-#define LAUNCH4(KI, FU)                                                                                            \
+    if (pl->use_v4) {
+#define LAUNCH4(KI, FU, NZ)                                                                                        \
     do {                                                                                                           \
         static std::once_flag once;                                                                                \
         std::call_once(once, [] {                                                                                  \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag4_kernel<KI, FU>),               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag4_kernel<KI, FU, NZ>),           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
         });                                                                                                        \
-        const size_t shmem4 = sizeof(float) * (FLAT_LDS + MAXK + W4<KI>::PAD + 4 * SCR4);                          \
-        hipLaunchKernelGGL((bnn_multiswag4_kernel<KI, FU>), grid, block, shmem4, st, p);                           \
+        const size_t shmem4 = sizeof(float) * (FLAT_LDS + MAXK + W4<KI>::PAD + 4 * SCR4 + NSC4);                   \
+        hipLaunchKernelGGL((bnn_multiswag4_kernel<KI, FU, NZ>), grid, block, shmem4, st, p);                       \
     } while (0)
-        if (pl->tab[0].kin4 == 31) {
-            if (fused) LAUNCH4(31, true); else LAUNCH4(31, false);
+        if (noisy) {
+            p.tab_f4 = pl->d_f4n;  // all 41 columns live: masked inputs carry pure noise
+            LAUNCH4(41, false, true);
+        } else if (pl->tab[0].kin4 == 31) {
+            if (fused) LAUNCH4(31, true, false); else LAUNCH4(31, false, false);
         } else {
-            if (fused) LAUNCH4(41, true); else LAUNCH4(41, false);
+            if (fused) LAUNCH4(41, true, false); else LAUNCH4(41, false, false);
         }
 #undef LAUNCH4
     } else if (noisy) {

@@ -108,7 +108,7 @@ Tables build_tables(uint64_t zero_mask, bool all_columns) {
 
     // 4x4x1 images: 31 live columns for the v50 mask, else all 41 with zero weights on the masked ones
     T.kin4 = v50 ? 31 : F;
-    if (!all_columns) {
+    {
         auto build4 = [&](auto lay) {
             using LY = decltype(lay);
             const int kin = T.kin4;

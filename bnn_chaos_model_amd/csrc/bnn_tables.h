@@ -14,7 +14,7 @@ struct Tables {
     std::vector<int16_t> f1;   // nf1(nk1) * 64: feature_nn fragments + C-init biases
     std::vector<int16_t> f2;   // NF2 * 64: regress_nn fragments + C-init biases
     int kin4;                  // layer-1 inputs of the 4x4x1 kernel: 31 (v50 mask) or 41
-    std::vector<int16_t> f4;   // W4<kin4>::PAD: feature_nn images for the 4x4x1 kernel (empty for the all-columns variant)
+    std::vector<int16_t> f4;   // W4<kin4>::PAD: feature_nn images for the 4x4x1 kernel
     std::vector<int32_t> order[6];  // accumulation order per Linear layer (input index or -1 = bias)
 };
 
