@@ -61,16 +61,37 @@ def synthetic_ensemble(S, device):
     return t(wa), t(w2), t(pd)
 
 
+def host_threads():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes give a
+    16-CPU share of a 256-thread host: running 256 threads there only measures oversubscription)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(round(q / per))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(x_cpu, wa, w2, pd, budget_s=15.0):
     """The oracle (oracle/bnn_oracle.c: fp32 C restatement, OpenMP over systems) on a bounded sample of the same
     workload: same synthetic inputs, same ensemble, a few draws, sized to about `budget_s` seconds of CPU work."""
     import numpy as np
     from oracle import oracle as orc
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = host_threads()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle library is first loaded
     rng = np.random.default_rng(0)
 
     def run(Bs, Js):
@@ -90,6 +111,53 @@ def cpu_baseline(x_cpu, wa, w2, pd, budget_s=15.0):
     return {"value": Bmax * Js / t, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": f"{Bmax} systems x {Js} draws = {Bmax * Js} evals in {t:.1f} s; same synthetic inputs and ensemble; "
                       f"oracle/bnn_oracle.c (fp32, fmaf chains), OpenMP threads = {cores}"}
+
+
+def torch_cpu_baseline(x_cpu, wa, w2, pd, budget_s=8.0):
+    """The reference's own op sequence (spock_reg_model.py:815-838 elementwise, :884-907) written with torch CPU ops --
+    i.e. what the reference's PyTorch-CPU path costs on this host.  Not the oracle, not
+    the reference's code: a few lines of eager torch, all host threads."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as Fn
+    cores = host_threads()
+    torch.set_num_threads(cores)
+    x = torch.as_tensor(x_cpu)
+    wa_t, w2_t, pd_t = (torch.as_tensor(a) for a in (wa, w2, pd))
+    dead = [1, 2, 3, 4, 5, 6, 7, 38, 39, 40]
+    K = pd_t.shape[2]
+
+    def one_draw(s):
+        with torch.no_grad():
+            a, a2, D = wa_t[s], w2_t[s], pd_t[s] - wa_t[s][:, None]
+            w = a + 0.5 / np.sqrt(2.0) * torch.randn(a.shape) * torch.sqrt(torch.abs(a2 - a ** 2))
+            w = w + 0.5 * (D @ torch.randn(K, 1))[:, 0] / np.sqrt(2 * (K - 1))
+            o = 81
+            def lin(h, n_out, n_in):
+                nonlocal o
+                W = w[o:o + n_out * n_in].reshape(n_out, n_in); o += n_out * n_in
+                b = w[o:o + n_out]; o += n_out
+                return Fn.linear(h, W, b)
+            xm = x.clone(); xm[..., dead] = 0
+            h = lin(torch.relu(lin(torch.relu(lin(xm, 40, 41)), 40, 40)), 20, 40)
+            mu_, var_ = h.mean(1), h.std(1) ** 2
+            n = h.shape[1]
+            m = torch.randn_like(mu_) * torch.sqrt(var_ / n) + mu_
+            v = torch.randn_like(var_) * torch.sqrt(2 * var_ ** 2 / (n - 1)) + var_
+            sstat = torch.cat((m, torch.sqrt(torch.abs(v) + 1e-5)), 1)
+            r = lin(torch.relu(lin(torch.relu(lin(sstat, 40, 40)), 40, 40)), 2, 40)
+            return torch.cat((0.5 * (torch.tanh(r[:, [0]]) + 1) * 8 + 4, 0.5 * (torch.tanh(r[:, [1]]) + 1) * 5.5 + 0.5), 1)
+
+    one_draw(0)
+    t0 = time.perf_counter(); one_draw(1); t1 = time.perf_counter() - t0
+    Js = max(2, int(min(200, budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    for j in range(Js):
+        one_draw(j % wa_t.shape[0])
+    t = time.perf_counter() - t0
+    B = x.shape[0]
+    return {"value": B * Js / t, "unit": "evals/s", "cores": cores, "kind": "port (eager torch CPU ops in the reference's order)",
+            "sample": f"{B} systems x {Js} draws in {t:.1f} s, torch {torch.__version__}, {cores} threads"}
 
 
 def main():
@@ -225,6 +293,10 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(x.cpu().numpy(), wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
             except Exception as e:  # the oracle is a checker, never a dependency of the measured path
                 res["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+            try:
+                res["cpu_baseline_torch"] = torch_cpu_baseline(x.cpu().numpy(), wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
+            except Exception as e:
+                res["cpu_baseline_torch"] = {"value": None, "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
