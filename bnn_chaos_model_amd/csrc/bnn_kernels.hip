@@ -38,17 +38,29 @@ using namespace bnn;
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void bnn_moments_kernel(const float* __restrict__ samples, int64_t R, int64_t B, double* __restrict__ mom, int accumulate) {
-    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// Predictive moments: 64 systems x 16 draw-lanes per workgroup; lane (b, rr) sums draws rr, rr+16, ... in order, the 16
+// partials are then added in a fixed tree, so the result is deterministic (but not the strictly sequential sum).
+__global__ __launch_bounds__(1024) void bnn_moments_kernel(const float* __restrict__ samples, int64_t R, int64_t B, double* __restrict__ mom,
+                                                          int accumulate) {
+    __shared__ double part[16][64][4];
+    const int l = threadIdx.x, rr = threadIdx.y;
+    const int64_t b = (int64_t)blockIdx.x * 64 + l;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (accumulate) { s0 = mom[b * 4]; s1 = mom[b * 4 + 1]; s2 = mom[b * 4 + 2]; s3 = mom[b * 4 + 3]; }
-    for (int64_t r = 0; r < R; ++r) {
-        f32x2 v = *reinterpret_cast<const f32x2*>(samples + (r * B + b) * 2);
-        double mu = v.x, sd = v.y;
-        s0 += mu; s1 += mu * mu; s2 += sd; s3 += sd * sd;
+    if (b < B)
+        for (int64_t r = rr; r < R; r += 16) {
+            f32x2 v = *reinterpret_cast<const f32x2*>(samples + (r * B + b) * 2);
+            double mu = v.x, sd = v.y;
+            s0 += mu; s1 += mu * mu; s2 += sd; s3 += sd * sd;
+        }
+    part[rr][l][0] = s0; part[rr][l][1] = s1; part[rr][l][2] = s2; part[rr][l][3] = s3;
+    __syncthreads();
+    for (int h = 8; h > 0; h >>= 1) {
+        if (rr < h)
+            for (int k = 0; k < 4; ++k) part[rr][l][k] += part[rr + h][l][k];
+        __syncthreads();
     }
-    mom[b * 4] = s0; mom[b * 4 + 1] = s1; mom[b * 4 + 2] = s2; mom[b * 4 + 3] = s3;
+    if (rr == 0 && b < B)
+        for (int k = 0; k < 4; ++k) mom[b * 4 + k] = (accumulate ? mom[b * 4 + k] : 0.0) + part[0][l][k];
 }
 
 // Per-system percentiles over the draws: one workgroup bitonic-sorts one (system, channel) column of R values in LDS.
@@ -583,7 +595,7 @@ int bnn_feature_pack_f64(const double* tseries, const double* mass, const double
 int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments, int32_t accumulate, void* stream) {
     if (!samples || !moments || R < 0 || B < 0) return fail(BNN_ERR_INVALID, "bad argument");
     if (B == 0) return 0;
-    hipLaunchKernelGGL(bnn_moments_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, samples, R, B, moments,
+    hipLaunchKernelGGL(bnn_moments_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64, 16), 0, (hipStream_t)stream, samples, R, B, moments,
                        accumulate);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -138,7 +138,7 @@ int bnn_feature_pack_f64(const double* tseries, const double* mass, const double
                          const double* mean, const double* scale, double* X64_out, float* x32_out, void* stream);
 
 /* Predictive moments over draws: samples [R,B,2] -> moments [B,4] (float64):
- * sum mu, sum mu^2, sum std, sum std^2 over r, in r order (deterministic).  accumulate != 0 adds to
+ * sum mu, sum mu^2, sum std, sum std^2 over r (float64; a fixed 16-way partition of r, so deterministic).  accumulate != 0 adds to
  * the existing contents (for processing draws in slabs). */
 int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments, int32_t accumulate, void* stream);
 

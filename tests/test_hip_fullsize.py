@@ -110,6 +110,6 @@ def test_multiswag_sharded_driver_single_rank(full):
     sub = slice(0, 2000)
     mom = drv.predictive_moments(f["x"][sub].contiguous(), 2000, f["idx"][:700], philox_seed=SEED)
     want = f["ops"].moments(f["out"][:700, sub].contiguous())
-    assert torch.equal(mom, want)
+    assert torch.allclose(mom, want, rtol=1e-13, atol=0)  # slabs of 256 draws vs one launch: float64 sums, different association
     st = moments_to_mean_std(mom, 700)
     assert st["mean_mu"].min() >= 4 and st["mean_mu"].max() <= 12 and (st["std_mu"] >= 0).all()
