@@ -61,6 +61,7 @@ def lib():
     L.bnn_moments_f64.argtypes = [_vp, C.c_int64, C.c_int64, _vp, C.c_int32, _vp]
     L.bnn_truncnorm_f32.argtypes = [_vp, C.c_int64, _vp, C.c_int32, C.c_double, C.c_uint64, C.c_int64, _vp, _vp]
     L.bnn_prior_resample_f32.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, C.c_double, C.c_uint64, C.c_int64, _vp]
+    L.bnn_regress_f32.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp]
     L.bnn_group_min_f32.argtypes = [_vp, C.c_int64, C.c_int32, _vp, _vp]
     L.bnn_quantiles_f32.argtypes = [_vp, C.c_int64, C.c_int64, _vp, C.c_int32, _vp, _vp]
     L.bnn_feature_pack_f64.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, _vp]
@@ -75,7 +76,7 @@ def lib():
 
 EXPORTS = ("bnn_abi_version", "bnn_last_error", "bnn_device_count", "bnn_param_count", "bnn_plan_create",
            "bnn_plan_destroy", "bnn_plan_layer_order", "bnn_layer_order", "bnn_fragment_table", "bnn_swag_draw_f32", "bnn_forward_f32", "bnn_multiswag_f32",
-           "bnn_moments_f64", "bnn_truncnorm_f32", "bnn_prior_resample_f32", "bnn_group_min_f32", "bnn_quantiles_f32", "bnn_feature_pack_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32")
+           "bnn_moments_f64", "bnn_truncnorm_f32", "bnn_prior_resample_f32", "bnn_regress_f32", "bnn_group_min_f32", "bnn_quantiles_f32", "bnn_feature_pack_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32")
 
 
 def check(rc):

@@ -63,6 +63,59 @@ __global__ __launch_bounds__(1024) void bnn_moments_kernel(const float* __restri
         for (int k = 0; k < 4; ++k) mom[b * 4 + k] = (accumulate ? mom[b * 4 + k] : 0.0) + part[0][l][k];
 }
 
+// regress_nn + soft_clamp on an explicit summary (predict_instability, spock_reg_model.py:437-442): one thread per system, the
+// draw's regress_nn parameters in LDS, each neuron a bias-initialised fmaf chain in the fused kernel's accumulation order, so
+// the result is bit-identical to the tail of bnn_forward_f32 on the same summary.
+struct RegressParams {
+    const float* summary;  // [J,B,40]
+    const float* W;        // [J,d]
+    float* out;            // [J,B,2]
+    float* pre;            // [J,B,2] or null
+    int64_t B;
+    float std_lo, std_span;
+    int8_t ord[3][H];
+};
+
+constexpr int REG_NW = D - OFF_W4;  // 3362 floats
+constexpr int REG_LD = H + 1;
+
+__global__ __launch_bounds__(128) void bnn_regress_kernel(RegressParams p) {
+    __shared__ float w[REG_NW];
+    __shared__ float a[128 * REG_LD];
+    __shared__ float h[128 * REG_LD];
+    const int tid = threadIdx.x, j = blockIdx.y;
+    const float* wj = p.W + (int64_t)j * D + OFF_W4;
+    for (int i = tid; i < REG_NW; i += 128) w[i] = wj[i];
+    const int64_t b = (int64_t)blockIdx.x * 128 + tid;
+    const bool live = b < p.B;
+    const int64_t o = (int64_t)j * p.B + b;
+    for (int k = 0; k < S2; ++k) a[tid * REG_LD + k] = live ? p.summary[o * S2 + k] : 0.0f;
+    __syncthreads();
+    float* av = a + tid * REG_LD;
+    float* hv = h + tid * REG_LD;
+    for (int n = 0; n < H; ++n) {
+        float acc = w[OFF_B4 - OFF_W4 + n];
+        for (int i = 0; i < S2; ++i) { int k = p.ord[0][i]; acc = fmaf(w[n * S2 + k], av[k], acc); }
+        hv[n] = fmaxf(acc, 0.0f);
+    }
+    for (int n = 0; n < H; ++n) {
+        float acc = w[OFF_B5 - OFF_W4 + n];
+        for (int i = 0; i < H; ++i) { int k = p.ord[1][i]; acc = fmaf(w[OFF_W5 - OFF_W4 + n * H + k], hv[k], acc); }
+        av[n] = fmaxf(acc, 0.0f);
+    }
+    float r[2];
+    for (int n = 0; n < 2; ++n) {
+        float acc = w[OFF_B6 - OFF_W4 + n];
+        for (int i = 0; i < H; ++i) { int k = p.ord[2][i]; acc = fmaf(w[OFF_W6 - OFF_W4 + n * H + k], av[k], acc); }
+        r[n] = acc;
+    }
+    if (!live) return;
+    float mu = (0.5f * (tanhf(r[0]) + 1.0f)) * 8.0f + 4.0f;
+    float sd = (0.5f * (tanhf(r[1]) + 1.0f)) * p.std_span + p.std_lo;
+    *reinterpret_cast<f32x2*>(p.out + o * 2) = (f32x2){mu, sd};
+    if (p.pre) *reinterpret_cast<f32x2*>(p.pre + o * 2) = (f32x2){r[0], r[1]};
+}
+
 // Per-system percentiles over the draws: one workgroup bitonic-sorts one (system, channel) column of R values in LDS.
 struct QuantParams { double q[16]; int nq; };
 __global__ __launch_bounds__(256) void bnn_quantiles_kernel(const float* __restrict__ samples, int64_t R, int64_t B, int npad, QuantParams qp,
@@ -540,6 +593,25 @@ int bnn_prior_resample_f32(float* vals, int64_t n, const int64_t* rank, const do
     if (!vals || !rank || !cum || !edge || m < 2) return fail(BNN_ERR_INVALID, "NULL argument or table shorter than 2");
     hipLaunchKernelGGL(bnn_prior_resample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vals, n, rank, cum, edge,
                        m, u, threshold, philox_seed, id0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bnn_regress_f32(const bnn_plan* pl, const float* summary, const float* W, int64_t J, int64_t B, float* out, float* pre_clamp,
+                    void* stream) {
+    if (!pl) return fail(BNN_ERR_INVALID, "plan is NULL");
+    if (J < 0 || B < 0 || J > 65535) return fail(BNN_ERR_INVALID, "bad J/B");
+    if (J == 0 || B == 0) return 0;
+    if (!summary || !W || !out) return fail(BNN_ERR_INVALID, "NULL argument");
+    RegressParams p;
+    p.summary = summary; p.W = W; p.out = out; p.pre = pre_clamp; p.B = B;
+    p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);
+    for (int l = 0; l < 3; ++l) {
+        const std::vector<int32_t>& o = pl->tab[0].order[3 + l];
+        if ((int)o.size() != H) return fail(BNN_ERR_INVALID, "internal: regress_nn order table");
+        for (int i = 0; i < H; ++i) p.ord[l][i] = (int8_t)o[i];
+    }
+    hipLaunchKernelGGL(bnn_regress_kernel, dim3((unsigned)((B + 127) / 128), (unsigned)J), dim3(128), 0, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -218,6 +218,22 @@ def moments(samples, mom=None):
     return mom
 
 
+@_on_device_of(0)
+def regress(summary, W, plan=None, debug=False):
+    """predict_instability on an explicit summary: summary [J,B,40], W [J,d] -> out [J,B,2] (and pre_clamp with debug)."""
+    summary = _f32(summary, "summary")
+    W = _f32(W, "W")
+    J, B, S = summary.shape
+    plan = plan or get_plan()
+    if S != 2 * LATENT or W.shape != (J, plan.d):
+        raise ValueError("regress needs summary [J,B,40] and W [J,d]")
+    out = torch.empty((J, B, 2), dtype=torch.float32, device=summary.device)
+    pre = torch.empty_like(out) if debug else None
+    N.check(N.lib().bnn_regress_f32(plan.handle, N.ptr(summary), N.ptr(W), J, B, N.ptr(out), N.ptr(pre) if debug else None,
+                                    N.stream_ptr()))
+    return (out, pre) if debug else out
+
+
 def philox_normal(kind, philox_seed, id0, n_rows, width=0, B=0, system_id0=0, device="cuda"):
     """The normals the kernels generate in-kernel: kind 0 -> z1[n_rows,width], 1 -> z2[n_rows,width], 2 -> eps[n_rows,B,2,20],
     3 -> eps_in[n_rows,B,T=width,41], 4 -> eps_sum[n_rows,B,40]."""

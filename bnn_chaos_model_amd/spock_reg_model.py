@@ -304,16 +304,21 @@ class VarModel:
         return summ
 
     def predict_instability(self, summary_stats):
-        """regress_nn + soft_clamp (:437-442) on an explicit summary (off the hot path: plain torch ops on the GPU)."""
+        """regress_nn + soft_clamp (:437-442) on an explicit summary -> (mu [B,1], std [B,1]) on its device."""
         g = _gpu()
-        sd = {k: v.to(g) for k, v in self.state_dict().items() if k.startswith("regress_nn")}
-        s = summary_stats.to(g, torch.float32)
-        h = torch.relu(s @ sd["regress_nn.0.weight"].T + sd["regress_nn.0.bias"])
-        h = torch.relu(h @ sd["regress_nn.2.weight"].T + sd["regress_nn.2.bias"])
-        testy = (h @ sd["regress_nn.4.weight"].T + sd["regress_nn.4.bias"]).to(summary_stats.device)
-        mu = soft_clamp(testy[:, [0]], 4.0, 12.0)
-        std = soft_clamp(testy[:, [1]], self.lowest, 6.0)
-        return mu, std
+        s = summary_stats.detach().to(g, torch.float32).contiguous()
+        out = ops.regress(s[None], self._w[None].to(g), plan=self._plan())[0].to(summary_stats.device)
+        return out[:, [0]], out[:, [1]]
+
+    def add_input_noise(self, x):
+        """x + randn_like(x) * exp(input_noise_logvar / 2) (:444-446); forward() fuses this step into the kernel."""
+        lv = self._w[:41].to(x.device)
+        return x + torch.randn_like(x) * torch.exp(lv[None, None, :] / 2)
+
+    def add_summary_noise(self, summary_stats):
+        """summary + randn_like(summary) * exp(summary_noise_logvar / 2) (:448-450); forward() fuses this step."""
+        lv = self._w[41:81].to(summary_stats.device)
+        return summary_stats + torch.randn_like(summary_stats) * torch.exp(lv[None, :] / 2)
 
     def forward(self, x, noisy_val=True):
         """VarModel.forward (:486-528) with the currently loaded weights -> cat(mu, std) [B,2] on x.device."""

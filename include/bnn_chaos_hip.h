@@ -163,6 +163,12 @@ int bnn_truncnorm_f32(const float* musd, int64_t n, const double* normals, int32
 int bnn_prior_resample_f32(float* vals, int64_t n, const int64_t* rank, const double* cum, const double* edge, int64_t m,
                            const double* u, double threshold, uint64_t philox_seed, int64_t id0, void* stream);
 
+/* predict_instability (spock_reg_model.py:437-442) on an explicit summary: regress_nn + soft_clamp.
+ *   summary [J,B,40], W [J,d] (flat parameter vectors; only regress_nn.* is read) -> out [J,B,2] = (mu, std),
+ *   pre_clamp [J,B,2] or NULL.  Same accumulation order as the tail of bnn_forward_f32 (bit-identical on its summary). */
+int bnn_regress_f32(const bnn_plan* plan, const float* summary, const float* W, int64_t J, int64_t B, float* out, float* pre_clamp,
+                    void* stream);
+
 /* np.min over the last axis of size `group` (min over trios, figures/multiswag_5_planet.py:428): vals [n,group] -> out [n]. */
 int bnn_group_min_f32(const float* vals, int64_t n, int32_t group, float* out, void* stream);
 

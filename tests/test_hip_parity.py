@@ -92,6 +92,27 @@ def test_forward_vs_reference_and_oracle(si, xname, ops, orc, inputs):
 
 
 @pytest.mark.parametrize("si", (0, 12))
+def test_regress_is_the_tail_of_forward(si, ops, inputs):
+    """bnn_regress_f32 (predict_instability, :437-442) on the summary bnn_forward_f32 reports == that forward's outputs, bit for bit."""
+    z = load_golden(f"case_swagfast_v50_{si}_slow.npz")
+    tp = tape(z)
+    eps = np.stack([tp[2][1], tp[3][1]], axis=1)[None]
+    W = dev(np.stack([z["w"], z["w"] * 0.5]))
+    out, pre, summ = ops.forward(dev(inputs["slow"]), W, eps=dev(np.concatenate([eps, eps])), debug=True)
+    out2, pre2 = ops.regress(summ, W, debug=True)
+    assert torch.equal(pre2, pre) and torch.equal(out2, out)
+    nbad, mx = close_report(out2[0].cpu().numpy(), z["out"])
+    assert nbad == 0, (nbad, mx)
+    # ragged system counts, empty batch
+    for B in (1, 127, 129):
+        o = ops.regress(summ[:, :B].contiguous(), W)
+        assert torch.equal(o, out[:, :B])
+    assert ops.regress(summ[:, :0].contiguous(), W).shape == (2, 0, 2)
+    with pytest.raises(ValueError):
+        ops.regress(summ, W[:1])
+
+
+@pytest.mark.parametrize("si", (0, 12))
 @pytest.mark.parametrize("noisy", (0, 1))
 def test_varmodel_forward_vs_reference(si, noisy, ops, orc, inputs):
     z = load_golden(f"case_forward_v50_{si}_noisy{noisy}.npz")

@@ -102,6 +102,23 @@ def test_compute_summary_stats_and_predict_instability(models, inputs):
     assert nbad == 0, (nbad, mx)
 
 
+def test_noise_helpers_follow_the_reference_stream(models, inputs):
+    """add_input_noise / add_summary_noise (:444-450) draw one randn_like each and scale by exp(logvar / 2)."""
+    m = models[0]
+    x = torch.tensor(inputs["slow"][:4])
+    torch.manual_seed(5)
+    got = m.add_input_noise(x)
+    torch.manual_seed(5)
+    want = x + torch.randn_like(x) * torch.exp(m.flatten()[:41].cpu() / 2)
+    assert torch.equal(got, want)
+    s = torch.randn(4, 40)
+    torch.manual_seed(6)
+    got = m.add_summary_noise(s)
+    torch.manual_seed(6)
+    want = s + torch.randn_like(s) * torch.exp(m.flatten()[41:81].cpu() / 2)
+    assert torch.equal(got, want)
+
+
 def test_feature_regressor_sample_full_swag(ckpt_dir, inputs):
     """FeatureRegressor.sample_full_swag x3 (figures/spock/regression.py:74-92) == the captured reference run."""
     from bnn_chaos_model_amd.regression import FeatureRegressor
