@@ -6,7 +6,10 @@ N-body features (the REBOUND integration upstream of it is out of scope):
     MultiSWAG MC loop, samples x 10 chunks   --sample_full_swag_many-->  time [samples, sims, trios, 2]       (:295-298)
     fast_truncnorm(left=4, nsamp=40) -> prior resampling past 9 -> min over trios -> median / 68 % / 95 % bands (:388-489)
 
-    python examples/five_planet_pipeline.py --ckpt '/path/to/pretrained/*v50*output.pkl' [--sims 50] [--samples 100]
+    python examples/five_planet_pipeline.py [--ckpt '/path/to/pretrained/*v50*output.pkl'] [--sims 50] [--samples 100]
+
+Without --ckpt the two pretrained seeds held as test fixtures (tests/golden/swag_v50_{0,12}.npz) are written out as
+reference-format checkpoints in a temporary directory and used as the ensemble.
 """
 import argparse
 import os
@@ -37,12 +40,29 @@ def run(ckpt_glob, sims=50, trios=3, samples=100, rng="philox", seed=0):
     return {"time": time, "samps_time": samps_time, "outs": outs, "bands": bands, "average": outs.mean(1)}
 
 
+def fixture_checkpoints(dirname):
+    """tests/golden/swag_v50_*.npz -> reference-format *_output.pkl files; returns the glob for FeatureRegressor."""
+    import json
+    from bnn_chaos_model_amd import checkpoint
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+    for i in (0, 12):
+        z = np.load(os.path.join(golden, f"swag_v50_{i}.npz"))
+        checkpoint.write_swag_file(os.path.join(dirname, f"steps=300000_v50_{i:02d}_output.pkl"), json.loads(str(z["hparams_json"])),
+                                   json.loads(str(z["swa_params_json"])), torch.tensor(z["w_avg"]), torch.tensor(z["w2_avg"]),
+                                   torch.tensor(z["pre_D"]))
+    return os.path.join(dirname, "*v50*output.pkl")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ckpt", required=True)
+    ap.add_argument("--ckpt", default=None)
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--samples", type=int, default=100)
     a = ap.parse_args()
+    if a.ckpt is None:
+        import tempfile
+        _tmp = tempfile.TemporaryDirectory()
+        a.ckpt = fixture_checkpoints(_tmp.name)
     r = run(a.ckpt, sims=a.sims, samples=a.samples)
     torch.cuda.synchronize()
     b = r["bands"].cpu().numpy()
