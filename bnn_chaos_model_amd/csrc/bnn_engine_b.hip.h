@@ -185,10 +185,11 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h[n] = bq1[n];
                 auto rd = [&](int kp) {
-                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    const int kr = (BNN_EXP & 16) ? 0 : kp;  // timing experiment 16: one group of operand reads per layer
+                    const int k0 = 2 * kr, k1 = 2 * kr + 1;
                     q[kp][0] = wqA1[(k0 * 2 + 0) * 4]; q[kp][1] = wqA1[(k0 * 2 + 1) * 4];
                     if (k1 < KIN) { q[kp][2] = wqA1[(k1 * 2 + 0) * 4]; q[kp][3] = wqA1[(k1 * 2 + 1) * 4]; }
-                    q[kp][4] = wqB1[kp * 4];
+                    q[kp][4] = wqB1[kr * 4];
                 };
                 rd(0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
             }
             STAMP(2);  // layer 1
 #pragma unroll
-            for (int n = 0; n < 10; ++n) h[n] = relu4(h[n]);
+            for (int n = 0; n < 10; ++n) h[n] = (BNN_EXP & 8) ? h[n] : relu4(h[n]);  // timing experiment 8: no ReLU
             // x of this tile is dead: fetch the next tile's rows into the same registers (one tile of work to land)
 #if !(BNN_EXP & 2)  // timing experiment 2: no further x loads
             {
@@ -230,10 +231,11 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h2[n] = bq2[n];
                 auto rd = [&](int kp) {
-                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    const int kr = (BNN_EXP & 16) ? 0 : kp;
+                    const int k0 = 2 * kr, k1 = 2 * kr + 1;
                     q[kp][0] = wqA2[(k0 * 2 + 0) * 4]; q[kp][1] = wqA2[(k0 * 2 + 1) * 4];
                     q[kp][2] = wqA2[(k1 * 2 + 0) * 4]; q[kp][3] = wqA2[(k1 * 2 + 1) * 4];
-                    q[kp][4] = wqB2[kp * 4];
+                    q[kp][4] = wqB2[kr * 4];
                 };
                 rd(0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
             }
             STAMP(4);  // layer 2
 #pragma unroll
-            for (int n = 0; n < 10; ++n) h2[n] = relu4(h2[n]);
+            for (int n = 0; n < 10; ++n) h2[n] = (BNN_EXP & 8) ? h2[n] : relu4(h2[n]);
             STAMP(5);  // relu 2
             // feature_nn.4: quads of inputs: reads A(k..k+3) + B(quad)
             f32x4 y[5];
@@ -264,9 +266,10 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
 #pragma unroll
                 for (int n = 0; n < 5; ++n) y[n] = bq3[n];
                 auto rd = [&](int kq) {
+                    const int kr = (BNN_EXP & 16) ? 0 : kq;
 #pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) q[kq][cc] = wqA3[(4 * kq + cc) * 4];
-                    q[kq][4] = wqB3[kq * 4];
+                    for (int cc = 0; cc < 4; ++cc) q[kq][cc] = wqA3[(4 * kr + cc) * 4];
+                    q[kq][4] = wqB3[kr * 4];
                 };
                 rd(0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 5 + 5, 0);

@@ -441,6 +441,15 @@ static int pick_spc(const bnn_grid* g, int64_t csz) {
     return 64;
 }
 
+static size_t exp_lds_pad() {  // experiments only: BNN_EXP_LDS_PAD=bytes lowers the occupancy (one workgroup per CU above ~12 KB)
+#if BNN_EXP & 4
+    const char* e = getenv("BNN_EXP_LDS_PAD");
+    return e ? (size_t)atoi(e) : 0;
+#else
+    return 0;
+#endif
+}
+
 static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, bool fused, bool noisy, void* stream) {
     if (!pl || !g) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
     if (g->B < 0 || g->J < 0 || g->nchunks < 1) return fail(BNN_ERR_INVALID, "negative size");
@@ -483,7 +492,7 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag4_kernel<KI, FU, NZ>),           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
         });                                                                                                        \
-        const size_t shmem4 = sizeof(float) * (FLAT_LDS + MAXK + W4<KI>::PAD + 4 * SCR4 + NSC4);                   \
+        const size_t shmem4 = sizeof(float) * (FLAT_LDS + MAXK + W4<KI>::PAD + 4 * SCR4 + NSC4) + exp_lds_pad();   \
         hipLaunchKernelGGL((bnn_multiswag4_kernel<KI, FU, NZ>), grid, block, shmem4, st, p);                       \
     } while (0)
         if (noisy) {
