@@ -17,7 +17,6 @@ to the kernels as explicit noise: after torch.manual_seed(s) the outputs match t
 seed to fp32 rounding.  With `rng = "philox"` the kernels generate counter-based noise themselves
 (no noise tensors in HBM); set `philox_seed` for reproducibility.
 """
-import copy
 import random
 from collections import OrderedDict
 

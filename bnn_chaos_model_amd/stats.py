@@ -9,7 +9,6 @@ rng="numpy" consumes numpy's global generator exactly as the reference does (np.
 of d elements; np.random.rand(n_samples)) and feeds the draws to the kernels, so np.random.seed(s) reproduces the
 reference's numbers bit for bit; rng="philox" generates the noise in-kernel.
 """
-import ctypes as C
 
 import numpy as np
 import torch
