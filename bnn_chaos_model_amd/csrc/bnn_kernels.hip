@@ -441,6 +441,14 @@ static int pick_spc(const bnn_grid* g, int64_t csz) {
     return 64;
 }
 
+constexpr int MAX_DEVICES = 64;
+
+static int current_device_slot() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return (dev >= 0 && dev < MAX_DEVICES) ? dev : 0;
+}
+
 static size_t exp_lds_pad() {  // experiments only: BNN_EXP_LDS_PAD=bytes lowers the occupancy (one workgroup per CU above ~12 KB)
 #if BNN_EXP & 4
     const char* e = getenv("BNN_EXP_LDS_PAD");
@@ -477,8 +485,8 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     const int nk1 = pl->tab[v].nk1;
 #define LAUNCH(NK, NZ, FU)                                                                                         \
     do {                                                                                                           \
-        static std::once_flag once;                                                                                \
-        std::call_once(once, [] {                                                                                  \
+        static std::once_flag once[MAX_DEVICES];  /* the attribute belongs to the (function, device) pair */     \
+        std::call_once(once[current_device_slot()], [] {                                                           \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag_kernel<NK, NZ, FU>),            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
         });                                                                                                        \
@@ -487,8 +495,8 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     if (pl->use_v4) {
 #define LAUNCH4(KI, FU, NZ)                                                                                        \
     do {                                                                                                           \
-        static std::once_flag once;                                                                                \
-        std::call_once(once, [] {                                                                                  \
+        static std::once_flag once[MAX_DEVICES];                                                                   \
+        std::call_once(once[current_device_slot()], [] {                                                           \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag4_kernel<KI, FU, NZ>),           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
         });                                                                                                        \
@@ -647,8 +655,8 @@ int bnn_quantiles_f32(const float* samples, int64_t R, int64_t B, const double* 
     }
     int npad = 2;
     while (npad < R) npad <<= 1;
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static std::once_flag once[MAX_DEVICES];
+    std::call_once(once[current_device_slot()], [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_quantiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     });
     if (2 * B > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many systems for one launch");
