@@ -617,7 +617,7 @@ int bnn_prior_resample_f32(float* vals, int64_t n, const int64_t* rank, const do
 int bnn_regress_f32(const bnn_plan* pl, const float* summary, const float* W, int64_t J, int64_t B, float* out, float* pre_clamp,
                     void* stream) {
     if (!pl) return fail(BNN_ERR_INVALID, "plan is NULL");
-    if (J < 0 || B < 0 || J > 65535) return fail(BNN_ERR_INVALID, "bad J/B");
+    if (J < 0 || B < 0) return fail(BNN_ERR_INVALID, "bad J/B");
     if (J == 0 || B == 0) return 0;
     if (!summary || !W || !out) return fail(BNN_ERR_INVALID, "NULL argument");
     RegressParams p;
@@ -628,8 +628,15 @@ int bnn_regress_f32(const bnn_plan* pl, const float* summary, const float* W, in
         if ((int)o.size() != H) return fail(BNN_ERR_INVALID, "internal: regress_nn order table");
         for (int i = 0; i < H; ++i) p.ord[l][i] = (int8_t)o[i];
     }
-    hipLaunchKernelGGL(bnn_regress_kernel, dim3((unsigned)((B + 127) / 128), (unsigned)J), dim3(128), 0, (hipStream_t)stream, p);
-    HIP_TRY(hipGetLastError());
+    if ((B + 127) / 128 > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many systems for one launch");
+    for (int64_t j0 = 0; j0 < J; j0 += 65535) {  // grid.y limit
+        const int64_t nj = J - j0 < 65535 ? J - j0 : 65535;
+        RegressParams q = p;
+        q.summary = summary + j0 * B * S2; q.W = W + j0 * D; q.out = out + j0 * B * 2;
+        q.pre = pre_clamp ? pre_clamp + j0 * B * 2 : nullptr;
+        hipLaunchKernelGGL(bnn_regress_kernel, dim3((unsigned)((B + 127) / 128), (unsigned)nj), dim3(128), 0, (hipStream_t)stream, q);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 

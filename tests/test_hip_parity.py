@@ -108,6 +108,10 @@ def test_regress_is_the_tail_of_forward(si, ops, inputs):
         o = ops.regress(summ[:, :B].contiguous(), W)
         assert torch.equal(o, out[:, :B])
     assert ops.regress(summ[:, :0].contiguous(), W).shape == (2, 0, 2)
+    # more draws than one grid dimension holds (launches are split at 65535 draws)
+    Jb = 65535 + 3
+    big = ops.regress(summ[0, :1].expand(Jb, 1, 40).contiguous(), W[:1].expand(Jb, -1).contiguous())
+    assert torch.equal(big, out[0, :1].expand(Jb, 1, 2))
     with pytest.raises(ValueError):
         ops.regress(summ, W[:1])
 
