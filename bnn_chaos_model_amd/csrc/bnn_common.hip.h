@@ -55,11 +55,13 @@ DEVINL uint4 philox4x32_10(uint4 c, uint2 k) {
     return c;
 }
 
-// Box-Muller on 24-bit uniforms in (0,1); v_sin/v_cos take revolutions, so no range reduction.
+// Box-Muller on 24-bit uniforms in (0,1); v_sin/v_cos take revolutions, so no range reduction; v_log / v_sqrt as they
+// are (1 ulp; the radicand lies in [1e-7, 34]): these normals are noise, and every consumer -- in-kernel or through
+// bnn_philox_normal_f32 -- gets them from this one function.
 DEVINL f32x2 box_muller(uint32_t a, uint32_t b) {
     float u1 = ((float)(a >> 8) + 0.5f) * 5.9604644775390625e-8f;
     float u2 = ((float)(b >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    float r = sqrtf(-2.0f * __logf(u1));
+    float r = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1));
     f32x2 o;
     o.x = r * __builtin_amdgcn_cosf(u2);
     o.y = r * __builtin_amdgcn_sinf(u2);
