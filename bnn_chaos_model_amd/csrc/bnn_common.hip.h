@@ -46,8 +46,9 @@ constexpr uint32_t TAG_Z1 = 0x10000000u, TAG_Z2 = 0x20000000u, TAG_EPS = 0x30000
 DEVINL uint4 philox4x32_10(uint4 c, uint2 k) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a mul_hi + mul_lo pair: both are quarter-rate
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
         k.x += 0x9E3779B9u;
         k.y += 0xBB67AE85u;
