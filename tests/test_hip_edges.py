@@ -290,6 +290,25 @@ def test_degenerate_inputs_match_oracle(kind, ops, orc, swag_states):
     assert torch.isfinite(out).all()
 
 
+def test_non_finite_input_stays_inside_its_own_system(ops, swag_states):
+    """The feature stage removes NaN/inf before the path (figures/spock/regression.py:195), so non-finite rows are outside
+    the path's domain (ReLU on the bit pattern does not propagate every NaN the way torch.relu does).  What is guaranteed: a
+    non-finite value never leaks into the other systems of its wave / workgroup, and masked columns may hold anything."""
+    B = 40
+    x = synth(B, 100, 21)
+    wa, w2, pd = state(swag_states)
+    idx = torch.zeros(3, dtype=torch.int32)
+    clean = ops.multiswag(dev(x), dev(wa), dev(w2), dev(pd), idx, philox_seed=9)
+    bad = x.copy()
+    bad[5, 17, 9] = np.nan          # live column
+    bad[22, 3, 12] = np.inf         # live column
+    bad[30, :, 3] = np.nan          # masked column (v50): never read
+    got = ops.multiswag(dev(bad), dev(wa), dev(w2), dev(pd), idx, philox_seed=9)
+    assert torch.isnan(got[:, 5]).all()
+    keep = [b for b in range(B) if b not in (5, 22)]
+    assert torch.equal(got[:, keep], clean[:, keep])
+
+
 def test_hip_graph_capture_and_replay(ops, swag_states):
     """The ops only enqueue work on the current stream (no allocation, no sync once buffers exist): the two-launch
     multiswag call can be captured in a HIP graph and replayed."""
