@@ -26,6 +26,15 @@ class BnnGrid(C.Structure):
                 ("systems_per_block", C.c_int32), ("noisy", C.c_int32), ("reserved", C.c_int32)]
 
 
+class BnnStats(C.Structure):
+    _fields_ = [("tn_nsamp", C.c_int32), ("tn_left", C.c_float), ("prior_thr", C.c_float), ("prior_m", C.c_int32),
+                ("prior_step", C.c_float), ("reserved", C.c_int32), ("prior_surv", C.c_void_p)]
+
+
+class BnnSketch(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("reserved", C.c_int32), ("lo", C.c_float * 4), ("hi", C.c_float * 4), ("n", C.c_int32 * 4)]
+
+
 class NativeError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"bnn_chaos_hip error {code}: {msg}")
@@ -37,13 +46,18 @@ _vp = C.c_void_p
 
 
 def lib():
-    """Load libbnn_chaos_hip.so; build it with hipcc first if sources are newer (needs ROCm)."""
+    """Load libbnn_chaos_hip.so; (re)build it with hipcc first when it is missing or older than its sources (needs ROCm;
+    build() is a no-op when the library is up to date; an explicit BNN_CHAOS_SO is taken as it is)."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
+    if not os.environ.get("BNN_CHAOS_SO"):
         from .csrc import build as _b
-        _b.build()
+        try:
+            _b.build()
+        except Exception:
+            if not os.path.exists(SO_PATH):  # no compiler AND no library: nothing to run (there is no CPU fallback)
+                raise
     L = C.CDLL(SO_PATH)
     L.bnn_last_error.restype = C.c_char_p
     L.bnn_plan_create.argtypes = [C.POINTER(BnnArch), C.POINTER(_vp)]
@@ -68,7 +82,14 @@ def lib():
     L.bnn_philox_normal_f32.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                         _vp, _vp]
     L.bnn_philox_raw_u32.argtypes = [C.c_uint32] * 6 + [C.c_int64, _vp, _vp]
-    if L.bnn_abi_version() != 1:
+    L.bnn_prior_table_f32.argtypes = [C.c_double, C.c_double, C.c_int32, _vp, C.POINTER(C.c_double)]
+    L.bnn_stats_draw_f32.argtypes = [_vp, C.c_int64, C.c_int64, C.POINTER(BnnStats), C.c_uint64, C.c_int64, C.c_int64, _vp, _vp]
+    L.bnn_multiswag_stats_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp,
+                                          _vp, C.c_float, C.c_uint64, C.c_int64, C.c_int64, _vp, C.POINTER(BnnStats), _vp, _vp]
+    L.bnn_sketch_bins.argtypes = [C.POINTER(BnnSketch)]
+    L.bnn_sketch_update_u32.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int32, C.POINTER(BnnSketch), _vp, _vp, _vp]
+    L.bnn_sketch_quantiles_f32.argtypes = [_vp, C.c_int64, C.POINTER(BnnSketch), _vp, C.c_int32, _vp, _vp]
+    if L.bnn_abi_version() != 2:
         raise NativeError(-1, "ABI version mismatch")
     _lib = L
     return L
@@ -76,7 +97,9 @@ def lib():
 
 EXPORTS = ("bnn_abi_version", "bnn_last_error", "bnn_device_count", "bnn_param_count", "bnn_plan_create",
            "bnn_plan_destroy", "bnn_plan_layer_order", "bnn_layer_order", "bnn_fragment_table", "bnn_swag_draw_f32", "bnn_forward_f32", "bnn_multiswag_f32",
-           "bnn_moments_f64", "bnn_truncnorm_f32", "bnn_prior_resample_f32", "bnn_regress_f32", "bnn_group_min_f32", "bnn_quantiles_f32", "bnn_feature_pack_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32")
+           "bnn_moments_f64", "bnn_truncnorm_f32", "bnn_prior_resample_f32", "bnn_regress_f32", "bnn_group_min_f32", "bnn_quantiles_f32", "bnn_feature_pack_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32",
+           "bnn_prior_table_f32", "bnn_stats_draw_f32", "bnn_multiswag_stats_f32", "bnn_sketch_bins", "bnn_sketch_update_u32",
+           "bnn_sketch_quantiles_f32")
 
 
 def check(rc):

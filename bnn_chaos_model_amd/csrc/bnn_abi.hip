@@ -1,18 +1,11 @@
-// bnn_kernels.hip -- the one translation unit of libbnn_chaos_hip.so: gfx950 (MI355X, CDNA4) kernels of the
-// MultiSWAG inference hot path and the C ABI of include/bnn_chaos_hip.h.
+// bnn_abi.hip -- the C ABI of include/bnn_chaos_hip.h plus the small kernels of libbnn_chaos_hip.so (gfx950, MI355X):
+// SWAG draw, predictive moments, regress_nn on an explicit summary, the statistics epilogue (numpy-replay forms, the Philox
+// form, the streaming quantile sketch), feature packing and the Philox fills.  The forward kernel lives in bnn_forward.hip.h
+// and is instantiated by the bnn_fwd_*.hip translation units (bnn_internal.h lists them).
 //
 // Reference path (MilesCranmer/bnn_chaos_model): SWAGModel.sample_weights + forward_swag_fast / VarModel.forward in
 // spock_reg_model.py:415-450, 486-528, 815-908, driven by figures/spock/regression.py:74-92 and
 // figures/multiswag_5_planet.py:295-298.  DESIGN.md section 4 has the long form.
-//
-//   bnn_common.hip.h    types, Philox4x32-10 normals, kernel parameters, the SWAG draw
-//   bnn_engine_a.hip.h  feature_nn on v_mfma_f32_16x16x4_f32 (weights in registers; any mask; noisy forward)
-//   bnn_engine_b.hip.h  feature_nn on v_mfma_f32_4x4x1_16b_f32 (no padding; weights streamed from LDS; default)
-//   this file           moments / feature packing / Philox fill kernels, plans, launchers, extern "C" entry points
-//
-// One 256-thread workgroup = 4 independent waves, one weight draw x a block of systems.  fp32 MFMA is bit for bit a
-// k-ordered fmaf chain, so every result is reproducible on a CPU given the accumulation order exported by
-// bnn_plan_layer_order().
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fmaf/MFMA are the only fusions).
 #include <hip/hip_runtime.h>
@@ -21,19 +14,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/bnn_chaos_hip.h"
-#include "bnn_layout.h"
+#include "bnn_common.hip.h"
+#include "bnn_stats.hip.h"
 #include "bnn_tables.h"
 
 using namespace bnn;
-
-#include "bnn_common.hip.h"
-#include "bnn_engine_a.hip.h"
-#include "bnn_engine_b.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // small kernels
@@ -150,7 +139,6 @@ __global__ __launch_bounds__(256) void bnn_quantiles_kernel(const float* __restr
 }
 
 // fast_truncnorm, right = inf: one thread per element, candidates in float64 exactly as numpy forms them
-constexpr uint32_t TAG_TN = 0x60000000u, TAG_U = 0x70000000u;
 __global__ void bnn_truncnorm_kernel(const float* __restrict__ musd, int64_t n, const double* __restrict__ normals, int nsamp, double left,
                                      uint64_t seed, int64_t id0, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,13 +251,16 @@ __global__ void bnn_philox_fill_kernel(int kind, uint64_t seed, int64_t id0, int
         int el = (int)(i % S2);
         int64_t sys = (i / S2) % B, row = i / (S2 * B);
         out[i] = philox_sys4(kind == 2 ? TAG_EPS : TAG_SUM, id0 + row, sys0 + sys, el >> 2, seed)[el & 3];
-    } else {  // kind 3: eps_in [n_rows, B, T = width, 41]
+    } else {  // kind 3: eps_in [n_rows, B, T = width, 41]: block t*7 + col/6, normal col%6 (bnn_common.hip.h)
         const int T = width;
         int64_t per = (int64_t)T * F, total = n_rows * B * per;
         if (i >= total) return;
         int col = (int)(i % F), t = (int)((i / F) % T);
         int64_t sys = (i / per) % B, row = i / (per * B);
-        out[i] = philox_sys4(TAG_IN, id0 + row, sys0 + sys, t * 11 + (col >> 2), seed)[col & 3];
+        float n6[6];
+        philox_in6(id0 + row, sys0 + sys, t * NIN_BLOCKS + col / NIN_PER_BLOCK, seed, n6);
+        const int j = col % NIN_PER_BLOCK;
+        out[i] = j == 0 ? n6[0] : j == 1 ? n6[1] : j == 2 ? n6[2] : j == 3 ? n6[3] : j == 4 ? n6[4] : n6[5];
     }
 }
 
@@ -279,6 +270,133 @@ __global__ void bnn_philox_raw_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uin
     if (i >= n) return;
     uint4 r = philox4x32_10(make_uint4(c0 + (uint32_t)i, c1, c2, c3), make_uint2(k0, k1));
     out[i * 4] = r.x; out[i * 4 + 1] = r.y; out[i * 4 + 2] = r.z; out[i * 4 + 3] = r.w;
+}
+
+// SWAGModel.sample_weights for J draws: grid.x = (draw, 256-row slice of the parameter vector), so J is bounded only by 2^31 / 30.
+constexpr int DRAW_SLICES = (D + 255) / 256;
+__global__ __launch_bounds__(256) void bnn_swag_draw_kernel(const float* __restrict__ w_avg, const float* __restrict__ w2_avg,
+                                                            const float* __restrict__ pre_D, int S, int K,
+                                                            const int32_t* __restrict__ seed_idx, const float* __restrict__ z1,
+                                                            const float* __restrict__ z2, float c1, float c2, float scale,
+                                                            uint64_t seed, int64_t draw_id0, float* __restrict__ W_out) {
+    __shared__ float slabs[4 * SLAB];
+    __shared__ float zsh[MAXK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e = blockIdx.x / DRAW_SLICES;
+    const int slice = blockIdx.x % DRAW_SLICES;
+    int s = seed_idx[e];
+    const bool bad = (s < 0 || s >= S);
+    if (bad) s = 0;
+    if (threadIdx.x < K)
+        zsh[threadIdx.x] = z2 ? z2[e * K + threadIdx.x] : philox_z(TAG_Z2, draw_id0 + e, threadIdx.x, seed);
+    const int i0 = (slice * 4 + wave) * 64;
+    const float* pd = pre_D + (int64_t)s * D * K;
+    if (i0 < D) draw_stage(pd, i0, K, lane, slabs + wave * SLAB);
+    __syncthreads();
+    const int i = i0 + lane;
+    if (i < D) {
+        float z1v = z1 ? z1[e * D + i] : philox_z(TAG_Z1, draw_id0 + e, i, seed);
+        float w = draw_row(w_avg + (int64_t)s * D, w2_avg + (int64_t)s * D, i, K, lane, slabs + wave * SLAB, zsh, z1v, c1, c2,
+                           scale);
+        W_out[e * D + i] = bad ? __builtin_nanf("") : w;
+    }
+}
+
+// The Philox form of the statistics epilogue on materialised (mu, std) pairs: the same per-evaluation routine as the forward
+// kernel's fused tail (bnn_stats.hip.h), one thread per evaluation.
+__global__ void bnn_stats_draw_kernel(const float* __restrict__ musd, int64_t R, int64_t B, StatsParams sp, uint64_t seed, int64_t row_id0,
+                                      int64_t sys_id0, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * B) return;
+    const int64_t r = i / B, b = i % B;
+    const f32x2 ms = *reinterpret_cast<const f32x2*>(musd + 2 * i);
+    out[i] = stats_draw(sp, ms.x, ms.y, row_id0 + r, sys_id0 + b, seed);
+}
+
+// ---- streaming quantile sketch ----------------------------------------------------------------------------------
+// Per simulation (= `group` consecutive systems; min over the group first, figures/multiswag_5_planet.py:428) a histogram over
+// piecewise-uniform bins plus float64 sum / sum of squares.  hist is bin-major [nbins][n_sims] so that the threads of a wave (one
+// simulation each) touch neighbouring words.  Bin 0 collects everything below the first segment.
+struct SketchSpec {
+    int32_t nseg, nbins;
+    float lo[4], hi[4], inv_w[4];
+    int32_t n[4], base[4];
+};
+
+DEVINL int sketch_bin(const SketchSpec& sk, float t) {
+    if (!(t >= sk.lo[0])) return 0;
+    int s = 0;
+    while (s + 1 < sk.nseg && t >= sk.hi[s]) ++s;
+    int k = (int)((t - sk.lo[s]) * sk.inv_w[s]);
+    k = k < 0 ? 0 : (k > sk.n[s] - 1 ? sk.n[s] - 1 : k);
+    return sk.base[s] + k;
+}
+
+__global__ void bnn_sketch_update_kernel(const float* __restrict__ tv, int64_t R, int64_t B, int group, SketchSpec sk, uint32_t* __restrict__ hist,
+                                         double* __restrict__ mom) {
+    const int64_t n_sims = B / group;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sims) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t r = 0; r < R; ++r) {
+        const float* p = tv + r * B + i * group;
+        float v = p[0];
+        for (int j = 1; j < group; ++j) {
+            const float w = p[j];
+            v = (w < v || w != w) ? w : v;  // np.min propagates NaN
+        }
+        hist[(int64_t)sketch_bin(sk, v) * n_sims + i] += 1u;
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+    }
+    mom[2 * i] += s1;
+    mom[2 * i + 1] += s2;
+}
+
+// numpy 'linear' percentiles from the sketch: order statistic k of a bin holding ranks c .. c+n-1 is placed at
+// edge + width * (k - c + 0.5) / n, so every estimate lies in the bin of the exact value (error < one bin width).
+struct SketchQ { double q[16]; int nq; };
+__global__ void bnn_sketch_quantiles_kernel(const uint32_t* __restrict__ hist, int64_t n_sims, SketchSpec sk, SketchQ qp, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sims) return;
+    uint64_t total = 0;
+    for (int b = 0; b < sk.nbins; ++b) total += hist[(int64_t)b * n_sims + i];
+    if (total == 0) {
+        for (int k = 0; k < qp.nq; ++k) out[i * qp.nq + k] = __builtin_nanf("");
+        return;
+    }
+    int64_t klo[16];
+    double frac[16], vlo[16], vhi[16];
+    for (int k = 0; k < qp.nq; ++k) {
+        const double vi = qp.q[k] / 100.0 * (double)(total - 1);
+        int64_t lo = (int64_t)floor(vi);
+        if (lo > (int64_t)total - 1) lo = (int64_t)total - 1;
+        klo[k] = lo;
+        frac[k] = vi - (double)lo;
+        vlo[k] = vhi[k] = 0.0;
+    }
+    uint64_t c = 0;
+    int seg = 0, kin = 0;  // position of bin b inside its segment
+    for (int b = 0; b < sk.nbins; ++b) {
+        const uint32_t n = hist[(int64_t)b * n_sims + i];
+        double edge, width;
+        if (b == 0) { edge = sk.lo[0]; width = 0.0; }
+        else {
+            while (b >= sk.base[seg] + sk.n[seg]) ++seg;
+            kin = b - sk.base[seg];
+            width = ((double)sk.hi[seg] - (double)sk.lo[seg]) / (double)sk.n[seg];
+            edge = (double)sk.lo[seg] + width * kin;
+        }
+        if (n) {
+            for (int k = 0; k < qp.nq; ++k) {
+                const int64_t a = klo[k], a1 = (a + 1 < (int64_t)total) ? a + 1 : a;
+                if (a >= (int64_t)c && a < (int64_t)(c + n)) vlo[k] = edge + width * ((double)(a - (int64_t)c) + 0.5) / (double)n;
+                if (a1 >= (int64_t)c && a1 < (int64_t)(c + n)) vhi[k] = edge + width * ((double)(a1 - (int64_t)c) + 0.5) / (double)n;
+            }
+        }
+        c += n;
+    }
+    for (int k = 0; k < qp.nq; ++k) out[i * qp.nq + k] = (float)(vlo[k] + (vhi[k] - vlo[k]) * frac[k]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -298,16 +416,12 @@ static int fail(int code, const std::string& msg) {
 struct bnn_plan {
     bnn_arch arch;
     Tables tab[2];  // [0] = arch mask, [1] = all 41 columns (noisy forward)
-    int16_t* d_f1[2] = {nullptr, nullptr};
-    int16_t* d_f2[2] = {nullptr, nullptr};
-    int16_t* d_f4 = nullptr;   // 4x4x1 image table for the plan's mask
+    int16_t* d_f2 = nullptr;   // regress_nn fragment gather table
+    int16_t* d_f4 = nullptr;   // feature_nn 4x4x1 image table for the plan's mask
     int16_t* d_f4n = nullptr;  // ... with every column live (noisy forward)
-    bool use_v4 = false;      // feature_nn on the 4x4x1 engine (v50 mask, quiet forward)
-    float* d_rcp = nullptr;  // [RCP_N] 1/(i+1)
+    float* d_rcp = nullptr;    // [RCP_N] 1/(i+1)
     int device = 0;
 };
-
-constexpr int RCP_N = 4096;  // supports T up to 16384 timesteps
 
 static int check_arch(const bnn_arch* a) {
     if (!a) return fail(BNN_ERR_INVALID, "arch is NULL");
@@ -334,6 +448,10 @@ int bnn_param_count(const bnn_arch* arch) {
     return rc ? rc : D;
 }
 
+static bool upload(const void* host, size_t bytes, void** dev) {
+    return hipMalloc(dev, bytes) == hipSuccess && hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice) == hipSuccess;
+}
+
 int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
     int rc = check_arch(arch);
     if (rc) return rc;
@@ -346,37 +464,14 @@ int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
         delete pl;
         return fail(BNN_ERR_NO_DEVICE, "no HIP device");
     }
-    for (int v = 0; v < 2; ++v) {
-        size_t n1 = pl->tab[v].f1.size() * sizeof(int16_t), n2 = pl->tab[v].f2.size() * sizeof(int16_t);
-        if (hipMalloc(&pl->d_f1[v], n1) != hipSuccess || hipMalloc(&pl->d_f2[v], n2) != hipSuccess ||
-            hipMemcpy(pl->d_f1[v], pl->tab[v].f1.data(), n1, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(pl->d_f2[v], pl->tab[v].f2.data(), n2, hipMemcpyHostToDevice) != hipSuccess) {
-            bnn_plan_destroy(pl);
-            return fail(BNN_ERR_HIP, "plan table upload failed");
-        }
-    }
-    if (!pl->tab[0].f4.empty()) {  // always, since the 41-input form of the 4x4x1 engine serves every mask
-        size_t n4 = pl->tab[0].f4.size() * sizeof(int16_t);
-        if (hipMalloc(&pl->d_f4, n4) != hipSuccess || hipMemcpy(pl->d_f4, pl->tab[0].f4.data(), n4, hipMemcpyHostToDevice) != hipSuccess) {
-            bnn_plan_destroy(pl);
-            return fail(BNN_ERR_HIP, "plan table upload failed");
-        }
-        size_t n4n = pl->tab[1].f4.size() * sizeof(int16_t);
-        if (hipMalloc(&pl->d_f4n, n4n) != hipSuccess || hipMemcpy(pl->d_f4n, pl->tab[1].f4.data(), n4n, hipMemcpyHostToDevice) != hipSuccess) {
-            bnn_plan_destroy(pl);
-            return fail(BNN_ERR_HIP, "plan table upload failed");
-        }
-        const char* kv = getenv("BNN_CHAOS_KERNEL");  // "16x16" forces the first engine (A/B runs)
-        pl->use_v4 = !(kv && std::string(kv) == "16x16");
-    }
-    {
-        std::vector<float> rc(RCP_N);
-        for (int i = 0; i < RCP_N; ++i) rc[i] = 1.0f / (float)(i + 1);
-        if (hipMalloc(&pl->d_rcp, RCP_N * sizeof(float)) != hipSuccess ||
-            hipMemcpy(pl->d_rcp, rc.data(), RCP_N * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-            bnn_plan_destroy(pl);
-            return fail(BNN_ERR_HIP, "plan table upload failed");
-        }
+    std::vector<float> rcp(RCP_N);
+    for (int i = 0; i < RCP_N; ++i) rcp[i] = 1.0f / (float)(i + 1);
+    if (!upload(pl->tab[0].f2.data(), pl->tab[0].f2.size() * sizeof(int16_t), (void**)&pl->d_f2) ||
+        !upload(pl->tab[0].f4.data(), pl->tab[0].f4.size() * sizeof(int16_t), (void**)&pl->d_f4) ||
+        !upload(pl->tab[1].f4.data(), pl->tab[1].f4.size() * sizeof(int16_t), (void**)&pl->d_f4n) ||
+        !upload(rcp.data(), RCP_N * sizeof(float), (void**)&pl->d_rcp)) {
+        bnn_plan_destroy(pl);
+        return fail(BNN_ERR_HIP, "plan table upload failed");
     }
     *out = pl;
     return 0;
@@ -384,25 +479,17 @@ int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
 
 int bnn_plan_destroy(bnn_plan* pl) {
     if (!pl) return 0;
-    for (int v = 0; v < 2; ++v) {
-        if (pl->d_f1[v]) (void)hipFree(pl->d_f1[v]);
-        if (pl->d_f2[v]) (void)hipFree(pl->d_f2[v]);
-    }
-    if (pl->d_rcp) (void)hipFree(pl->d_rcp);
+    if (pl->d_f2) (void)hipFree(pl->d_f2);
     if (pl->d_f4) (void)hipFree(pl->d_f4);
     if (pl->d_f4n) (void)hipFree(pl->d_f4n);
+    if (pl->d_rcp) (void)hipFree(pl->d_rcp);
     delete pl;
     return 0;
 }
 
 int bnn_plan_layer_order(const bnn_plan* pl, int layer, int noisy, int32_t* host_order, int cap) {
     if (!pl || layer < 0 || layer > 5) return fail(BNN_ERR_INVALID, "bad plan/layer");
-    std::vector<int32_t> o = pl->tab[noisy ? 1 : 0].order[layer];
-    if (pl->use_v4 && layer < 3) {  // 4x4x1 engine: bias first, then inputs in ascending order
-        o.clear();
-        for (int k = 0; k < (layer == 0 ? F : H); ++k)
-            if (layer != 0 || noisy || !((pl->arch.zero_mask >> k) & 1ull)) o.push_back(k);
-    }
+    const std::vector<int32_t>& o = pl->tab[noisy ? 1 : 0].order[layer];
     if (host_order)
         for (int i = 0; i < (int)o.size() && i < cap; ++i) host_order[i] = o[i];
     return (int)o.size();
@@ -422,9 +509,9 @@ int bnn_layer_order(const bnn_arch* arch, int layer, int noisy, int32_t* host_or
 int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host_table, int cap) {
     int rc = check_arch(arch);
     if (rc) return rc;
-    if (which != 1 && which != 2) return fail(BNN_ERR_INVALID, "which must be 1 or 2");
+    if (which != 1 && which != 2) return fail(BNN_ERR_INVALID, "which must be 1 (feature_nn images) or 2 (regress_nn fragments)");
     Tables t = build_tables(arch->zero_mask, noisy != 0);
-    const std::vector<int16_t>& v = which == 1 ? t.f1 : t.f2;
+    const std::vector<int16_t>& v = which == 1 ? t.f4 : t.f2;
     if (host_table)
         for (int i = 0; i < (int)v.size() && i < cap; ++i) host_table[i] = v[i];
     return (int)v.size();
@@ -441,23 +528,6 @@ static int pick_spc(const bnn_grid* g, int64_t csz) {
     return 64;
 }
 
-constexpr int MAX_DEVICES = 64;
-
-static int current_device_slot() {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    return (dev >= 0 && dev < MAX_DEVICES) ? dev : 0;
-}
-
-static size_t exp_lds_pad() {  // experiments only: BNN_EXP_LDS_PAD=bytes lowers the occupancy (one workgroup per CU above ~12 KB)
-#if BNN_EXP & 4
-    const char* e = getenv("BNN_EXP_LDS_PAD");
-    return e ? (size_t)atoi(e) : 0;
-#else
-    return 0;
-#endif
-}
-
 static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, bool fused, bool noisy, void* stream) {
     if (!pl || !g) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
     if (g->B < 0 || g->J < 0 || g->nchunks < 1) return fail(BNN_ERR_INVALID, "negative size");
@@ -465,62 +535,27 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     if (g->T < 8 || (g->T % 4) || g->T / 4 > RCP_N) return fail(BNN_ERR_UNSUPPORTED, "T must be a multiple of 4 in [8, 16384]");
     if (g->systems_per_block < 0 || (g->systems_per_block % 64)) return fail(BNN_ERR_INVALID, "systems_per_block must be a multiple of 64");
     if (g->B == 0 || g->J == 0) return 0;
-    if (!p.x || !p.out) return fail(BNN_ERR_INVALID, "x/out is NULL");
+    if (!p.x || !(p.out || p.sink)) return fail(BNN_ERR_INVALID, "x/out is NULL");
     if (p.draw_id0 % g->nchunks) return fail(BNN_ERR_INVALID, "draw_id0 must be a multiple of nchunks");
-    const int v = noisy ? 1 : 0;
     p.B = g->B; p.T = g->T; p.ntiles = g->T / 4; p.J = g->J; p.nch = g->nchunks;
     p.csz = (g->B + g->nchunks - 1) / g->nchunks;
     p.spc = pick_spc(g, p.csz);
     p.row_id0 = p.draw_id0 / g->nchunks;
-    p.tab_f1 = pl->d_f1[v]; p.tab_f2 = pl->d_f2[v]; p.tab_f4 = pl->d_f4; p.rcp_tab = pl->d_rcp;
+    p.tab_f2 = pl->d_f2; p.tab_f4 = noisy ? pl->d_f4n : pl->d_f4; p.rcp_tab = pl->d_rcp;
     p.zero_mask = pl->arch.zero_mask;
     p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);
     const int64_t nsub = (p.csz + p.spc - 1) / p.spc;
     const int64_t nblk = nsub * g->J;
     if (nblk > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "grid too large; split the draws");
-    const size_t shmem = sizeof(float) * (FLAT_LDS + MAXK);
     static_assert(NF2 * 64 <= FLAT_LDS, "regress_nn fragments overwrite the flat vector in place");
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)nblk), block(256);
-    const int nk1 = pl->tab[v].nk1;
-#define LAUNCH(NK, NZ, FU)                                                                                         \
-    do {                                                                                                           \
-        static std::once_flag once[MAX_DEVICES];  /* the attribute belongs to the (function, device) pair */     \
-        std::call_once(once[current_device_slot()], [] {                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag_kernel<NK, NZ, FU>),            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
-        });                                                                                                        \
-        hipLaunchKernelGGL((bnn_multiswag_kernel<NK, NZ, FU>), grid, block, shmem, st, p);                         \
-    } while (0)
-    if (pl->use_v4) {
-#define LAUNCH4(KI, FU, NZ)                                                                                        \
-    do {                                                                                                           \
-        static std::once_flag once[MAX_DEVICES];                                                                   \
-        std::call_once(once[current_device_slot()], [] {                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_multiswag4_kernel<KI, FU, NZ>),           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
-        });                                                                                                        \
-        const size_t shmem4 = sizeof(float) * (FLAT_LDS + MAXK + W4<KI>::PAD + 4 * SCR4 + NSC4) + exp_lds_pad();   \
-        hipLaunchKernelGGL((bnn_multiswag4_kernel<KI, FU, NZ>), grid, block, shmem4, st, p);                       \
-    } while (0)
-        if (noisy) {
-            p.tab_f4 = pl->d_f4n;  // all 41 columns live: masked inputs carry pure noise
-            LAUNCH4(41, false, true);
-        } else if (pl->tab[0].kin4 == 31) {
-            if (fused) LAUNCH4(31, true, false); else LAUNCH4(31, false, false);
-        } else {
-            if (fused) LAUNCH4(41, true, false); else LAUNCH4(41, false, false);
-        }
-#undef LAUNCH4
-    } else if (noisy) {
-        LAUNCH(11, true, false);
-    } else if (nk1 == 8) {
-        if (fused) LAUNCH(8, false, true); else LAUNCH(8, false, false);
-    } else {
-        if (fused) LAUNCH(11, false, true); else LAUNCH(11, false, false);
-    }
-#undef LAUNCH
-    HIP_TRY(hipGetLastError());
+    const bool k31 = pl->tab[0].kin4 == 31;
+    hipError_t e;
+    if (p.sink) e = launch_fwd_stats(k31, (unsigned)nblk, st, p);
+    else if (noisy) e = launch_fwd_noisy((unsigned)nblk, st, p);
+    else if (k31) e = launch_fwd_k31(fused, (unsigned)nblk, st, p);
+    else e = launch_fwd_k41(fused, (unsigned)nblk, st, p);
+    if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("forward kernel launch: ") + hipGetErrorString(e));
     return 0;
 }
 
@@ -542,7 +577,8 @@ int bnn_swag_draw_f32(const bnn_plan* plan, const float* w_avg, const float* w2_
     int rc = draw_consts(K, scale, &c1, &c2);
     if (rc) return rc;
     if (J == 0) return 0;
-    dim3 grid((D + 255) / 256, J), block(256);
+    if ((int64_t)J * DRAW_SLICES > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many draws for one launch");
+    dim3 grid((unsigned)((int64_t)J * DRAW_SLICES)), block(256);
     hipLaunchKernelGGL(bnn_swag_draw_kernel, grid, block, 0, (hipStream_t)stream, w_avg, w2_avg, pre_D, S, K, seed_idx, z1, z2, c1,
                        c2, scale, philox_seed, draw_id0, W_out);
     HIP_TRY(hipGetLastError());
@@ -662,10 +698,11 @@ int bnn_quantiles_f32(const float* samples, int64_t R, int64_t B, const double* 
     }
     int npad = 2;
     while (npad < R) npad <<= 1;
-    static std::once_flag once[MAX_DEVICES];
-    std::call_once(once[current_device_slot()], [] {
+    static bool attr_set[MAX_DEVICES];
+    if (!attr_set[current_device_slot()]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_quantiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    });
+        attr_set[current_device_slot()] = true;
+    }
     if (2 * B > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many systems for one launch");
     hipLaunchKernelGGL(bnn_quantiles_kernel, dim3((unsigned)(2 * B)), dim3(256), (size_t)npad * sizeof(float), (hipStream_t)stream, samples, R,
                        B, npad, qp, out);
@@ -689,8 +726,9 @@ int bnn_feature_pack_f64(const double* tseries, const double* mass, const double
 }
 
 int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments, int32_t accumulate, void* stream) {
-    if (!samples || !moments || R < 0 || B < 0) return fail(BNN_ERR_INVALID, "bad argument");
-    if (B == 0) return 0;
+    if (R < 0 || B < 0) return fail(BNN_ERR_INVALID, "bad argument");
+    if (B == 0) return 0;  // an empty shard (more ranks than systems) has NULL data pointers
+    if (!samples || !moments) return fail(BNN_ERR_INVALID, "bad argument");
     hipLaunchKernelGGL(bnn_moments_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64, 16), 0, (hipStream_t)stream, samples, R, B, moments,
                        accumulate);
     HIP_TRY(hipGetLastError());
@@ -714,6 +752,117 @@ int bnn_philox_raw_u32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
     if (n == 0) return 0;
     hipLaunchKernelGGL(bnn_philox_raw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c0, c1, c2, c3, k0, k1,
                        n, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- streaming statistics epilogue ----------------------------------------------------------------------------------
+static int stats_params(const bnn_stats* st, StatsParams* sp) {
+    if (!st) return fail(BNN_ERR_INVALID, "stats is NULL");
+    if (st->tn_nsamp < 1 || st->tn_nsamp > 4096) return fail(BNN_ERR_RANGE, "tn_nsamp must be in [1, 4096]");
+    const bool prior = st->prior_thr < INFINITY;
+    if (prior && (!st->prior_surv || st->prior_m < 2 || !(st->prior_step > 0.0f))) return fail(BNN_ERR_INVALID, "prior table missing");
+    sp->tn_nsamp = st->tn_nsamp; sp->tn_left = st->tn_left; sp->prior_thr = st->prior_thr;
+    sp->prior_surv = st->prior_surv; sp->prior_m = st->prior_m; sp->prior_step = st->prior_step;
+    return 0;
+}
+
+int bnn_prior_table_f32(double thr, double top, int32_t m, float* host_surv, double* host_step) {
+    if (m < 2 || !(top > thr) || !host_surv || !host_step) return fail(BNN_ERR_INVALID, "bad prior table request");
+    // figures/multiswag_5_planet.py:400-404: p(t) ~ a exp(-b t) - c exp(-d t^2); G(t) = integral of p from t to infinity
+    const double a = 3.27086190404742, b = 0.424033970670719, c = 10.8793430454878, d = 0.200351029031774;
+    auto G = [&](double t) { return a / b * std::exp(-b * t) - c * 0.5 * std::sqrt(M_PI / d) * std::erfc(std::sqrt(d) * t); };
+    const double g0 = G(thr), step = (top - thr) / (double)(m - 1);
+    for (int i = 0; i < m; ++i) host_surv[i] = (float)(G(thr + step * i) / g0);
+    host_surv[0] = 1.0f;
+    *host_step = step;
+    return 0;
+}
+
+int bnn_stats_draw_f32(const float* musd, int64_t R, int64_t B, const bnn_stats* st, uint64_t philox_seed, int64_t row_id0,
+                       int64_t system_id0, float* out, void* stream) {
+    if (R < 0 || B < 0) return fail(BNN_ERR_INVALID, "bad R/B");
+    StatsParams sp;
+    int rc = stats_params(st, &sp);
+    if (rc) return rc;
+    if (R == 0 || B == 0) return 0;
+    if (!musd || !out) return fail(BNN_ERR_INVALID, "NULL argument");
+    const int64_t n = R * B;
+    if ((n + 255) / 256 > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many evaluations for one launch");
+    hipLaunchKernelGGL(bnn_stats_draw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, musd, R, B, sp, philox_seed,
+                       row_id0, system_id0, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bnn_multiswag_stats_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg, const float* w2_avg,
+                            const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx, const float* z1, const float* z2,
+                            const float* eps, float scale, uint64_t philox_seed, int64_t draw_id0, int64_t system_id0,
+                            float* W_workspace, const bnn_stats* st, float* t_out, void* stream) {
+    if (!plan || !grid) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
+    StatsParams sp;
+    int rc = stats_params(st, &sp);
+    if (rc) return rc;
+    if (grid->B == 0 || grid->J == 0) return 0;
+    if (!w_avg || !w2_avg || !pre_D || !seed_idx || !W_workspace || !t_out) return fail(BNN_ERR_INVALID, "NULL argument (the statistics form needs a draw workspace)");
+    rc = bnn_swag_draw_f32(plan, w_avg, w2_avg, pre_D, S, K, seed_idx, grid->J, z1, z2, scale, philox_seed, draw_id0, W_workspace, stream);
+    if (rc) return rc;
+    FwdParams p{};
+    p.x = x; p.W = W_workspace; p.eps = eps;
+    p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
+    p.sink = t_out; p.st = sp;
+    return launch_forward(plan, grid, p, false, false, stream);
+}
+
+static int sketch_spec(const bnn_sketch* sk, SketchSpec* out) {
+    if (!sk || sk->nseg < 1 || sk->nseg > 4) return fail(BNN_ERR_INVALID, "sketch needs 1..4 segments");
+    SketchSpec s{};
+    s.nseg = sk->nseg;
+    int base = 1;  // bin 0 = below the first segment
+    for (int i = 0; i < sk->nseg; ++i) {
+        if (sk->n[i] < 1 || !(sk->hi[i] > sk->lo[i]) || (i && sk->lo[i] != sk->hi[i - 1])) return fail(BNN_ERR_INVALID, "sketch segments must be ascending and contiguous");
+        s.lo[i] = sk->lo[i]; s.hi[i] = sk->hi[i]; s.n[i] = sk->n[i]; s.base[i] = base;
+        s.inv_w[i] = (float)((double)sk->n[i] / ((double)sk->hi[i] - (double)sk->lo[i]));
+        base += sk->n[i];
+    }
+    s.nbins = base;
+    *out = s;
+    return 0;
+}
+
+int bnn_sketch_bins(const bnn_sketch* sk) {
+    SketchSpec s;
+    int rc = sketch_spec(sk, &s);
+    return rc ? rc : s.nbins;
+}
+
+int bnn_sketch_update_u32(const float* t, int64_t R, int64_t B, int32_t group, const bnn_sketch* sk, uint32_t* hist, double* mom, void* stream) {
+    SketchSpec s;
+    int rc = sketch_spec(sk, &s);
+    if (rc) return rc;
+    if (R < 0 || B < 0 || group < 1 || (B % group)) return fail(BNN_ERR_INVALID, "B must be a multiple of group");
+    if (R == 0 || B == 0) return 0;
+    if (!t || !hist || !mom) return fail(BNN_ERR_INVALID, "NULL argument");
+    const int64_t n_sims = B / group;
+    hipLaunchKernelGGL(bnn_sketch_update_kernel, dim3((unsigned)((n_sims + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, R, B, (int)group, s, hist, mom);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bnn_sketch_quantiles_f32(const uint32_t* hist, int64_t n_sims, const bnn_sketch* sk, const double* host_q, int32_t nq, float* out, void* stream) {
+    SketchSpec s;
+    int rc = sketch_spec(sk, &s);
+    if (rc) return rc;
+    if (n_sims < 0 || nq < 1 || nq > 16 || !host_q) return fail(BNN_ERR_INVALID, "bad argument");
+    if (n_sims == 0) return 0;
+    if (!hist || !out) return fail(BNN_ERR_INVALID, "NULL argument");
+    SketchQ qp;
+    qp.nq = nq;
+    for (int i = 0; i < nq; ++i) {
+        if (!(host_q[i] >= 0.0 && host_q[i] <= 100.0)) return fail(BNN_ERR_RANGE, "percentiles must be in [0, 100]");
+        qp.q[i] = host_q[i];
+    }
+    hipLaunchKernelGGL(bnn_sketch_quantiles_kernel, dim3((unsigned)((n_sims + 127) / 128)), dim3(128), 0, (hipStream_t)stream, hist, n_sims, s, qp, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -1,7 +1,13 @@
-// bnn_common.hip.h -- shared device code of the MultiSWAG kernels: vector types, build switches, Philox4x32-10
-// normals, kernel parameters, MFMA/ReLU helpers, and the SWAG draw (SWAGModel.sample_weights,
-// spock_reg_model.py:815-838) as a kernel and as a workgroup-prologue routine.  Included by bnn_kernels.hip only.
+// bnn_common.hip.h -- device code shared by the kernel translation units: vector types, Philox4x32-10 and the normals
+// derived from it, MFMA / ReLU helpers, and the SWAG draw (SWAGModel.sample_weights, spock_reg_model.py:815-838) as a
+// per-row routine used by the draw kernel and by the forward kernel's in-prologue draw.
 #pragma once
+#include <hip/hip_runtime.h>
+
+#include "bnn_internal.h"
+
+namespace bnn {
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -11,37 +17,12 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
 #define DEVINL __device__ __forceinline__
 
-#ifndef BNN_PRIO_STAGGER
-#define BNN_PRIO_STAGGER 0
-#endif
-#ifndef BNN_STAMPS
-#define BNN_STAMPS 0  // diagnostic build: wave 0 of each workgroup of the 4x4x1 kernel sums s_memtime deltas per phase
-#endif                // into the pre_clamp buffer (as uint64 [block][12]); never enabled in the shipped library
-#if BNN_STAMPS
-#define STAMP(i)                                                                 \
-    do {                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                       \
-        unsigned long long _t;                                                   \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); \
-        st_acc[i] += _t - st_prev;                                               \
-        st_prev = _t;                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                       \
-    } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
-#ifndef BNN_EXP
-#define BNN_EXP 0  // timing experiments (wrong results when non-zero)
-#endif
-#ifndef BNN_WAVES_PER_SIMD
-#define BNN_WAVES_PER_SIMD 3  // register budget of the 16x16x4 kernel: 2 -> 256 VGPRs, 3 -> 168 (+3 % measured)
-#endif
-
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11) and the normals derived from it.
 // Counters use GLOBAL draw / output-row / system ids, so results are invariant to sharding.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t TAG_Z1 = 0x10000000u, TAG_Z2 = 0x20000000u, TAG_EPS = 0x30000000u, TAG_IN = 0x40000000u, TAG_SUM = 0x50000000u;
+constexpr uint32_t TAG_Z1 = 0x10000000u, TAG_Z2 = 0x20000000u, TAG_EPS = 0x30000000u, TAG_IN = 0x40000000u, TAG_SUM = 0x50000000u,
+                   TAG_TN = 0x60000000u, TAG_U = 0x70000000u, TAG_TNS = 0x80000000u, TAG_US = 0x90000000u;
 
 DEVINL uint4 philox4x32_10(uint4 c, uint2 k) {
 #pragma unroll
@@ -81,51 +62,56 @@ DEVINL float philox_z(uint32_t tag, int64_t draw, int elem, uint64_t seed) {
     f32x4 n = philox_normal4(tag | (uint32_t)(elem >> 2), (uint32_t)draw, (uint32_t)((uint64_t)draw >> 32), 0u, seed);
     return n[elem & 3];
 }
-// eps[row][sys][kind][n], quad = (kind*20 + n) / 4: counter = (tag | quad, sys lo, sys hi16 | row hi16 << 16, row lo)
-DEVINL f32x4 philox_sys4(uint32_t tag, int64_t row, int64_t sys, int quad, uint64_t seed) {
+// per-(output row, system) streams: counter = (tag | quad, sys lo, sys hi16 | row hi16 << 16, row lo)
+DEVINL uint4 philox_sys_ctr(uint32_t tag, int64_t row, int64_t sys, int quad) {
     uint32_t c2 = (uint32_t)(((uint64_t)sys >> 32) & 0xffffu) | ((uint32_t)(((uint64_t)row >> 32) & 0xffffu) << 16);
-    return philox_normal4(tag | (uint32_t)quad, (uint32_t)sys, c2, (uint32_t)row, seed);
+    return make_uint4(tag | (uint32_t)quad, (uint32_t)sys, c2, (uint32_t)row);
+}
+// eps[row][sys][kind][n], quad = (kind*20 + n) / 4
+DEVINL f32x4 philox_sys4(uint32_t tag, int64_t row, int64_t sys, int quad, uint64_t seed) {
+    uint4 c = philox_sys_ctr(tag, row, sys, quad);
+    return philox_normal4(c.x, c.y, c.z, c.w, seed);
 }
 DEVINL f32x4 philox_eps4(int64_t row, int64_t sys, int quad, uint64_t seed) { return philox_sys4(TAG_EPS, row, sys, quad, seed); }
-// input noise eps_in[row][sys][t][col] (:445): quad = t*11 + col/4 (rows padded to 44 so quads align with 4-column groups);
 // summary noise eps_sum[row][sys][n] (:449): quad = n/4.
 
-// ------------------------------------------------------------------------------------------------
-// kernel parameters
-// ------------------------------------------------------------------------------------------------
-struct FwdParams {
-    const float* x;
-    int64_t B;
-    int32_t T, ntiles;
-    int32_t J, nch;
-    int64_t csz;
-    int32_t spc;  // systems per workgroup (multiple of 64)
-    int32_t K, S;
-    const float* W;  // [J,d] materialised draws (unfused) or nullptr
-    const float* w_avg;
-    const float* w2_avg;
-    const float* pre_D;
-    const int32_t* seed_idx;
-    const float* z1;
-    const float* z2;
-    float c1, c2, scale;
-    const float* eps;
-    const float* eps_in;
-    const float* eps_sum;
-    uint64_t seed;
-    int64_t draw_id0, row_id0, sys_id0;
-    float* out;
-    float* pre_clamp;
-    float* summary;
-    const int16_t* tab_f1;
-    const int16_t* tab_f2;
-    const int16_t* tab_f4;  // 4x4x1 image gather table (v50 mask) or nullptr
-    const float* rcp_tab;  // [i] = 1/(i+1), correctly rounded
-    uint64_t zero_mask;
-    float std_lo, std_span;
-};
+// The input noise of forward(noisy_val=True) (:445) is 4 100 normals per evaluation and, next to v_mfma_f32_4x4x1 (which holds
+// the SIMD's vector issue port for its whole duration: profiles/r02_coexec2_probe.txt), every vector cycle spent on it is paid in
+// full.  So this stream takes SIX normals from each Philox block instead of four: the 128 bits are cut into six 21-bit
+// uniforms; a uniform becomes a float in [1, 2) with ONE shift/align + ONE and-or on the bit pattern (no int->float convert,
+// 8 issue cycles on this chip): the angle is used as it stands (v_sin / v_cos take revolutions and are periodic), the radius
+// level is 2 - f in (0, 1).  Normals reach 5.4 sigma; 2^21 distinct angles.
+// eps_in[row][sys][t][col]: block = t*7 + col/6, normal col%6 of the block.
+constexpr int NIN_PER_BLOCK = 6, NIN_BLOCKS = 7;  // 7 blocks x 6 >= 41 columns
+DEVINL float unit21(uint32_t aligned) {  // bits [22:2] of `aligned` are the 21-bit field; +half a step so that f is never 1 or 2
+    return __builtin_bit_cast(float, (aligned & 0x007FFFFCu) | 0x3F800002u);
+}
+DEVINL f32x2 box_muller21(float f_radius, float f_angle) {
+    const float u1 = 2.0f - f_radius;
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln2 log2 u1)
+    f32x2 o;
+    o.x = r * __builtin_amdgcn_cosf(f_angle);
+    o.y = r * __builtin_amdgcn_sinf(f_angle);
+    return o;
+}
+DEVINL void philox_normal6(uint4 ctr, uint64_t seed, float (&n)[6]) {
+    const uint4 r = philox4x32_10(ctr, make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    // fields (bit offsets in the 128-bit block x:y:z:w, little end first): 0, 21, 42, 63, 84, 105 -- each moved to bits [22:2]
+    const float f0 = unit21(r.x << 2);
+    const float f1 = unit21(__builtin_amdgcn_alignbit(r.y, r.x, 19));
+    const float f2 = unit21(r.y >> 8);
+    const float f3 = unit21(__builtin_amdgcn_alignbit(r.z, r.y, 29));
+    const float f4 = unit21(__builtin_amdgcn_alignbit(r.w, r.z, 18));
+    const float f5 = unit21(r.w >> 7);
+    const f32x2 a = box_muller21(f0, f1), b = box_muller21(f2, f3), c = box_muller21(f4, f5);
+    n[0] = a.x; n[1] = a.y; n[2] = b.x; n[3] = b.y; n[4] = c.x; n[5] = c.y;
+}
+DEVINL void philox_in6(int64_t row, int64_t sys, int block, uint64_t seed, float (&n)[6]) {
+    philox_normal6(philox_sys_ctr(TAG_IN, row, sys, block), seed, n);
+}
 
 DEVINL f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+DEVINL f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
 // nn.ReLU as ONE integer max on the bit pattern: negative floats (and -0.0) are negative ints -> +0.0.
 DEVINL float relu1(float v) {
@@ -138,6 +124,19 @@ DEVINL f32x4 relu4(f32x4 v) {
     f32x4 o = v;
 #pragma unroll
     for (int i = 0; i < NLIVE; ++i) o[i] = relu1(v[i]);
+    return o;
+}
+
+template <int CTRL>
+DEVINL float quad_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// predict_instability's soft_clamp (:295-296, :437-442)
+DEVINL f32x2 soft_clamp2(float r0, float r1, float std_lo, float std_span) {
+    f32x2 o;
+    o.x = (0.5f * (tanhf(r0) + 1.0f)) * 8.0f + 4.0f;
+    o.y = (0.5f * (tanhf(r1) + 1.0f)) * std_span + std_lo;
     return o;
 }
 
@@ -199,30 +198,4 @@ DEVINL float draw_row_direct(const float* __restrict__ w_avg_s, const float* __r
     return w + t2;
 }
 
-__global__ __launch_bounds__(256) void bnn_swag_draw_kernel(const float* __restrict__ w_avg, const float* __restrict__ w2_avg,
-                                                            const float* __restrict__ pre_D, int S, int K,
-                                                            const int32_t* __restrict__ seed_idx, const float* __restrict__ z1,
-                                                            const float* __restrict__ z2, float c1, float c2, float scale,
-                                                            uint64_t seed, int64_t draw_id0, float* __restrict__ W_out) {
-    __shared__ float slabs[4 * SLAB];
-    __shared__ float zsh[MAXK];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = blockIdx.y;
-    int s = seed_idx[e];
-    const bool bad = (s < 0 || s >= S);
-    if (bad) s = 0;
-    if (threadIdx.x < K)
-        zsh[threadIdx.x] = z2 ? z2[(int64_t)e * K + threadIdx.x] : philox_z(TAG_Z2, draw_id0 + e, threadIdx.x, seed);
-    const int i0 = (blockIdx.x * 4 + wave) * 64;
-    const float* pd = pre_D + (int64_t)s * D * K;
-    if (i0 < D) draw_stage(pd, i0, K, lane, slabs + wave * SLAB);
-    __syncthreads();
-    const int i = i0 + lane;
-    if (i < D) {
-        float z1v = z1 ? z1[(int64_t)e * D + i] : philox_z(TAG_Z1, draw_id0 + e, i, seed);
-        float w = draw_row(w_avg + (int64_t)s * D, w2_avg + (int64_t)s * D, i, K, lane, slabs + wave * SLAB, zsh, z1v, c1, c2,
-                           scale);
-        W_out[(int64_t)e * D + i] = bad ? __builtin_nanf("") : w;
-    }
-}
-
+}  // namespace bnn

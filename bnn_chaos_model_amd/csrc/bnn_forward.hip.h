@@ -1,23 +1,22 @@
-// bnn_engine_b.hip.h -- feature_nn engine B: v_mfma_f32_4x4x1_16b_f32, no padding, weights streamed from packed
-// LDS images.  Included by bnn_kernels.hip after bnn_engine_a.hip.h (shares its tail helpers).
-#pragma once
-// ------------------------------------------------------------------------------------------------
-// Second feature_nn engine: v_mfma_f32_4x4x1_16b_f32 (bnn_layout.h, "second operand layout").
-// lane = row, so there is no padding anywhere: 310 + 400 + 200 = 910 MFMAs of 8 cycles per 64 rows (113.75 pipe
-// cycles per row against 148 for the 16x16x4 tiling).  Weights stream from an LDS image with broadcast
-// ds_read_b128 (one read feeds four MFMAs; LDS reads do not occupy the fp32 pipe), activations never leave
-// registers: a layer's accumulator registers are the next layer's B operands as they stand.
+// bnn_forward.hip.h -- the forward kernel of the MultiSWAG path: feature_nn on
+// v_mfma_f32_4x4x1_16b_f32 with weights streamed from packed LDS images, time pool, sampled moments, regress_nn, soft_clamp,
+// optionally the in-prologue SWAG draw (FUSED), forward(noisy_val=True) (NOISY) or the fused statistics tail (STATS).
+// Included by the bnn_fwd_*.hip translation units, each of which instantiates a few of the template's forms.
+//
+// lane = row, so there is no padding anywhere: 310 + 400 + 200 = 910 MFMAs of 8 cycles per 64 rows (113.75 pipe cycles per
+// row against 148 for a 16x16x4 tiling).  Weights stream from an LDS image with broadcast ds_read_b128 (one read feeds four
+// MFMAs), activations never leave registers: a layer's accumulator registers are the next layer's B operands as they stand.
 // A wave owns 16 systems at a time: lane l = system l>>2, timestep phase l&3; tile `it` = timesteps 4it..4it+3.
 // Accumulation order per output = bias, then inputs in ascending order: the oracle's natural order.
-// KIN = 31: the v50 column mask (31 live columns); KIN = 41: any mask (whole rows, zero weights); NOISY: forward(noisy_val=True).  Everything after the time pool (sampled
-// moments, regress_nn on the 16x16x4 path, soft_clamp) is shared with the first kernel.
-// ------------------------------------------------------------------------------------------------
-DEVINL f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+// KIN = 31: the v50 column mask (31 live columns); KIN = 41: any mask (whole rows, zero weights on masked columns).
+// The 4x4x1 MFMA holds the SIMD's vector issue port for all of its 8 cycles (profiles/r02_coexec2_probe.txt): nothing
+// co-issues with it, from either wave of the SIMD, so the kernel's time is the SUM of its matrix and vector instructions and the
+// loop below is written to need as few vector instructions as the arithmetic allows.
+#pragma once
+#include "bnn_common.hip.h"
+#include "bnn_stats.hip.h"
 
-template <int CTRL>
-DEVINL float quad_perm(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
+namespace bnn {
 
 template <int KIN>
 DEVINL void load_row(const float* __restrict__ rp, float (&xv)[KIN]) {
@@ -41,19 +40,21 @@ DEVINL void load_row(const float* __restrict__ rp, float (&xv)[KIN]) {
 }
 
 constexpr int SCR4 = 2 * 16 * S2;  // floats of LDS scratch per wave: Philox normals + summaries of 16 systems
+constexpr int NSC4 = 96;           // LDS floats for the noise scales of the noisy forward: exp(logvar/2) for 41 inputs + 40 summaries
 
-constexpr int NSC4 = 96;  // LDS floats for the noise scales of the noisy forward: exp(logvar/2) for 41 inputs + 40 summaries
+template <int KIN>
+constexpr size_t fwd_lds_bytes() { return sizeof(float) * (FLAT_LDS + MAXK + W4<KIN>::PAD + 4 * SCR4 + NSC4); }
 
-template <int KIN, bool FUSED, bool NOISY = false>
-__global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams p) {
+template <int KIN, bool FUSED, bool NOISY, bool STATS>
+__global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) {
     using LY = W4<KIN>;
-    static_assert(!NOISY || (KIN == F && !FUSED), "the noisy forward multiplies all 41 columns and takes materialised weights");
+    static_assert(!NOISY || (KIN == F && !FUSED && !STATS), "the noisy forward multiplies all 41 columns and takes materialised weights");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot, later ...
     float* f2frag = lds;               // ... [NF2][64] regress_nn operands in fragment order
     float* zsh = lds + FLAT_LDS;       // [MAXK]
     float* wl = zsh + MAXK;            // [LY::PAD] feature_nn images for the 4x4x1 operands
-    float* scr = wl + LY::PAD;          // [4][SCR4]
+    float* scr = wl + LY::PAD;         // [4][SCR4]
     float* nsc = scr + 4 * SCR4;       // [NSC4] (NOISY only)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -61,21 +62,20 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
     const int g = lane >> 4, c = lane & 15;   // regress_nn (16x16x4) coordinates
     const int sl = lane >> 2, ph = lane & 3;  // feature_nn (4x4x1) coordinates: system in the wave-batch, timestep phase
 
+    // work item: draw e, block `sub` of its chunk of systems (torch.chunk semantics).  Draw-fastest block order: workgroups that
+    // are resident together work on the SAME systems under different draws, so x comes from HBM about once and from L2 after that.
     const int64_t id = blockIdx.x;
     const int e = (int)(id % p.J);
     const int64_t sub = id / p.J;
     const int ch = e % p.nch;
-    const int64_t r = e / p.nch;
+    const int64_t r = e / p.nch;  // output row
     const int64_t seg0 = (int64_t)ch * p.csz;
     const int64_t seg1 = (seg0 + p.csz < p.B) ? seg0 + p.csz : p.B;
     const int64_t b0 = seg0 + sub * p.spc;
     const int64_t b1 = (b0 + p.spc < seg1) ? b0 + p.spc : seg1;
     if (b0 >= b1) return;
 
-#if BNN_STAMPS
-    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
-#endif
+    // ---- prologue: flat parameter vector of draw e -> LDS -> operand images
     bool bad_seed = false;
     if constexpr (FUSED) {
         int s = p.seed_idx[e];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
     if constexpr (NOISY) {  // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
         if (tid < F + S2) nsc[tid] = expf(flat[OFF_INLV + tid] / 2.0f);
     }
-    {
+    {   // regress_nn operands replace the flat vector in place: gather to registers, barrier, write
         constexpr int PER = (NF2 + 3) / 4;
         float tmp[PER];
 #pragma unroll
@@ -118,7 +118,6 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
         __syncthreads();
     }
 
-    STAMP(0);  // prologue
     const int T = p.T, ntiles = p.ntiles;
     const float nm1 = (float)(T - 1), nT = (float)T;
     const float half_n0 = (float)ntiles * 0.5f;
@@ -148,32 +147,7 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
         float xv[KIN];
         load_row<KIN>(rowp, xv);
         asm volatile("" ::: "memory");
-        STAMP(1);  // batch setup + first row load issue
         for (int it = 0; it < ntiles; ++it) {
-            if constexpr (NOISY) {
-                // masks, then add_input_noise (:486-504): masked columns become pure noise.  This lane's row is timestep
-                // 4*it + ph of system sysc; its 41 normals are Philox quads t*11 + 0..10 (or the explicit tensor's row).
-                const int t = 4 * it + ph;
-                const float* er = p.eps_in ? p.eps_in + (r * p.B + sysc) * rowstride + (int64_t)t * F : nullptr;
-#pragma unroll
-                for (int q = 0; q < 11; ++q) {
-                    f32x4 n4;
-                    if (er) {
-                        if (q < 10) n4 = *reinterpret_cast<const f32x4u*>(er + 4 * q);
-                        else n4 = (f32x4){er[40], 0.0f, 0.0f, 0.0f};
-                    } else {
-                        n4 = philox_sys4(TAG_IN, p.row_id0 + r, p.sys_id0 + sysc, t * 11 + q, p.seed);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int col = 4 * q + j;
-                        if (col < F) {
-                            const float xm = ((p.zero_mask >> col) & 1ull) ? 0.0f : xv[col];
-                            xv[col] = xm + n4[j] * nsc[col];
-                        }
-                    }
-                }
-            }
             // A operands are read one group of 20 MFMAs ahead of their use and the order is pinned with
             // sched_group_barrier (5 LDS reads, then 20 MFMAs): left alone, the scheduler issues each read one or two
             // MFMAs before its use and the LDS latency lands on the matrix pipe.
@@ -185,16 +159,46 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h[n] = bq1[n];
                 auto rd = [&](int kp) {
-                    const int kr = (BNN_EXP & 16) ? 0 : kp;  // timing experiment 16: one group of operand reads per layer
-                    const int k0 = 2 * kr, k1 = 2 * kr + 1;
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
                     q[kp][0] = wqA1[(k0 * 2 + 0) * 4]; q[kp][1] = wqA1[(k0 * 2 + 1) * 4];
                     if (k1 < KIN) { q[kp][2] = wqA1[(k1 * 2 + 0) * 4]; q[kp][3] = wqA1[(k1 * 2 + 1) * 4]; }
-                    q[kp][4] = wqB1[kr * 4];
+                    q[kp][4] = wqB1[kp * 4];
+                };
+                // masks, then add_input_noise (:486-504): masked columns become pure noise.  This lane's row is timestep
+                // 4*it + ph of system sysc; its 41 normals are the 7 Philox blocks t*7 + 0..6, six normals each (or the explicit
+                // tensor's row).  A block is generated right in front of the three column pairs that consume it, so that its
+                // registers are short-lived (the whole row's noise up front cost 13 spilled VGPRs).
+                const float* er = nullptr;
+                int tblk = 0;
+                if constexpr (NOISY) {
+                    const int t = 4 * it + ph;
+                    tblk = t * NIN_BLOCKS;
+                    if (p.eps_in) er = p.eps_in + (r * p.B + sysc) * rowstride + (int64_t)t * F;
+                }
+                auto noise6 = [&](int blk) {
+                    float n6[6];
+                    if (er) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) n6[j] = (6 * blk + j < F) ? er[6 * blk + j] : 0.0f;
+                    } else {
+                        philox_in6(p.row_id0 + r, p.sys_id0 + sysc, tblk + blk, p.seed, n6);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const int col = 6 * blk + j;
+                        if (col < KIN) {
+                            const float xm = ((p.zero_mask >> col) & 1ull) ? 0.0f : xv[col];
+                            xv[col] = xm + n6[j] * nsc[col];
+                        }
+                    }
                 };
                 rd(0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
+                if constexpr (!NOISY) __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
 #pragma unroll
                 for (int kp = 0; kp < NP; ++kp) {
+                    if constexpr (NOISY) {
+                        if (kp % 3 == 0) noise6(kp / 3);
+                    }
                     if (kp + 1 < NP) rd(kp + 1);
                     const int k0 = 2 * kp, k1 = 2 * kp + 1;
                     const float b0 = xv[k0];
@@ -207,22 +211,20 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
                         h[4] = mfma4(q[kp][3].x, b1v, h[4]); h[5] = mfma4(q[kp][3].y, b1v, h[5]); h[6] = mfma4(q[kp][3].z, b1v, h[6]); h[7] = mfma4(q[kp][3].w, b1v, h[7]);
                         h[8] = mfma4(q[kp][4].z, b1v, h[8]); h[9] = mfma4(q[kp][4].w, b1v, h[9]);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+                    if constexpr (!NOISY) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+                    }
                 }
             }
-            STAMP(2);  // layer 1
 #pragma unroll
-            for (int n = 0; n < 10; ++n) h[n] = (BNN_EXP & 8) ? h[n] : relu4(h[n]);  // timing experiment 8: no ReLU
+            for (int n = 0; n < 10; ++n) h[n] = relu4(h[n]);
             // x of this tile is dead: fetch the next tile's rows into the same registers (one tile of work to land)
-#if !(BNN_EXP & 2)  // timing experiment 2: no further x loads
             {
                 const int itn = (it + 1 < ntiles) ? it + 1 : it;
                 load_row<KIN>(rowp + (int64_t)itn * 4 * F, xv);
                 asm volatile("" ::: "memory");
             }
-#endif
-            STAMP(3);  // relu 1 + load issue
             // feature_nn.2 + ReLU
             f32x4 h2[10];
             {
@@ -231,11 +233,10 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h2[n] = bq2[n];
                 auto rd = [&](int kp) {
-                    const int kr = (BNN_EXP & 16) ? 0 : kp;
-                    const int k0 = 2 * kr, k1 = 2 * kr + 1;
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
                     q[kp][0] = wqA2[(k0 * 2 + 0) * 4]; q[kp][1] = wqA2[(k0 * 2 + 1) * 4];
                     q[kp][2] = wqA2[(k1 * 2 + 0) * 4]; q[kp][3] = wqA2[(k1 * 2 + 1) * 4];
-                    q[kp][4] = wqB2[kr * 4];
+                    q[kp][4] = wqB2[kp * 4];
                 };
                 rd(0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
@@ -254,10 +255,8 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
                     __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
                 }
             }
-            STAMP(4);  // layer 2
 #pragma unroll
-            for (int n = 0; n < 10; ++n) h2[n] = (BNN_EXP & 8) ? h2[n] : relu4(h2[n]);
-            STAMP(5);  // relu 2
+            for (int n = 0; n < 10; ++n) h2[n] = relu4(h2[n]);
             // feature_nn.4: quads of inputs: reads A(k..k+3) + B(quad)
             f32x4 y[5];
             {
@@ -266,10 +265,9 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
 #pragma unroll
                 for (int n = 0; n < 5; ++n) y[n] = bq3[n];
                 auto rd = [&](int kq) {
-                    const int kr = (BNN_EXP & 16) ? 0 : kq;
 #pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) q[kq][cc] = wqA3[(4 * kr + cc) * 4];
-                    q[kq][4] = wqB3[kr * 4];
+                    for (int cc = 0; cc < 4; ++cc) q[kq][cc] = wqA3[(4 * kq + cc) * 4];
+                    q[kq][4] = wqB3[kq * 4];
                 };
                 rd(0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 5 + 5, 0);
@@ -287,16 +285,8 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
                     __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
                 }
             }
-            STAMP(6);  // layer 3
             // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
             const float rcn = p.rcp_tab[it];
-#if BNN_EXP & 1  // timing experiment: pool replaced by integer ops (co-issue with the matrix pipe)
-#pragma unroll
-            for (int n = 0; n < 5; ++n)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    mean[n][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, mean[n][i]) ^ __builtin_bit_cast(int, y[n][i]));
-#else
 #pragma unroll
             for (int n = 0; n < 5; ++n)
 #pragma unroll
@@ -306,8 +296,6 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
                     m2[n][i] = fmaf(dl, y[n][i] - mn, m2[n][i]);
                     mean[n][i] = mn;
                 }
-#endif
-            STAMP(7);  // pool
         }
 
         // merge the 4 lanes of a quad: equal-count Chan update, symmetric (all four lanes end with the same bits)
@@ -384,7 +372,6 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
         }
         __builtin_amdgcn_wave_barrier();
 
-        STAMP(8);  // merge + noise + finish
         // ---- regress_nn on the 16 systems of this wave-batch (16x16x4 path): column c <-> system wb0 + c
         const int64_t sysb = wb0 + c;
         const bool validb = sysb < b1;
@@ -432,24 +419,32 @@ __global__ __launch_bounds__(256, 2) void bnn_multiswag4_kernel(const FwdParams 
         for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(60 + ks), a5[ks >> 2][ks & 3], a6);
         if (g == 0 && validb) {
             // predict_instability + soft_clamp (:295-296, :437-442)
-            float r0 = a6[0], r1 = a6[1];
-            float mu = (0.5f * (tanhf(r0) + 1.0f)) * 8.0f + 4.0f;
-            float sd = (0.5f * (tanhf(r1) + 1.0f)) * p.std_span + p.std_lo;
-            if (bad_seed) mu = sd = __builtin_nanf("");
-            const int64_t o = (r * p.B + sysb) * 2;
-            *reinterpret_cast<f32x2*>(p.out + o) = (f32x2){mu, sd};
-#if !BNN_STAMPS
-            if (p.pre_clamp) *reinterpret_cast<f32x2*>(p.pre_clamp + o) = (f32x2){r0, r1};
-#endif
+            const float r0 = a6[0], r1 = a6[1];
+            f32x2 ms = soft_clamp2(r0, r1, p.std_lo, p.std_span);
+            if (bad_seed) ms.x = ms.y = __builtin_nanf("");
+            if constexpr (STATS) {
+                p.sink[r * p.B + sysb] = stats_draw(p.st, ms.x, ms.y, p.row_id0 + r, p.sys_id0 + sysb, p.seed);
+            } else {
+                const int64_t o = (r * p.B + sysb) * 2;
+                *reinterpret_cast<f32x2*>(p.out + o) = ms;
+                if (p.pre_clamp) *reinterpret_cast<f32x2*>(p.pre_clamp + o) = (f32x2){r0, r1};
+            }
         }
         __builtin_amdgcn_wave_barrier();  // scratch is reused by the next wave-batch
-        STAMP(9);  // regress_nn + store
     }
-#if BNN_STAMPS
-    if (p.pre_clamp && tid == 0) {
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.pre_clamp) + (int64_t)blockIdx.x * 12;
-        for (int i = 0; i < 12; ++i) dst[i] = st_acc[i];
-    }
-#endif
 }
 
+template <int KIN, bool FUSED, bool NOISY, bool STATS>
+inline hipError_t launch_forward_form(unsigned nblk, hipStream_t st, const FwdParams& p) {
+    static bool attr_set[MAX_DEVICES];  // the attribute belongs to the (function, device) pair
+    const int slot = current_device_slot();
+    if (!attr_set[slot]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_kernel<KIN, FUSED, NOISY, STATS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[slot] = true;
+    }
+    hipLaunchKernelGGL((bnn_forward_kernel<KIN, FUSED, NOISY, STATS>), dim3(nblk), dim3(256), fwd_lds_bytes<KIN>(), st, p);
+    return hipGetLastError();
+}
+
+}  // namespace bnn

@@ -1,0 +1,77 @@
+// bnn_internal.h -- what the translation units of libbnn_chaos_hip.so share on the HOST side: kernel parameter
+// blocks and the launch functions each kernel TU exports to the C ABI (bnn_abi.hip).  No device code here.
+//
+//   bnn_fwd_k31.hip     forward kernel, 31 live input columns (the v50 mask), quiet      (workspace + in-prologue draw)
+//   bnn_fwd_k41.hip     forward kernel, all 41 columns (any other mask), quiet           (workspace + in-prologue draw)
+//   bnn_fwd_noisy.hip   forward kernel, forward(noisy_val=True)
+//   bnn_fwd_bf16.hip    reduced-precision forward kernels (bf16 matrix pipe; opt-in, configs[4])
+//   bnn_small.hip       SWAG draw, moments, regress_nn, statistics epilogue, feature packing, Philox fills
+//   bnn_abi.hip         extern "C" entry points of include/bnn_chaos_hip.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bnn_layout.h"
+
+namespace bnn {
+
+struct StatsParams {
+    int32_t tn_nsamp;         // candidates per truncated-normal draw (the scripts use 40)
+    float tn_left;            // left truncation point (4)
+    float prior_thr;          // values >= this are redrawn from the prior (9); +inf: never
+    const float* prior_surv;  // [prior_m] survival function of the prior at t_i = prior_thr + i * prior_step (decreasing from 1)
+    int32_t prior_m;
+    float prior_step;
+};
+
+struct FwdParams {
+    const float* x;
+    int64_t B;
+    int32_t T, ntiles;
+    int32_t J, nch;
+    int64_t csz;
+    int32_t spc;  // systems per workgroup (multiple of 64)
+    int32_t K, S;
+    const float* W;  // [J,d] materialised draws (unfused) or nullptr
+    const float* w_avg;
+    const float* w2_avg;
+    const float* pre_D;
+    const int32_t* seed_idx;
+    const float* z1;
+    const float* z2;
+    float c1, c2, scale;
+    const float* eps;
+    const float* eps_in;
+    const float* eps_sum;
+    uint64_t seed;
+    int64_t draw_id0, row_id0, sys_id0;
+    float* out;
+    float* pre_clamp;
+    float* summary;
+    const int16_t* tab_f2;
+    const int16_t* tab_f4;  // 4x4x1 image gather table
+    const float* rcp_tab;   // [i] = 1/(i+1), correctly rounded
+    uint64_t zero_mask;
+    float std_lo, std_span;
+    // fused statistics epilogue (bnn_multiswag_stats_f32): when `sink` is set the (mu, std) pair of every evaluation goes
+    // through truncated-normal draw -> prior resampling (bnn_stats.hip.h) and lands in sink[R, B] instead of out[R, B, 2].
+    float* sink;
+    StatsParams st;
+};
+
+constexpr int RCP_N = 4096;  // supports T up to 16384 timesteps
+
+// Each returns hipGetLastError() after the launch.  grid = (draw, block-of-systems) pairs, 256 threads.
+hipError_t launch_fwd_k31(bool fused, unsigned nblk, hipStream_t st, const FwdParams& p);
+hipError_t launch_fwd_k41(bool fused, unsigned nblk, hipStream_t st, const FwdParams& p);
+hipError_t launch_fwd_noisy(unsigned nblk, hipStream_t st, const FwdParams& p);
+hipError_t launch_fwd_stats(bool k31, unsigned nblk, hipStream_t st, const FwdParams& p);  // quiet forward + fused statistics tail
+
+constexpr int MAX_DEVICES = 64;
+inline int current_device_slot() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return (dev >= 0 && dev < MAX_DEVICES) ? dev : 0;
+}
+
+}  // namespace bnn

@@ -1,6 +1,6 @@
 // bnn_layout.h -- operand layout shared by the table builder (host) and the kernels (device).
 //
-// The network is evaluated with v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain).
+// regress_nn is evaluated with v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain), 16 systems at a time.
 // For every Linear layer  out[neuron][row] = sum_k W[neuron][k] * act[k][row] + b[neuron]:
 //   A operand = weights      lane (g = lane>>4, m = lane&15) holds W[nmap(mt, m)][kmap(kstep, g)]
 //   B operand = activations  lane (g, c = lane&15)           holds act[kmap(kstep, g)][row c]
@@ -9,6 +9,7 @@
 // layer consumes register i' of m-tile mt', whose lane group g carries neuron nmap(mt', 4g+i').
 // The neuron->(m-tile, row) maps below put padding in whole registers so that a 40-wide layer
 // costs 10 k-steps (not 12) downstream.
+// feature_nn is evaluated with v_mfma_f32_4x4x1_16b_f32 from packed LDS images ("second operand layout" below).
 #pragma once
 #include <stdint.h>
 
@@ -52,20 +53,11 @@ constexpr int MAXK = 32;  // SWAG rank supported (reference uses K = 30, run_swa
 constexpr uint64_t V50_ZERO_MASK = (1ull << 7) | (1ull << 3) | (1ull << 6) | (1ull << 38) | (1ull << 39) | (1ull << 40) |
                                    (1ull << 1) | (1ull << 2) | (1ull << 4) | (1ull << 5);
 
-constexpr int COL_BIAS = -1;  // k slot fed with 1.0: carries the layer-1 bias
-constexpr int COL_PAD = -2;   // k slot fed with 0
-
 // 40-wide layers: three m-tiles; neurons 32..39 sit in registers i = 0,1 of m-tile 2.
 BNN_HD inline int nmap_hidden(int mt, int m) {
     if (mt < 2) return 16 * mt + m;
     int g = m >> 2, i = m & 3;
     return i < 2 ? 32 + 2 * g + i : -1;
-}
-// 20-wide latent layer: two m-tiles; neurons 16..19 sit in register 0 of m-tile 1.
-BNN_HD inline int nmap_latent(int mt, int m) {
-    if (mt == 0) return m;
-    int g = m >> 2, i = m & 3;
-    return i == 0 ? 16 + g : -1;
 }
 // 2-wide output layer: one m-tile, rows 0 and 1.
 BNN_HD inline int nmap_out(int m) { return m < 2 ? m : -1; }
@@ -76,27 +68,13 @@ BNN_HD inline int kmap_hidden(int ks, int g) {
     int mt = ks >> 2, i = ks & 3;
     return nmap_hidden(mt, 4 * g + i);
 }
-// k-steps over the 40-wide summary [mu_sample(20) | std_sample(20)]: ks = kind*5 + r, r<4: register r of
-// latent m-tile 0, r=4: register 0 of latent m-tile 1.
+// k-steps over the 40-wide summary [mu_sample(20) | std_sample(20)]: ks = kind*5 + r; lane group g carries neuron
+// 4g + r for r < 4 and neuron 16 + g for r = 4 of that kind.
 BNN_HD inline int kmap_summary(int ks, int g) {
     int kind = ks / 5, r = ks % 5;
     int n = r < 4 ? 4 * g + r : 16 + g;
     return kind * L + n;
 }
-// layer-1 k slots.  NK1 = 8 (v50 fast path: 31 live columns + bias = 32 slots): lane group g reads 8
-// consecutive floats of its row starting at column 8+8g; group 3 takes columns 32..37, then column 0, then bias.
-// NK1 = 11 (generic / noisy path): group g reads columns 11g..11g+10; slot 41 is the bias, 42,43 padding.
-BNN_HD inline int kmap_input(int nk1, int s, int g) {
-    if (nk1 == 8) {
-        if (g < 3) return 8 + 8 * g + s;
-        if (s < 6) return 32 + s;
-        return s == 6 ? 0 : COL_BIAS;
-    }
-    int q = 11 * g + s;
-    if (q < F) return q;
-    return q == F ? COL_BIAS : COL_PAD;
-}
-
 // ---- second operand layout: v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 neurons x 4 rows, K = 1) -----------------
 // lane l = row (B operand), register r of neuron group n = neuron 4n + r (A operand: lane l supplies W[4n + (l&3)][k]).
 // No padding inside a layer: 40 outputs = 10 groups, 20 outputs = 5 groups.  The A operands stream from LDS images,
@@ -124,8 +102,7 @@ struct W4 {
     static constexpr int PAD = (N + 15) / 16 * 16;   // 3760 (KIN = 31) / 4160 (KIN = 41)
 };
 
-// fragment table indices (see bnn_tables.cpp)
-BNN_HD inline int nf1(int nk1) { return 3 * nk1 + 30 + 20 + 12 + 8; }
+// regress_nn fragment count (see bnn_tables.cpp)
 constexpr int NF2 = 30 + 30 + 10 + 12 + 12 + 4;
 
 }  // namespace bnn

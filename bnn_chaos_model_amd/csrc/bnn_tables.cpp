@@ -1,5 +1,6 @@
-// bnn_tables.cpp -- builds the per-lane gather tables that turn the reference's flat parameter
-// vector (spock_reg_model.py:734-761 order) into v_mfma_f32_16x16x4_f32 A operands and C-init biases.
+// bnn_tables.cpp -- builds the gather tables that turn the reference's flat parameter vector (spock_reg_model.py:734-761
+// order) into MFMA operands: the packed LDS images of feature_nn (v_mfma_f32_4x4x1) and the per-lane fragments + C-init
+// biases of regress_nn (v_mfma_f32_16x16x4).
 #include "bnn_tables.h"
 
 namespace bnn {
@@ -22,49 +23,7 @@ struct Builder {
 Tables build_tables(uint64_t zero_mask, bool all_columns) {
     Tables T;
     const bool v50 = !all_columns && zero_mask == V50_ZERO_MASK;
-    T.nk1 = v50 ? 8 : 11;
-    const int nk1 = T.nk1;
     auto dropped = [&](int col) { return !all_columns && ((zero_mask >> col) & 1ull); };
-
-    T.f1.assign((size_t)nf1(nk1) * 64, (int16_t)ZERO_IDX);
-    Builder b1(T.f1);
-    // layer 1 (feature_nn.0): A[s][mt], lane (g, m)
-    for (int s = 0; s < nk1; ++s)
-        for (int mt = 0; mt < 3; ++mt)
-            b1.frag([&](int g, int m) {
-                int n = nmap_hidden(mt, m), col = kmap_input(nk1, s, g);
-                if (n < 0 || col == COL_PAD) return ZERO_IDX;
-                if (col == COL_BIAS) return OFF_B1 + n;
-                if (dropped(col)) return ZERO_IDX;
-                return OFF_W1 + n * F + col;
-            });
-    // layer 2 (feature_nn.2)
-    for (int ks = 0; ks < NKH; ++ks)
-        for (int mt = 0; mt < 3; ++mt)
-            b1.frag([&](int g, int m) {
-                int n = nmap_hidden(mt, m), k = kmap_hidden(ks, g);
-                return (n < 0 || k < 0) ? ZERO_IDX : OFF_W2 + n * H + k;
-            });
-    // layer 3 (feature_nn.4)
-    for (int ks = 0; ks < NKH; ++ks)
-        for (int mt = 0; mt < 2; ++mt)
-            b1.frag([&](int g, int m) {
-                int n = nmap_latent(mt, m), k = kmap_hidden(ks, g);
-                return (n < 0 || k < 0) ? ZERO_IDX : OFF_W3 + n * H + k;
-            });
-    // C-init biases: lane (g, c) register i <-> neuron nmap(mt, 4g+i)
-    for (int mt = 0; mt < 3; ++mt)
-        for (int i = 0; i < 4; ++i)
-            b1.frag([&](int g, int) {
-                int n = nmap_hidden(mt, 4 * g + i);
-                return n < 0 ? ZERO_IDX : OFF_B2 + n;
-            });
-    for (int mt = 0; mt < 2; ++mt)
-        for (int i = 0; i < 4; ++i)
-            b1.frag([&](int g, int) {
-                int n = nmap_latent(mt, 4 * g + i);
-                return n < 0 ? ZERO_IDX : OFF_B3 + n;
-            });
 
     T.f2.assign((size_t)NF2 * 64, (int16_t)ZERO_IDX);
     Builder b2(T.f2);
@@ -144,21 +103,15 @@ Tables build_tables(uint64_t zero_mask, bool all_columns) {
         if (v50) build4(W4<31>{}); else build4(W4<F>{});
     }
 
-    // accumulation order = k-step major, lane group (the MFMA's k index) minor
-    for (int s = 0; s < nk1; ++s)
-        for (int g = 0; g < 4; ++g) {
-            int col = kmap_input(nk1, s, g);
-            if (col == COL_PAD) continue;
-            if (col == COL_BIAS) { T.order[0].push_back(-1); continue; }
-            if (dropped(col)) continue;
-            T.order[0].push_back(col);
-        }
+    // accumulation order.  feature_nn (4x4x1, K = 1 per instruction): the accumulator starts at the bias, then the live inputs in
+    // ascending order.  regress_nn (16x16x4): k-step major, lane group (the MFMA's k index) minor.
+    for (int k = 0; k < F; ++k)
+        if (!dropped(k)) T.order[0].push_back(k);
+    for (int k = 0; k < H; ++k) { T.order[1].push_back(k); T.order[2].push_back(k); }
     for (int ks = 0; ks < NKH; ++ks)
         for (int g = 0; g < 4; ++g) {
             int k = kmap_hidden(ks, g);
             if (k < 0) continue;
-            T.order[1].push_back(k);
-            T.order[2].push_back(k);
             T.order[4].push_back(k);
             T.order[5].push_back(k);
         }

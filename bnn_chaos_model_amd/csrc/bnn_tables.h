@@ -10,8 +10,6 @@ namespace bnn {
 // Entry [f * 64 + lane] = index into the LDS-resident flat parameter vector (ZERO_IDX for padding)
 // that lane `lane` loads into fragment register f.
 struct Tables {
-    int nk1;                   // layer-1 k-steps: 8 (v50 mask) or 11 (any mask / all 41 columns)
-    std::vector<int16_t> f1;   // nf1(nk1) * 64: feature_nn fragments + C-init biases
     std::vector<int16_t> f2;   // NF2 * 64: regress_nn fragments + C-init biases
     int kin4;                  // layer-1 inputs of the 4x4x1 kernel: 31 (v50 mask) or 41
     std::vector<int16_t> f4;   // W4<kin4>::PAD: feature_nn images for the 4x4x1 kernel

@@ -1,15 +1,21 @@
-"""Builds libbnn_chaos_hip.so (gfx950 only) in-tree with hipcc.  `python -m bnn_chaos_model_amd.csrc.build`"""
+"""Builds libbnn_chaos_hip.so (gfx950 only) in-tree with hipcc: one object per translation unit, compiled in parallel, then one
+link.  `python -m bnn_chaos_model_amd.csrc.build [--force] [extra hipcc flags] [-o other_name.so]`"""
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libbnn_chaos_hip.so")
-SRCS = ["bnn_kernels.hip", "bnn_tables.cpp"]
-DEPS = SRCS + ["bnn_layout.h", "bnn_tables.h", "bnn_common.hip.h", "bnn_engine_a.hip.h", "bnn_engine_b.hip.h", os.path.join("..", "..", "include", "bnn_chaos_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+OBJDIR = os.path.join(HERE, "build")
+# translation units (bnn_internal.h says what each holds); the forward-kernel units dominate the build time
+SRCS = ["bnn_fwd_k31.hip", "bnn_fwd_k41.hip", "bnn_fwd_noisy.hip", "bnn_fwd_stats.hip", "bnn_abi.hip",
+        "bnn_tables.cpp"]
+HEADERS = ["bnn_layout.h", "bnn_tables.h", "bnn_internal.h", "bnn_common.hip.h", "bnn_stats.hip.h", "bnn_forward.hip.h",
+           os.path.join("..", "..", "include", "bnn_chaos_hip.h")]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+          "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 
 def hipcc():
@@ -19,23 +25,60 @@ def hipcc():
     raise RuntimeError("hipcc not found (need ROCm; this library has no CPU build)")
 
 
+def _mtime(name):
+    return os.path.getmtime(os.path.join(HERE, name))
+
+
+def source_hash(extra=()):
+    """Content hash of everything the library is built from (file times do not survive a copy to another machine)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(CFLAGS + list(extra)).encode())
+    for name in sorted(SRCS + HEADERS):
+        h.update(name.encode())
+        with open(os.path.join(HERE, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def stale():
-    if not os.path.exists(SO):
+    """True when the library is missing or was built from other sources than the ones next to it."""
+    try:
+        with open(SO + ".srchash") as f:
+            return not os.path.exists(SO) or f.read().strip() != source_hash()
+    except OSError:
         return True
-    t = os.path.getmtime(SO)
-    return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in DEPS)
 
 
 def build(force=False, verbose=False, extra=(), out=None):
-    """extra: additional hipcc flags (e.g. -DBNN_WAVES_PER_SIMD=3); out: alternative .so name for A/B builds."""
+    """extra: additional hipcc flags; out: alternative .so name for A/B builds (always a full rebuild)."""
     so = SO if out is None else os.path.join(HERE, out)
     if not force and out is None and not stale():
         return so
-    cmd = [hipcc()] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(HERE, s) for s in SRCS] + ["-o", so + ".tmp"]
+    cc = hipcc()
+    objdir = OBJDIR if out is None else os.path.join(HERE, "build_" + os.path.splitext(out)[0])
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(_mtime(h) for h in HEADERS)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        if not force and out is None and os.path.exists(obj) and os.path.getmtime(obj) > max(_mtime(src), hdr_t):
+            return obj
+        cmd = [cc] + CFLAGS + list(extra) + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=HERE)
+        return obj
+
+    workers = min(len(SRCS), max(1, (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(workers) as ex:
+        objs = list(ex.map(compile_one, SRCS))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", so + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=HERE)
     os.replace(so + ".tmp", so)
+    with open(so + ".srchash", "w") as f:
+        f.write(source_hash(extra))
     return so
 
 
@@ -46,4 +89,4 @@ if __name__ == "__main__":
         i = args.index("-o")
         out = args[i + 1]
         del args[i:i + 2]
-    print(build(force=True, verbose=True, extra=args, out=out))
+    print(build(force="--force" in sys.argv[1:] or out is not None, verbose=True, extra=args, out=out))

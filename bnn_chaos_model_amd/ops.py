@@ -75,14 +75,13 @@ def swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, scale=0.5, philo
 
     w_avg, w2_avg [S,d]; pre_D [S,d,K]; seed_idx [J] int32; z1 [J,d] / z2 [J,K] explicit normals or None (Philox)."""
     plan = plan or get_plan()
-    w_avg, w2_avg, pre_D = _f32(w_avg, "w_avg"), _f32(w2_avg, "w2_avg"), _f32(pre_D, "pre_D")
-    S, d, K = pre_D.shape
-    if d != plan.d or w_avg.shape != (S, d) or w2_avg.shape != (S, d):
-        raise ValueError("ensemble tensors have inconsistent shapes")
+    w_avg, w2_avg, pre_D, S, d, K = _ensemble(plan, w_avg, w2_avg, pre_D)
     seed_idx = seed_idx.to(device=w_avg.device, dtype=torch.int32).contiguous()
     J = seed_idx.numel()
     z1, z2 = _f32(z1, "z1"), _f32(z2, "z2")
-    if z1 is not None and (z1.shape != (J, d) or z2.shape != (J, K)):
+    if (z1 is None) != (z2 is None):
+        raise ValueError("z1 and z2 must both be given or both be None")
+    if z1 is not None and (tuple(z1.shape) != (J, d) or tuple(z2.shape) != (J, K)):
         raise ValueError("z1 must be [J,d] and z2 [J,K]")
     W = torch.empty((J, d), dtype=torch.float32, device=w_avg.device)
     N.check(N.lib().bnn_swag_draw_f32(plan.handle, N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K, N.ptr(seed_idx), J,
@@ -104,11 +103,19 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     if x.dim() != 3 or x.shape[2] != 41:
         raise NotImplementedError("x must be [B, T, 41]")  # figures/spock/regression.py:210-211
     B, T, _ = x.shape
+    if W.dim() != 2 or W.shape[1] != plan.d:
+        raise ValueError(f"W must be [J,{plan.d}]")
     J = W.shape[0]
+    _check_grid(J, nchunks, draw_id0)
     R = J // nchunks
     eps, eps_in, eps_sum = _f32(eps, "eps"), _f32(eps_in, "eps_in"), _f32(eps_sum, "eps_sum")
+    _check_same_device(x, W=W, eps=eps, eps_in=eps_in, eps_sum=eps_sum)
     if eps is not None and tuple(eps.shape) != (R, B, 2, LATENT):
         raise ValueError(f"eps must be [{R},{B},2,{LATENT}]")
+    if (eps_in is None) != (eps_sum is None):
+        raise ValueError("eps_in and eps_sum must both be given or both be None")
+    if eps_in is not None and (tuple(eps_in.shape) != (R, B, T, 41) or tuple(eps_sum.shape) != (R, B, 2 * LATENT)):
+        raise ValueError(f"eps_in must be [{R},{B},{T},41] and eps_sum [{R},{B},{2 * LATENT}]")
     out = torch.empty((R, B, 2), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, 2 * LATENT), dtype=torch.float32, device=x.device) if debug else None
@@ -119,17 +126,33 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     return (out, pre, summ) if debug else out
 
 
-_workspaces = {}
+def _check_grid(J, nchunks, draw_id0):
+    if nchunks < 1 or J % nchunks:
+        raise ValueError("the number of draws must be a multiple of nchunks")
+    if draw_id0 % nchunks:
+        raise ValueError("draw_id0 must be a multiple of nchunks")
+
+
+def _check_same_device(x, **tensors):
+    for name, t in tensors.items():
+        if t is not None and t.device != x.device:
+            raise ValueError(f"{name} is on {t.device}, x on {x.device}")
+
+
+def _ensemble(plan, w_avg, w2_avg, pre_D):
+    w_avg, w2_avg, pre_D = _f32(w_avg, "w_avg"), _f32(w2_avg, "w2_avg"), _f32(pre_D, "pre_D")
+    if pre_D.dim() != 3:
+        raise ValueError("pre_D must be [S,d,K]")
+    S, d, K = pre_D.shape
+    if d != plan.d or tuple(w_avg.shape) != (S, d) or tuple(w2_avg.shape) != (S, d):
+        raise ValueError(f"ensemble tensors must be w_avg, w2_avg [S,{plan.d}] and pre_D [S,{plan.d},K]")
+    return w_avg, w2_avg, pre_D, S, d, K
 
 
 def _workspace(J, d, device):
-    """[J,d] scratch for the draws of one call, cached per device (grown, never shrunk)."""
-    key = (device.type, device.index)
-    w = _workspaces.get(key)
-    if w is None or w.shape[0] < J:
-        w = torch.empty((max(J, 64), d), dtype=torch.float32, device=device)
-        _workspaces[key] = w
-    return w
+    """[J,d] scratch for the draws of ONE call.  torch's caching allocator is stream-ordered, so a fresh block per call is
+    cheap, safe when several streams run the op concurrently, and a captured HIP graph keeps its own block alive."""
+    return torch.empty((J, d), dtype=torch.float32, device=device)
 
 
 @_on_device_of(0)
@@ -139,19 +162,22 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
     figures/multiswag_5_planet.py:295-298 -> out[J/nchunks, B, 2].
 
     single_launch: True = every workgroup samples its draw in its prologue (no scratch memory); False = draws are
-    sampled once into a cached workspace and read by the forward kernel of the same call (same bits, faster when a
-    draw serves many workgroups).  None = choose by chunk size."""
+    sampled once into a [J,d] workspace allocated for this call and read by the forward kernel of the same call (same
+    bits, faster when a draw serves many workgroups).  None = choose by chunk size."""
     plan = plan or get_plan()
     x = _f32(x, "x")
     if x.dim() != 3 or x.shape[2] != 41:
         raise NotImplementedError("x must be [B, T, 41]")
-    w_avg, w2_avg, pre_D = _f32(w_avg, "w_avg"), _f32(w2_avg, "w2_avg"), _f32(pre_D, "pre_D")
-    S, d, K = pre_D.shape
+    w_avg, w2_avg, pre_D, S, d, K = _ensemble(plan, w_avg, w2_avg, pre_D)
     B, T, _ = x.shape
     seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()
     J = seed_idx.numel()
+    _check_grid(J, nchunks, draw_id0)
     R = J // nchunks
     z1, z2, eps = _f32(z1, "z1"), _f32(z2, "z2"), _f32(eps, "eps")
+    _check_same_device(x, w_avg=w_avg, w2_avg=w2_avg, pre_D=pre_D, z1=z1, z2=z2, eps=eps)
+    if (z1 is None) != (z2 is None):
+        raise ValueError("z1 and z2 must both be given or both be None")
     if z1 is not None and (tuple(z1.shape) != (J, d) or tuple(z2.shape) != (J, K)):
         raise ValueError("z1 must be [J,d] and z2 [J,K]")
     if eps is not None and tuple(eps.shape) != (R, B, 2, LATENT):
@@ -248,3 +274,134 @@ def philox_raw(ctr, key, n, device="cuda"):
     out = torch.empty((n, 4), dtype=torch.int32, device=device)
     N.check(N.lib().bnn_philox_raw_u32(*[int(c) for c in ctr], int(key[0]), int(key[1]), n, N.ptr(out), N.stream_ptr()))
     return out
+
+
+# ---- streaming statistics epilogue (include/bnn_chaos_hip.h "streaming statistics epilogue") -----------
+_prior_tables = {}
+
+
+def stats_params(nsamp=40, left=4.0, prior_threshold=9.0, prior_top=100.0, prior_knots=8192, device=None):
+    """bnn_stats for fast_truncnorm(left, nsamp) + prior resampling at/above prior_threshold (None or inf: no resampling)
+    (figures/multiswag_5_planet.py:388-422).  The survival table of the prior is built once per device and cached."""
+    import numpy as np
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    thr = float("inf") if prior_threshold is None else float(prior_threshold)
+    st = N.BnnStats(int(nsamp), float(left), thr, 0, 0.0, 0, None)
+    if thr != float("inf"):
+        key = (dev.index, thr, float(prior_top), int(prior_knots))
+        if key not in _prior_tables:
+            host = np.zeros(int(prior_knots), np.float32)
+            step = C.c_double()
+            N.check(N.lib().bnn_prior_table_f32(thr, float(prior_top), int(prior_knots), host.ctypes.data, C.byref(step)))
+            _prior_tables[key] = (torch.as_tensor(host).to(dev), step.value)
+        tab, step = _prior_tables[key]
+        st.prior_m, st.prior_step, st.prior_surv = int(prior_knots), step, tab.data_ptr()
+        st._keepalive = tab
+    return st
+
+
+@_on_device_of(0)
+def stats_draw(musd, st=None, philox_seed=0, row_id0=0, system_id0=0):
+    """The statistics epilogue on materialised pairs: musd [R,B,2] (the forward's output) -> t [R,B], one log10 instability
+    time per evaluation (truncated-normal draw, then prior resampling); Philox keyed by (global row, global system)."""
+    musd = _f32(musd, "musd")
+    if musd.dim() != 3 or musd.shape[2] != 2:
+        raise ValueError("musd must be [R,B,2]")
+    st = st or stats_params(device=musd.device)
+    R, B, _ = musd.shape
+    out = torch.empty((R, B), dtype=torch.float32, device=musd.device)
+    N.check(N.lib().bnn_stats_draw_f32(N.ptr(musd), R, B, C.byref(st), int(philox_seed), int(row_id0), int(system_id0), N.ptr(out),
+                                       N.stream_ptr()))
+    return out
+
+
+@_on_device_of(0)
+def multiswag_stats(x, w_avg, w2_avg, pre_D, seed_idx, st=None, z1=None, z2=None, eps=None, nchunks=1, scale=0.5, philox_seed=0,
+                    draw_id0=0, system_id0=0, plan=None, systems_per_block=0, out=None):
+    """multiswag with the statistics epilogue fused into the kernel's tail -> t [J/nchunks, B]: (mu, std) never reach memory.
+    Bit-identical to stats_draw(multiswag(...), row_id0=draw_id0 // nchunks, system_id0=system_id0)."""
+    plan = plan or get_plan()
+    x = _f32(x, "x")
+    if x.dim() != 3 or x.shape[2] != 41:
+        raise NotImplementedError("x must be [B, T, 41]")
+    w_avg, w2_avg, pre_D, S, d, K = _ensemble(plan, w_avg, w2_avg, pre_D)
+    B, T, _ = x.shape
+    seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()
+    J = seed_idx.numel()
+    _check_grid(J, nchunks, draw_id0)
+    R = J // nchunks
+    z1, z2, eps = _f32(z1, "z1"), _f32(z2, "z2"), _f32(eps, "eps")
+    _check_same_device(x, w_avg=w_avg, w2_avg=w2_avg, pre_D=pre_D, z1=z1, z2=z2, eps=eps)
+    if (z1 is None) != (z2 is None) or (z1 is not None and (tuple(z1.shape) != (J, d) or tuple(z2.shape) != (J, K))):
+        raise ValueError("z1 must be [J,d] and z2 [J,K] (or both None)")
+    if eps is not None and tuple(eps.shape) != (R, B, 2, LATENT):
+        raise ValueError(f"eps must be [{R},{B},2,{LATENT}]")
+    st = st or stats_params(device=x.device)
+    if out is None:
+        out = torch.empty((R, B), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (R, B) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out has the wrong shape/dtype")
+    g = _grid(B, T, J, nchunks, systems_per_block)
+    ws = _workspace(max(J, 1), d, x.device)
+    N.check(N.lib().bnn_multiswag_stats_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
+                                            N.ptr(seed_idx), N.ptr(z1), N.ptr(z2), N.ptr(eps), float(scale), int(philox_seed),
+                                            int(draw_id0), int(system_id0), N.ptr(ws), C.byref(st), N.ptr(out), N.stream_ptr()))
+    return out
+
+
+class QuantileSketch:
+    """Streaming per-simulation quantile sketch over any number of draws in O(n_sims * bins) memory: min over `group`
+    consecutive systems (min over trios, figures/multiswag_5_planet.py:428), then a histogram over piecewise-uniform bins
+    + float64 sum / sum of squares.  percentiles() = np.percentile(..., 'linear') read off the histogram: every estimate is
+    within one bin width (`resolution(t)`) of the exact order statistic.
+
+    Default bins: [4, 9) in steps of 1/128 (the truncated-normal range below the prior threshold), [9, 13) in 1/32,
+    [13, 101) in 1/2 (the prior's tail: P(t > 13 | t >= 9) = 0.18, P(t > 30 | t >= 9) = 1.4e-4); below 4 -> bin 0."""
+
+    DEFAULT = ((4.0, 9.0, 640), (9.0, 13.0, 128), (13.0, 101.0, 176))
+
+    def __init__(self, n_systems, group=1, segments=None, device=None):
+        if n_systems % group:
+            raise ValueError("n_systems must be a multiple of group")
+        self.group, self.n_sims = int(group), n_systems // group
+        self.segments = tuple(segments or self.DEFAULT)
+        sk = N.BnnSketch()
+        sk.nseg = len(self.segments)
+        for i, (lo, hi, n) in enumerate(self.segments):
+            sk.lo[i], sk.hi[i], sk.n[i] = lo, hi, n
+        self.spec = sk
+        self.nbins = N.check(N.lib().bnn_sketch_bins(C.byref(sk)))
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.hist = torch.zeros((self.nbins, self.n_sims), dtype=torch.int32, device=dev)   # uint32 counters
+        self.mom = torch.zeros((self.n_sims, 2), dtype=torch.float64, device=dev)
+        self.count = 0
+
+    def resolution(self, t):
+        for lo, hi, n in self.segments:
+            if t < hi:
+                return (hi - lo) / n
+        lo, hi, n = self.segments[-1]
+        return (hi - lo) / n
+
+    def update(self, t):
+        """t [R, n_systems] float32 on the sketch's device: R more draws."""
+        t = _f32(t, "t")
+        if t.dim() != 2 or t.shape[1] != self.n_sims * self.group or t.device != self.hist.device:
+            raise ValueError("t must be [R, n_systems] on the sketch's device")
+        with torch.cuda.device(t.device):
+            N.check(N.lib().bnn_sketch_update_u32(N.ptr(t), t.shape[0], t.shape[1], self.group, C.byref(self.spec), N.ptr(self.hist),
+                                                  N.ptr(self.mom), N.stream_ptr()))
+        self.count += t.shape[0]
+        return self
+
+    def percentiles(self, q):
+        import numpy as np
+        qa = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+        out = torch.empty((self.n_sims, qa.size), dtype=torch.float32, device=self.hist.device)
+        with torch.cuda.device(self.hist.device):
+            N.check(N.lib().bnn_sketch_quantiles_f32(N.ptr(self.hist), self.n_sims, C.byref(self.spec), qa.ctypes.data, qa.size,
+                                                     N.ptr(out), N.stream_ptr()))
+        return out
+
+    def mean(self):
+        return self.mom[:, 0] / max(self.count, 1)

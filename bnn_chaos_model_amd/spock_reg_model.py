@@ -19,6 +19,7 @@ seed to fp32 rounding.  With `rng = "philox"` the kernels generate counter-based
 """
 import random
 from collections import OrderedDict
+from copy import deepcopy as copy  # noqa: F401  (the reference module exports it: spock_reg_model.py, `from copy import deepcopy as copy`)
 
 import numpy as np
 import torch

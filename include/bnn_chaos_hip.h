@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BNN_ABI_VERSION 1
+#define BNN_ABI_VERSION 2
 
 enum bnn_status {
     BNN_OK = 0,
@@ -61,15 +61,16 @@ int bnn_param_count(const bnn_arch* arch); /* d (7583), or negative */
 int bnn_plan_create(const bnn_arch* arch, bnn_plan** out);
 int bnn_plan_destroy(bnn_plan* plan);
 /* Accumulation order used by the kernels for Linear layer `layer` (0..5): `order` receives up to
- * `cap` entries (input index, or -1 for the bias term; no -1 => accumulator starts at the bias).
+ * `cap` entries (input indices; the accumulator starts at the bias).
  * `noisy` selects the 41-column variant used by bnn_forward_f32 with eps_in != NULL.
  * Returns the number of entries.  Lets a test pin a CPU model to the same order. */
 int bnn_plan_layer_order(const bnn_plan* plan, int layer, int noisy, int32_t* host_order, int cap);
 
 /* Host-only views of the operand layout (no device needed; used by the CPU test-suite):
  * bnn_layer_order = bnn_plan_layer_order without a plan;
- * bnn_fragment_table: which = 1 feature_nn / 2 regress_nn gather table, entry [f*64 + lane] = index into the
- * flat parameter vector (or d = 7583 for "zero") that lane `lane` loads into MFMA operand register f.
+ * bnn_fragment_table: which = 2: regress_nn gather table, entry [f*64 + lane] = index into the flat parameter vector (or
+ * d = 7583 for "zero") that lane `lane` loads into v_mfma_f32_16x16x4 operand register f; which = 1: the feature_nn LDS image
+ * of the v_mfma_f32_4x4x1 path, entry [i] = index of the parameter stored at float i of the image (layout: bnn_layout.h, W4<KIN>).
  * Both return the number of entries (the required capacity) or a negative bnn_status. */
 int bnn_layer_order(const bnn_arch* arch, int layer, int noisy, int32_t* host_order, int cap);
 int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host_table, int cap);
@@ -174,10 +175,58 @@ int bnn_group_min_f32(const float* vals, int64_t n, int32_t group, float* out, v
 
 /* The normals the kernels generate when a noise pointer is NULL, written out for inspection:
  *   kind 0: z1 [n_draws, d]   kind 1: z2 [n_draws, K]   kind 2: eps [rows, B, 2, 20]
- *   kind 3: eps_in [rows, B, T = width, 41]   kind 4: eps_sum [rows, B, 40]
+ *   kind 3: eps_in [rows, B, T = width, 41] (six normals per Philox block)   kind 4: eps_sum [rows, B, 40]
  *   id0 = draw_id0 (kinds 0,1) or output-row id0 (kinds 2-4); system_id0 only for kinds 2-4. */
 int bnn_philox_normal_f32(int32_t kind, uint64_t philox_seed, int64_t id0, int64_t n_rows, int64_t B,
                           int64_t system_id0, int32_t width, float* out, void* stream);
+
+/* ---- streaming statistics epilogue: what the evaluation scripts consume, without [J,B,2] in memory -------
+ * Per evaluation: (mu, std) -> fast_truncnorm(left, nsamp) (figures/multiswag_5_planet.py:306-370, 388-392; main_figures.py:167-227)
+ * -> values >= prior_thr redrawn from the prior (:396-422), all noise Philox keyed by (global output row, global system), so the
+ * numbers do not depend on sharding, draw slabs or launch mode.  The prior is inverted from its exact survival function on m
+ * equally spaced knots (bnn_prior_table_f32; the reference inverts a Riemann-sum table whose size depends on the data). */
+typedef struct bnn_stats {
+    int32_t tn_nsamp;        /* candidates per truncated-normal draw: 40 in the scripts                  */
+    float tn_left;           /* left truncation point: 4                                                 */
+    float prior_thr;         /* values >= this are redrawn from the prior: 9 (INFINITY: never)           */
+    int32_t prior_m;         /* knots of the survival table                                              */
+    float prior_step;        /* knot spacing, from bnn_prior_table_f32                                   */
+    int32_t reserved;
+    const float* prior_surv; /* DEVICE [prior_m] fp32 survival function at prior_thr + i * prior_step    */
+} bnn_stats;
+
+/* Host: S(t_i) = P(T > t_i | T >= thr) of the scripts' prior (:400-404) at t_i = thr + i (top - thr)/(m - 1), float64 closed form
+ * (exp, erfc) rounded to fp32; *host_step = the knot spacing.  Copy host_surv to the device for bnn_stats.prior_surv. */
+int bnn_prior_table_f32(double thr, double top, int32_t m, float* host_surv, double* host_step);
+
+/* The epilogue on materialised pairs: musd [R,B,2] -> out [R,B] (log10 instability time per evaluation). */
+int bnn_stats_draw_f32(const float* musd, int64_t R, int64_t B, const bnn_stats* st, uint64_t philox_seed, int64_t row_id0,
+                       int64_t system_id0, float* out, void* stream);
+
+/* bnn_multiswag_f32 (draw-once workspace form; W_workspace [J,d] required) with the epilogue fused into the regress_nn tail:
+ * t_out [J/nchunks, B] float32 and nothing else leaves the chip; bit-identical to bnn_multiswag_f32 + bnn_stats_draw_f32. */
+int bnn_multiswag_stats_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg, const float* w2_avg,
+                            const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx, const float* z1, const float* z2,
+                            const float* eps, float scale, uint64_t philox_seed, int64_t draw_id0, int64_t system_id0,
+                            float* W_workspace, const bnn_stats* st, float* t_out, void* stream);
+
+/* Streaming per-simulation quantile sketch: min over `group` consecutive systems (min over trios, :428), then a histogram over
+ * 1..4 contiguous uniform segments (bin 0 = below lo[0]; values at or above the last hi fall in the last bin) and float64
+ * sum / sum of squares.  hist [nbins, n_sims] uint32 (bin-major), mom [n_sims, 2] float64, both zeroed by the caller and
+ * accumulated over any number of slabs t [R,B].  Memory is O(n_sims * nbins) whatever the number of draws.
+ * bnn_sketch_quantiles_f32: numpy 'linear' percentiles (np.median / np.percentile of :484-489, main_figures.py:277-278)
+ * read off the histogram; every estimate lies within one bin width of the exact order statistic.  out [n_sims, nq]. */
+typedef struct bnn_sketch {
+    int32_t nseg;
+    int32_t reserved;
+    float lo[4], hi[4];
+    int32_t n[4];
+} bnn_sketch;
+int bnn_sketch_bins(const bnn_sketch* sk); /* total bins (1 + sum n), or negative */
+int bnn_sketch_update_u32(const float* t, int64_t R, int64_t B, int32_t group, const bnn_sketch* sk, uint32_t* hist, double* mom,
+                          void* stream);
+int bnn_sketch_quantiles_f32(const uint32_t* hist, int64_t n_sims, const bnn_sketch* sk, const double* host_q, int32_t nq,
+                             float* out, void* stream);
 
 /* Raw Philox4x32-10 blocks for known-answer tests: out[n][4] = philox(ctr = {c0+i, c1, c2, c3}, key). */
 int bnn_philox_raw_u32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int64_t n,

@@ -31,7 +31,7 @@ def test_abi_exports_every_declared_symbol(N):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(N.EXPORTS)
-    assert lib.bnn_abi_version() == 1
+    assert lib.bnn_abi_version() == 2
 
 
 def test_arch_validation_and_error_strings(N):
@@ -61,93 +61,106 @@ def _table(N, mask, noisy, which):
     return t.reshape(-1, 64)
 
 
-@pytest.mark.parametrize("mask,noisy,nk1", [(V50_MASK, 0, 8), (V50_MASK, 1, 11), (0, 0, 11), (1 << 7, 0, 11)])
-def test_accumulation_orders_are_permutations(N, mask, noisy, nk1):
+def _image(N, mask, noisy):
+    a = N.BnnArch(41, 40, 20, 0, mask, 0.5, 0)
+    n = N.check(N.lib().bnn_fragment_table(C.byref(a), noisy, 1, None, 0))
+    t = np.zeros(n, np.int16)
+    N.check(N.lib().bnn_fragment_table(C.byref(a), noisy, 1, t.ctypes.data, n))
+    return t.astype(np.int64)
+
+
+def _w4(kin):
+    """Offsets of the feature_nn LDS image (bnn_layout.h, W4<KIN>)."""
+    np1 = (kin + 1) // 2
+    o = dict(L1A=0)
+    o["L1B"] = o["L1A"] + kin * 32
+    o["L2A"] = o["L1B"] + np1 * 16
+    o["L2B"] = o["L2A"] + 40 * 32
+    o["L3A"] = o["L2B"] + 20 * 16
+    o["L3B"] = o["L3A"] + 40 * 16
+    o["B1"] = o["L3B"] + 10 * 16
+    o["B2"] = o["B1"] + 40
+    o["B3"] = o["B2"] + 40
+    o["N"] = o["B3"] + 20
+    return o
+
+
+OFF = dict(W1=81, B1=1721, W2=1761, B2=3361, W3=3401, B3=4201, W4=4221, B4=5821, W5=5861, B5=7461, W6=7501, B6=7581, D=7583)
+
+
+@pytest.mark.parametrize("mask,noisy,kin", [(V50_MASK, 0, 31), (V50_MASK, 1, 41), (0, 0, 41), (1 << 7, 0, 41)])
+def test_accumulation_orders_are_permutations(N, mask, noisy, kin):
     live = [c for c in range(41) if noisy or not (mask >> c) & 1]
-    o0 = _order(N, mask, 0, noisy)
-    assert sorted(o0.tolist()) == sorted(live + [-1])            # every live column once + the bias slot
-    for layer in (1, 2, 3, 4, 5):
+    assert _order(N, mask, 0, noisy).tolist() == live           # bias first (the accumulator's start), then ascending inputs
+    for layer in (1, 2):
+        assert _order(N, mask, layer, noisy).tolist() == list(range(40))
+    for layer in (3, 4, 5):
         assert sorted(_order(N, mask, layer, noisy).tolist()) == list(range(40))
-    assert _table(N, mask, noisy, 1).shape[0] == 3 * nk1 + 30 + 20 + 12 + 8
+    assert _image(N, mask, noisy).size == (_w4(kin)["N"] + 15) // 16 * 16
 
 
-def test_fragment_tables_use_every_parameter_exactly_once(N):
-    """A operands: each weight of feature_nn / regress_nn appears in exactly one (register, lane) slot."""
-    OFF = dict(W1=81, B1=1721, W2=1761, B2=3361, W3=3401, B3=4201, W4=4221, B4=5821, W5=5861, B5=7461, W6=7501, B6=7581, D=7583)
-    f1 = _table(N, V50_MASK, 0, 1)
-    a1 = f1[:24 + 30 + 20].ravel()
-    a1 = a1[a1 != OFF["D"]]
+def test_operand_tables_use_every_parameter_exactly_once(N):
+    """Each weight and bias of feature_nn (LDS images of the 4x4x1 path) / regress_nn (16x16x4 fragments) sits in exactly one slot."""
+    img = _image(N, V50_MASK, 0)
+    o = _w4(31)
+    body = img[:o["N"]]
+    body = body[body != OFF["D"]]
     live = [0] + list(range(8, 38))
     want = {OFF["W1"] + n * 41 + c for n in range(40) for c in live} | set(range(OFF["B1"], OFF["B1"] + 40)) | \
-        set(range(OFF["W2"], OFF["B2"])) | set(range(OFF["W3"], OFF["B3"]))
-    assert len(a1) == len(want) and set(a1.tolist()) == want
-    b = f1[74:].ravel()
-    b = b[b != OFF["D"]]
-    assert set(b.tolist()) == set(range(OFF["B2"], OFF["B2"] + 40)) | set(range(OFF["B3"], OFF["B3"] + 20))
+        set(range(OFF["W2"], OFF["B2"] + 40)) | set(range(OFF["W3"], OFF["B3"] + 20))
+    assert len(body) == len(want) and set(body.tolist()) == want
+    assert (img[o["N"]:] == OFF["D"]).all()                      # tail padding reads the zero slot
     f2 = _table(N, V50_MASK, 0, 2)
     a2 = f2[:70].ravel()
     a2 = a2[a2 != OFF["D"]]
     want2 = set(range(OFF["W4"], OFF["B4"])) | set(range(OFF["W5"], OFF["B5"])) | set(range(OFF["W6"], OFF["B6"]))
     assert len(a2) == len(want2) and set(a2.tolist()) == want2
-    # generic (no mask) variant covers all 41 columns
-    g1 = _table(N, 0, 0, 1)[:33].ravel()
-    g1 = g1[g1 != OFF["D"]]
-    assert set(g1.tolist()) == set(range(OFF["W1"], OFF["B1"] + 40))
+    # any other mask: all 41 columns are in the image, the masked ones read the zero slot
+    g = _image(N, 1 << 7, 0)
+    og = _w4(41)
+    l1 = g[:og["L2A"]]
+    assert set(l1[l1 != OFF["D"]].tolist()) == {OFF["W1"] + n * 41 + c for n in range(40) for c in range(41) if c != 7}
+    n1 = _image(N, V50_MASK, 1)[:og["L2A"]]                      # noisy forward: every column live (masked ones carry noise)
+    assert set(n1[n1 != OFF["D"]].tolist()) == set(range(OFF["W1"], OFF["B1"]))
 
 
-def test_mfma_dataflow_emulation_matches_oracle(N, inputs):
-    """Evaluate feature_nn for one 16-row tile in numpy exactly the way the kernel wires v_mfma_f32_16x16x4_f32
-    (A = table-gathered weights, B = activations, accumulators feed the next layer) and compare with the oracle."""
+def test_image_dataflow_emulation_matches_oracle(N, inputs):
+    """Evaluate feature_nn for a few rows in numpy exactly the way the kernel reads its LDS images (v_mfma_f32_4x4x1: lane = row,
+    register r of neuron group n = neuron 4n + r, one input per instruction, four groups per broadcast ds_read_b128) and compare
+    with the oracle's latents."""
     from oracle import oracle as orc
     z = load_golden("case_swagfast_v50_0_slow.npz")
-    w = np.concatenate([z["w"], [0.0]]).astype(np.float32)
-    f1 = _table(N, V50_MASK, 0, 1).astype(np.int64)
-    x = inputs["slow"][0][:16]  # 16 rows = lane columns c
-    lane = np.arange(64)
-    g, c = lane >> 4, lane & 15
+    w = np.concatenate([z["w"], [0.0]]).astype(np.float64)
+    img = w[_image(N, V50_MASK, 0)]
+    o = _w4(31)
+    live = [0] + list(range(8, 38))
+    x = inputs["slow"][0][:8].astype(np.float64)[:, live]     # 8 rows x 31 live columns
 
-    def mfma(a, b, acc):  # acc[i][lane] : C[4g+i][c]; A lane (g,m): A[m][k=g]; B lane (g,c): B[k=g][c]
-        A = np.zeros((16, 4), np.float64); Bm = np.zeros((4, 16), np.float64)
-        A[lane & 15, lane >> 4] = a
-        Bm[lane >> 4, lane & 15] = b
-        Cm = A @ Bm
-        out = acc.copy()
-        for i in range(4):
-            out[i] += Cm[4 * g + i, c]
+    def layer(xin, A, Bimg, bias, n_groups, per_read):
+        """A: image [k][m][i][j] -> neuron 4*(4m+j)+i ; Bimg: leftover groups, `per_read` consecutive k per 16-float read."""
+        K = xin.shape[1]
+        M = (n_groups // 4)
+        out = np.tile(img[bias:bias + 4 * n_groups], (xin.shape[0], 1))
+        for k in range(K):
+            for m in range(M):
+                for i in range(4):
+                    for j in range(4):
+                        out[:, 4 * (4 * m + j) + i] += img[A + ((k * M + m) * 4 + i) * 4 + j] * xin[:, k]
+            if per_read == 2:      # groups 8, 9 of a 40-wide layer: [k/2][i][2*(k&1) + j]
+                for i in range(4):
+                    for j in range(2):
+                        out[:, 4 * (8 + j) + i] += img[Bimg + ((k >> 1) * 4 + i) * 4 + 2 * (k & 1) + j] * xin[:, k]
+            else:                  # group 4 of the latent layer: [k/4][i][k&3]
+                for i in range(4):
+                    out[:, 16 + i] += img[Bimg + ((k >> 2) * 4 + i) * 4 + (k & 3)] * xin[:, k]
         return out
 
-    def kmap_input(s, gg):
-        if gg < 3:
-            return 8 + 8 * gg + s
-        return 32 + s if s < 6 else (0 if s == 6 else -1)
-
-    b_in = np.zeros((8, 64))
-    for s in range(8):
-        for l in range(64):
-            col = kmap_input(s, l >> 4)
-            b_in[s, l] = 1.0 if col < 0 else x[l & 15, col]
-    h = [np.zeros((4, 64)) for _ in range(3)]
-    for s in range(8):
-        for mt in range(3):
-            h[mt] = mfma(w[f1[s * 3 + mt]], b_in[s], h[mt])
-    h = [np.maximum(v, 0) for v in h]
-    h2 = [np.stack([w[f1[74 + mt * 4 + i]] for i in range(4)]).astype(np.float64) for mt in range(3)]
-    for ks in range(10):
-        for mt in range(3):
-            h2[mt] = mfma(w[f1[24 + ks * 3 + mt]], h[ks >> 2][ks & 3], h2[mt])
-    h2 = [np.maximum(v, 0) for v in h2]
-    y = [np.stack([w[f1[86 + mt * 4 + i]] for i in range(4)]).astype(np.float64) for mt in range(2)]
-    for ks in range(10):
-        for mt in range(2):
-            y[mt] = mfma(w[f1[54 + ks * 2 + mt]], h2[ks >> 2][ks & 3], y[mt])
-    lat = np.zeros((16, 20))
-    for l in range(64):
-        for i in range(4):
-            lat[l & 15, 4 * (l >> 4) + i] = y[0][i, l]
-        lat[l & 15, 16 + (l >> 4)] = y[1][0, l]
+    h = np.maximum(layer(x, o["L1A"], o["L1B"], o["B1"], 10, 2), 0)
+    h2 = np.maximum(layer(h, o["L2A"], o["L2B"], o["B2"], 10, 2), 0)
+    lat = layer(h2, o["L3A"], o["L3B"], o["B3"], 5, 4)
     tp1, tp2 = z["tape_002"], z["tape_003"]
     _, ex = orc.forward(inputs["slow"][:1], z["w"], tp1[:1], tp2[:1], extras=True)
-    assert np.abs(lat - ex["latents"][0, :16]).max() < 5e-5
+    assert np.abs(lat - ex["latents"][0, :8]).max() < 5e-5
 
 
 def test_checkpoint_roundtrip_and_reference_file(tmp_path):
@@ -274,3 +287,40 @@ def test_sharded_moments_gloo_world2(B):
     s = orc.multiswag(x, wa, w2, pd, np.array([0, 1, 0], np.int32), z1, z2, eps).astype(np.float64)
     want = np.stack([s[..., 0].sum(0), (s[..., 0] ** 2).sum(0), s[..., 1].sum(0), (s[..., 1] ** 2).sum(0)], 1)
     assert got.shape == (B, 4) and np.array_equal(got, want)
+
+
+def test_integration_bindings_import_as_documented():
+    """the star import, the sys.modules alias and the shim directory on sys.path all give a module with
+    the reference's public names; `from spock import FeatureRegressor, FeatureRegressorXGB` (figures/multiswag_5_planet.py:28-29)
+    resolves.  Run in a clean interpreter so that nothing imported earlier can mask a failure."""
+    import subprocess
+    code = r'''
+import sys
+ns = {}
+exec("from bnn_chaos_model_amd.spock_reg_model import *", ns)
+for name in ("load_swag", "save_swag", "VarModel", "SWAGModel", "soft_clamp", "EPSILON", "copy", "mlp"):
+    assert name in ns, name
+import bnn_chaos_model_amd.spock_reg_model as m
+sys.modules["spock_reg_model"] = m
+import spock_reg_model
+assert spock_reg_model.load_swag is m.load_swag
+del sys.modules["spock_reg_model"]
+import os, bnn_chaos_model_amd
+sys.path.insert(0, os.path.join(os.path.dirname(bnn_chaos_model_amd.__file__), "shims"))
+import spock_reg_model as s2
+assert s2.load_swag is m.load_swag and s2.SWAGModel is m.SWAGModel and s2.copy is m.copy
+import spock
+from spock import FeatureRegressor, FeatureRegressorXGB
+from bnn_chaos_model_amd.regression import FeatureRegressor as FR
+assert FeatureRegressor is FR
+try:
+    FeatureRegressorXGB()
+except NotImplementedError:
+    pass
+else:
+    raise AssertionError("the XGBoost baseline is out of scope and must say so")
+print("ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
