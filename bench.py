@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
 """MultiSWAG ensemble-inference benchmark (BASELINE.json metric: system x MC-sample forward evals/s).
 
-One "step" = one pass of the hot path over one batch: every system of the batch under every weight
-draw of the MultiSWAG grid (30 seeds x 100 MC samples) -> (mu, std) per eval, then the predictive
-moments per system.  x, the ensemble and the outputs are resident in HBM before the timed region.
+One "step" = one pass of the hot path over one batch: every system of the batch under every weight draw of the grid
+-> (mu, std) per eval, then the predictive moments per system.  x, the ensemble and the outputs are resident in HBM before
+the timed region.  Default workload = BASELINE.json configs[2], the largest single-GPU configuration:
+1 000 000 systems x 100 MC samples (x = 16.4 GB, far beyond the 256 MiB Infinity Cache).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|noisy|tiny]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): systems are sharded over ranks
-(weak scaling: --systems is per GPU), every rank evaluates the same draws on its shard, and the one
-exchange of the path -- an all-gather of the per-system predictive moments -- is inside the step.
+--gpus N > 1 from a plain invocation launches N rank processes itself (a torch.distributed.run child, started BEFORE this
+process touches the GPU); under torch.distributed.run (WORLD_SIZE set) it is a rank.  One rank per GPU over RCCL: systems
+are sharded over ranks (weak scaling: the workload's systems are per GPU), every rank evaluates the same draws on its shard,
+and the one exchange of the path -- an all-gather of the per-system predictive moments -- is inside the step.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,32 +26,50 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_EVAL = 16408   # 100*41*4 B of x read + 8 B written
 ALG_FLOP_PER_EVAL = 814560   # 407 280 MAC: 100*(41*40 + 40*40 + 40*20) + (40*40 + 40*40 + 40*2)
+EXEC_FLOP_PER_EVAL = {31: 734560, 41: 814560}  # MACs the kernel issues: the v50 mask multiplies 31 of the 41 input columns
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector) peak
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
-    # BASELINE.json configs[1]: 30-seed MultiSWAG, 10k systems x 100 MC samples, fp32
+    # BASELINE.json configs[2]: 1M systems x 100 samples (one ensemble member per sample, members cycled)
+    "c3": dict(systems=1_000_000, seeds=30, samples=100, draws=100, name="configs[2]: 1M systems x 100 MC samples (30-seed ensemble cycled), fp32, fused draw+f1+pool+f2"),
+    # configs[1]: 30-seed MultiSWAG, 10k systems x 100 MC samples per seed
     "c2": dict(systems=10_000, seeds=30, samples=100, name="configs[1]: 30-seed MultiSWAG, 10k systems x 100 MC samples, fp32"),
-    # configs[2]: 1M systems x 100 samples (x = 16.4 GB, far beyond the 256 MiB Infinity Cache)
-    "c3": dict(systems=1_000_000, seeds=30, samples=100, draws=100, name="configs[2]: 1M systems x 100 samples (seeds cycled), fp32"),
+    # forward(noisy_val=True) with every normal generated in-kernel; not a BASELINE config
+    "noisy": dict(systems=10_000, seeds=30, samples=10, noisy=True, name="f4: forward(noisy_val=True), 10k systems x 300 draws, in-kernel Philox noise"),
     "tiny": dict(systems=512, seeds=30, samples=2, name="smoke-sized grid"),
 }
 
 
 def synthetic_x(B, device, seed):
-    """SURVEY.md section 8(d) 'slow' inputs: per-system base + 0.1 noise, column 0 = standardised time."""
+    """SURVEY.md section 8(d) 'slow' inputs: per-system base + 0.1 noise, column 0 = standardised time.  Built in slabs of
+    systems so that the temporaries stay small next to the 16.4 GB result at B = 1e6."""
     import torch
     g = torch.Generator(device=device).manual_seed(seed)
-    x = torch.randn(B, 1, 41, generator=g, device=device) + 0.1 * torch.randn(B, 100, 41, generator=g, device=device)
-    x[:, :, 0] = torch.linspace(-1.71, 1.74, 100, device=device)[None]
-    return x.contiguous()
+    x = torch.empty((B, 100, 41), dtype=torch.float32, device=device)
+    t0 = torch.linspace(-1.71, 1.74, 100, device=device)[None]
+    slab = 65536
+    for b0 in range(0, B, slab):
+        n = min(slab, B - b0)
+        xs = x[b0:b0 + n]
+        xs.normal_(generator=g).mul_(0.1)
+        xs.add_(torch.randn(n, 1, 41, generator=g, device=device))
+        xs[:, :, 0] = t0
+    return x
 
 
 def synthetic_ensemble(S, device):
-    """S SWAG states: the two converted pretrained seeds of tests/golden, perturbed per member (seeded)."""
+    """S SWAG states.  With tests/golden/ensemble_v50.npz present (the 30 converted pretrained seeds) the real ensemble is used;
+    otherwise the two converted seeds of tests/golden, perturbed per member (seeded): throughput does not depend on the values."""
     import numpy as np
     import torch
     gold = os.path.join(ROOT, "tests", "golden")
+    real = os.path.join(gold, "ensemble_v50.npz")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)
+    if os.path.exists(real):
+        z = np.load(real)
+        if z["w_avg"].shape[0] >= S:
+            return t(z["w_avg"][:S]), t(z["w2_avg"][:S]), t(z["pre_D"][:S])
     base = [np.load(os.path.join(gold, f"swag_v50_{i}.npz")) for i in (0, 12)]
     rng = np.random.default_rng(2024)
     wa, w2, pd = [], [], []
@@ -57,8 +79,7 @@ def synthetic_ensemble(S, device):
         wa.append(z["w_avg"] * jit)
         w2.append(z["w2_avg"] * jit * jit)
         pd.append(z["pre_D"] * jit[:, None])
-    t = lambda a: torch.as_tensor(np.stack(a)).to(device)
-    return t(wa), t(w2), t(pd)
+    return t(np.stack(wa)), t(np.stack(w2)), t(np.stack(pd))
 
 
 def host_threads():
@@ -86,8 +107,8 @@ def host_threads():
 
 
 def cpu_baseline(x_cpu, wa, w2, pd, budget_s=15.0):
-    """The oracle (oracle/bnn_oracle.c: fp32 C restatement, OpenMP over systems) on a bounded sample of the same
-    workload: same synthetic inputs, same ensemble, a few draws, sized to about `budget_s` seconds of CPU work."""
+    """The oracle (oracle/bnn_oracle.c: fp32 C restatement, OpenMP over systems) on a BOUNDED sample of the same workload:
+    the first systems of the same synthetic batch, the same ensemble, as many draws as fit in about `budget_s` seconds."""
     import numpy as np
     from oracle import oracle as orc
     cores = host_threads()
@@ -105,11 +126,11 @@ def cpu_baseline(x_cpu, wa, w2, pd, budget_s=15.0):
 
     Bmax = x_cpu.shape[0]
     run(Bmax, 1)                                        # warm the thread pool
-    t_probe = run(Bmax, 8)
-    Js = max(8, int(min(1000, 8 * budget_s / t_probe)))  # whole sample = Bmax systems x Js draws, about budget_s seconds
+    t_probe = run(Bmax, 4)
+    Js = max(4, int(min(1000, 4 * budget_s / t_probe)))  # whole sample = Bmax systems x Js draws, about budget_s seconds
     t = run(Bmax, Js)
     return {"value": Bmax * Js / t, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": f"{Bmax} systems x {Js} draws = {Bmax * Js} evals in {t:.1f} s; same synthetic inputs and ensemble; "
+            "sample": f"first {Bmax} systems of the batch x {Js} draws = {Bmax * Js} evals in {t:.1f} s; same synthetic inputs and ensemble; "
                       f"oracle/bnn_oracle.c (fp32, fmaf chains), OpenMP threads = {cores}"}
 
 
@@ -157,57 +178,103 @@ def torch_cpu_baseline(x_cpu, wa, w2, pd, budget_s=8.0):
     t = time.perf_counter() - t0
     B = x.shape[0]
     return {"value": B * Js / t, "unit": "evals/s", "cores": cores, "kind": "port (eager torch CPU ops in the reference's order)",
-            "sample": f"{B} systems x {Js} draws in {t:.1f} s, torch {torch.__version__}, {cores} threads"}
+            "sample": f"first {B} systems of the batch x {Js} draws in {t:.1f} s, torch {torch.__version__}, {cores} threads"}
 
 
-def main():
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Plain `python bench.py --gpus N`: start N ranks as a torch.distributed.run child and return its exit code.  This
+    process has not touched the GPU (nothing but `import` has run), so the children are fresh processes, not re-execs."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--systems", type=int, default=0, help="systems per GPU (overrides the workload)")
     ap.add_argument("--samples", type=int, default=0)
     ap.add_argument("--unfused", action="store_true", help="separate ops.swag_draw + ops.forward calls")
     ap.add_argument("--single-launch", action="store_true", help="in-kernel draw in every workgroup prologue (no workspace)")
     ap.add_argument("--spb", type=int, default=0, help="systems per workgroup (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-sample-systems", type=int, default=8192, help="systems of the batch the CPU baselines are timed on")
+    ap.add_argument("--allow-gloo", action="store_true", help="accept a gloo moments gather when RCCL cannot start (the line says degraded)")
+    ap.add_argument("--launcher-selftest", action="store_true", help="ranks only rendezvous (gloo, CPU) and report; no GPU work")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
+        sys.exit(f"bench.py --gpus {args.gpus} is running under a launcher with WORLD_SIZE={world}")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
     import torch.distributed as dist
+
+    if args.launcher_selftest:
+        dist.init_process_group("gloo")
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        if rank == 0:
+            print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": int(ones.item()), "collective": "gloo"}), flush=True)
+        dist.destroy_process_group()
+        return
+
     from bnn_chaos_model_amd import ops
     from bnn_chaos_model_amd.distributed import all_gather_moments
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run with N ranks")
     # BNN_BENCH_REHEARSE=1: every rank on cuda:0 with gloo -- exercises the N>1 code path on a one-GPU box
     rehearse = os.environ.get("BNN_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    degraded = False
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             dist.init_process_group("gloo")
+            degraded = True
         else:
             try:
                 dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
-                probe = torch.zeros(1, dtype=torch.float64, device=dev)
+                probe = torch.ones(1, dtype=torch.float64, device=dev)
                 dist.all_reduce(probe)                            # fail here, not inside the timed region
                 torch.cuda.synchronize()
-            except Exception as e:  # the one exchange of the path is 160 KB per rank: gloo via host memory still measures the job
-                print(f"[bench] RCCL unavailable ({type(e).__name__}: {e}); falling back to gloo for the moments gather", file=sys.stderr)
+            except Exception as e:
+                if not args.allow_gloo:   # a gloo number must never pass for an xGMI measurement
+                    print(f"[bench] rank {rank}: RCCL could not start ({type(e).__name__}: {e}); rerun with --allow-gloo to time the "
+                          "job with the moments gather on gloo (marked degraded)", file=sys.stderr, flush=True)
+                    sys.exit(3)
+                print(f"[bench] RCCL unavailable ({type(e).__name__}: {e}); gloo for the moments gather (degraded)", file=sys.stderr)
                 try:
                     dist.destroy_process_group()
                 except Exception:
                     pass
                 dist.init_process_group("gloo")
+                degraded = True
+        ones = torch.ones(1, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
     wl = dict(WORKLOADS[args.workload])
     if args.systems:
@@ -216,19 +283,23 @@ def main():
         wl["samples"] = args.samples
     B, S, M = wl["systems"], wl["seeds"], wl["samples"]
     J = wl.get("draws", S * M)
+    noisy = bool(wl.get("noisy"))
 
     x = synthetic_x(B, dev, seed=123 + rank)          # this rank's shard: global systems [rank*B, (rank+1)*B)
     wa, w2, pd = synthetic_ensemble(S, dev)           # replicated ensemble (29 MB)
     seed_idx = (torch.arange(J, dtype=torch.int32) % S).to(dev)  # dense grid: every seed x every sample
     out = torch.empty((J, B, 2), dtype=torch.float32, device=dev)
     plan = ops.get_plan()
+    W_noisy = ops.swag_draw(wa, w2, pd, seed_idx, philox_seed=99, plan=plan) if noisy else None
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(i, timed):
         if timed:
-            ev0[i].record()
-        if args.unfused:
+            ev0[i].record()          # on torch's current stream = the stream the ops launch on (ops.N.stream_ptr())
+        if noisy:
+            o = ops.forward(x, W_noisy, philox_seed=99, draw_id0=0, system_id0=rank * B, plan=plan, noisy=True, systems_per_block=args.spb)
+        elif args.unfused:
             W = ops.swag_draw(wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, plan=plan)
             o = ops.forward(x, W, philox_seed=99, draw_id0=0, system_id0=rank * B, plan=plan, systems_per_block=args.spb)
         else:
@@ -255,7 +326,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
@@ -264,37 +335,47 @@ def main():
     value = evals_per_step * args.steps / dt
     if rank == 0:
         evals_per_launch = B * J
+        kin = 41 if noisy else 31
         ach_tflops = evals_per_launch * ALG_FLOP_PER_EVAL / (kern_ms * 1e-3) / 1e12
+        exe_tflops = evals_per_launch * EXEC_FLOP_PER_EVAL[kin] / (kern_ms * 1e-3) / 1e12
         ach_gbs = evals_per_launch * ALG_BYTES_PER_EVAL / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf):   # HBM bytes per launch from the rocprofv3 PMC passes of this same command (scripts/profile_r02.sh)
             try:
-                rec = json.load(open(tf))
-                if rec.get("workload") == args.workload and rec.get("systems") == B and rec.get("draws") == J:
-                    traffic = rec.get("hbm_bytes_per_launch")
+                rec = json.load(open(tf)).get(args.workload)
+                if rec and rec.get("systems") == B and rec.get("draws") == J:
+                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
             except Exception:
                 traffic = None
+        kernel = ("bnn_forward_kernel<41,noisy> (ops.forward, noisy_val=True, in-kernel Philox)" if noisy else
+                  "ops.swag_draw + ops.forward" if args.unfused else
+                  ("multiswag, in-kernel draw per workgroup" if args.single_launch else "multiswag, draw-once workspace + forward"))
         res = {
             "metric": "system x MC-sample forward evals/sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "systems_per_gpu": B, "seeds": S, "mc_samples": M, "draws": J, "timesteps": 100,
-                       "features": 41, "noise": "in-kernel Philox4x32-10", "kernel": "ops.swag_draw + ops.forward" if args.unfused else ("multiswag, in-kernel draw per workgroup" if args.single_launch else "multiswag, draw-once workspace + forward"),
+                       "features": 41, "noise": "in-kernel Philox4x32-10", "kernel": kernel,
                        "sharding": f"systems over {world} rank(s), all-gather of moments",
-                       "collective": (dist.get_backend() if world > 1 else "none")},
+                       "collective": (dist.get_backend() if world > 1 else "none"), "degraded": degraded, "ranks_seen": ranks_seen},
             "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "flop_per_eval": ALG_FLOP_PER_EVAL,
+                         "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved_executed": exe_tflops, "frac_executed": exe_tflops / PEAK_F32_MFMA_TFLOPS,
+                         "kernel_ms": kern_ms, "flop_per_eval": ALG_FLOP_PER_EVAL, "flop_per_eval_executed": EXEC_FLOP_PER_EVAL[kin],
+                         "note": "frac counts the algorithm's 814 560 flop/eval (SURVEY 8d); frac_executed counts the MACs the kernel issues "
+                                 "(the v50 mask drops 10 of 41 input columns); kernel_ms = HIP events around the draw + forward launches",
                          "hbm_algorithmic_GBs": ach_gbs, "hbm_frac_of_8TBs": ach_gbs / PEAK_HBM_GBS},
         }
         if not args.no_cpu_baseline and world == 1:
+            ns = min(B, args.cpu_sample_systems)
+            xs = x[:ns].cpu().numpy()
             try:
-                res["cpu_baseline"] = cpu_baseline(x.cpu().numpy(), wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
+                res["cpu_baseline"] = cpu_baseline(xs, wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
             except Exception as e:  # the oracle is a checker, never a dependency of the measured path
                 res["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
             try:
-                res["cpu_baseline_torch"] = torch_cpu_baseline(x.cpu().numpy(), wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
+                res["cpu_baseline_torch"] = torch_cpu_baseline(xs, wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
             except Exception as e:
                 res["cpu_baseline_torch"] = {"value": None, "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)

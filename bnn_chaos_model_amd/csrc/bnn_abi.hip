@@ -251,6 +251,18 @@ __global__ void bnn_philox_fill_kernel(int kind, uint64_t seed, int64_t id0, int
         int el = (int)(i % S2);
         int64_t sys = (i / S2) % B, row = i / (S2 * B);
         out[i] = philox_sys4(kind == 2 ? TAG_EPS : TAG_SUM, id0 + row, sys0 + sys, el >> 2, seed)[el & 3];
+    } else if (kind == 5) {  // candidates of the truncated-normal draw [n_rows, B, nsamp = width] (bnn_stats.hip.h)
+        int64_t total = n_rows * B * width;
+        if (i >= total) return;
+        int k = (int)(i % width);
+        int64_t sys = (i / width) % B, row = i / ((int64_t)width * B);
+        out[i] = philox_sys4(TAG_TNS, id0 + row, sys0 + sys, k >> 2, seed)[k & 3];
+    } else if (kind == 6) {  // survival level of the prior draw [n_rows, B], uniform on (0, 1]
+        int64_t total = n_rows * B;
+        if (i >= total) return;
+        int64_t sys = i % B, row = i / B;
+        const uint4 q = philox4x32_10(philox_sys_ctr(TAG_US, id0 + row, sys0 + sys, 0), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        out[i] = ((float)(q.x >> 8) + 1.0f) * 5.9604644775390625e-8f;
     } else {  // kind 3: eps_in [n_rows, B, T = width, 41]: block t*7 + col/6, normal col%6 (bnn_common.hip.h)
         const int T = width;
         int64_t per = (int64_t)T * F, total = n_rows * B * per;
@@ -737,8 +749,9 @@ int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments,
 
 int bnn_philox_normal_f32(int32_t kind, uint64_t philox_seed, int64_t id0, int64_t n_rows, int64_t B, int64_t system_id0, int32_t width,
                           float* out, void* stream) {
-    if (!out || kind < 0 || kind > 4 || n_rows < 0) return fail(BNN_ERR_INVALID, "bad argument");
-    int64_t total = (kind == 2 || kind == 4) ? n_rows * B * S2 : kind == 3 ? n_rows * B * (int64_t)width * F : n_rows * (int64_t)width;
+    if (!out || kind < 0 || kind > 6 || n_rows < 0) return fail(BNN_ERR_INVALID, "bad argument");
+    int64_t total = (kind == 2 || kind == 4) ? n_rows * B * S2 : kind == 3 ? n_rows * B * (int64_t)width * F : kind == 5 ? n_rows * B * (int64_t)width
+                    : kind == 6 ? n_rows * B : n_rows * (int64_t)width;
     if (total == 0) return 0;
     hipLaunchKernelGGL(bnn_philox_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind, philox_seed,
                        id0, n_rows, B, system_id0, width, out);

@@ -13,19 +13,22 @@ import torch
 import torch.distributed as dist
 
 
-def shard_bounds(B, world):
-    """Contiguous, balanced partition of B systems: list of (lo, hi), the first B % world shards one longer."""
-    base, rem = divmod(int(B), int(world))
+def shard_bounds(B, world, group=1):
+    """Contiguous, balanced partition of B systems: list of (lo, hi), the first shards one unit longer.  group > 1 keeps
+    `group` consecutive systems (the trios of one simulation) on one rank, so that the min over trios stays local."""
+    if int(B) % int(group):
+        raise ValueError("B must be a multiple of group")
+    base, rem = divmod(int(B) // int(group), int(world))
     out, lo = [], 0
     for r in range(world):
-        n = base + (1 if r < rem else 0)
+        n = (base + (1 if r < rem else 0)) * int(group)
         out.append((lo, lo + n))
         lo += n
     return out
 
 
 def all_gather_moments(local, B, group=None):
-    """local [B_r, M] (this rank's slice, in shard_bounds order) -> [B, M] on every rank.  One collective."""
+    """local [B_r, M] (this rank's slice, in shard_bounds order) -> [B, M] on every rank.  One collective.
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local
@@ -37,6 +40,8 @@ def all_gather_moments(local, B, group=None):
         raise ValueError("local shard does not match shard_bounds(B, world)[rank]")
     if local.is_cuda and dist.get_backend(group) == "gloo":  # CPU rehearsal of the N>1 path: stage through host memory
         return all_gather_moments(local.cpu(), B, group).to(local.device)
+    if nmax == 0:
+        return local
     if all(hi - lo == nmax for lo, hi in bounds):
         out = torch.empty((world * nmax, M), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
@@ -98,3 +103,35 @@ class MultiSwagSharded:
         if x_local.shape[0] != hi - lo:
             raise ValueError(f"rank {rank} must hold systems [{lo}, {hi})")
         return all_gather_moments(self.local_moments(x_local, seed_idx, philox_seed, lo, scale), B_total, self.group)
+
+
+    # ---- what the evaluation scripts consume, at any number of draws, in O(B_r * bins) memory ----------
+    def local_bands(self, x_local, seed_idx, q, philox_seed, system_id0, trios=1, scale=0.5, stats=None, segments=None):
+        """Fused forward + statistics epilogue in slabs of draws -> quantile sketch of this rank's simulations.
+        Returns float32 [B_r / trios, len(q) + 1]: the percentiles q, then the mean (np.average) over the draws."""
+        ops = self.ops
+        wa, w2, pd = self.state
+        sk = ops.QuantileSketch(x_local.shape[0], group=trios, segments=segments, device=x_local.device)
+        st = stats or ops.stats_params(device=x_local.device)
+        J = seed_idx.numel()
+        for j0 in range(0, J, self.draws_per_launch):
+            idx = seed_idx[j0: j0 + self.draws_per_launch]
+            sk.update(ops.multiswag_stats(x_local, wa, w2, pd, idx, st=st, scale=scale, philox_seed=philox_seed, draw_id0=j0,
+                                          system_id0=system_id0, plan=self.plan))
+        if sk.n_sims == 0:
+            return torch.empty((0, len(q) + 1), dtype=torch.float32, device=x_local.device)
+        return torch.cat([sk.percentiles(q), sk.mean().float()[:, None]], 1)
+
+    def predictive_quantiles(self, x_local, B_total, seed_idx, q=(2.5, 16.0, 50.0, 84.0, 97.5), philox_seed=0, trios=1, scale=0.5,
+                             stats=None, segments=None):
+        """Per-simulation percentile bands + mean of the post-epilogue log10 instability time (truncated-normal draw, prior
+        resampling, min over `trios` consecutive systems: figures/multiswag_5_planet.py:388-428, 484-489) for the dense
+        (systems x draws) grid, sharded by simulation: [B_total / trios, len(q) + 1] on every rank after ONE all-gather.
+        Neither [J,B,2] nor [J,B] is ever materialised beyond one slab of `draws_per_launch` draws."""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        lo, hi = shard_bounds(B_total, world, trios)[rank]
+        if x_local.shape[0] != hi - lo:
+            raise ValueError(f"rank {rank} must hold systems [{lo}, {hi})")
+        local = self.local_bands(x_local, seed_idx, q, philox_seed, lo, trios, scale, stats, segments)
+        return all_gather_moments(local, B_total // trios, self.group)

@@ -262,8 +262,10 @@ def regress(summary, W, plan=None, debug=False):
 
 def philox_normal(kind, philox_seed, id0, n_rows, width=0, B=0, system_id0=0, device="cuda"):
     """The normals the kernels generate in-kernel: kind 0 -> z1[n_rows,width], 1 -> z2[n_rows,width], 2 -> eps[n_rows,B,2,20],
-    3 -> eps_in[n_rows,B,T=width,41], 4 -> eps_sum[n_rows,B,40]."""
-    shape = {2: (n_rows, B, 2, LATENT), 3: (n_rows, B, width, 41), 4: (n_rows, B, 2 * LATENT)}.get(kind, (n_rows, width))
+    3 -> eps_in[n_rows,B,T=width,41], 4 -> eps_sum[n_rows,B,40]; statistics epilogue: 5 -> truncated-normal candidates
+    [n_rows,B,nsamp=width], 6 -> survival level of the prior draw [n_rows,B]."""
+    shape = {2: (n_rows, B, 2, LATENT), 3: (n_rows, B, width, 41), 4: (n_rows, B, 2 * LATENT), 5: (n_rows, B, width),
+             6: (n_rows, B)}.get(kind, (n_rows, width))
     out = torch.empty(shape, dtype=torch.float32, device=device)
     N.check(N.lib().bnn_philox_normal_f32(kind, int(philox_seed), int(id0), n_rows, B, int(system_id0), width, N.ptr(out),
                                           N.stream_ptr()))

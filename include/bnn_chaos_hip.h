@@ -176,7 +176,9 @@ int bnn_group_min_f32(const float* vals, int64_t n, int32_t group, float* out, v
 /* The normals the kernels generate when a noise pointer is NULL, written out for inspection:
  *   kind 0: z1 [n_draws, d]   kind 1: z2 [n_draws, K]   kind 2: eps [rows, B, 2, 20]
  *   kind 3: eps_in [rows, B, T = width, 41] (six normals per Philox block)   kind 4: eps_sum [rows, B, 40]
- *   id0 = draw_id0 (kinds 0,1) or output-row id0 (kinds 2-4); system_id0 only for kinds 2-4. */
+ *   kind 5: candidates of the statistics epilogue's truncated-normal draw [rows, B, nsamp = width]
+ *   kind 6: survival level of its prior draw [rows, B], uniform on (0, 1]
+ *   id0 = draw_id0 (kinds 0,1) or output-row id0 (kinds 2-6); system_id0 only for kinds 2-6. */
 int bnn_philox_normal_f32(int32_t kind, uint64_t philox_seed, int64_t id0, int64_t n_rows, int64_t B,
                           int64_t system_id0, int32_t width, float* out, void* stream);
 

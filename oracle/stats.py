@@ -50,3 +50,41 @@ def resample_prior(samps, u, normalization, threshold=9.0):
         cum, edges = prior_table(n, normalization)
         out[mask] = interp1d_linear(cum, edges, u[:n])
     return out
+
+
+# ---- the streaming (Philox) form of the epilogue: restatement of bnn_chaos_model_amd/csrc/bnn_stats.hip.h -------------------
+def prior_survival_table(thr=9.0, top=100.0, m=8192):
+    """S(t_i) = P(T > t_i | T >= thr) of the prior (:400-404) in closed form (float64), rounded to fp32; returns (S, step)."""
+    from scipy.special import erfc
+    a, b, c, d = 3.27086190404742, 0.424033970670719, 10.8793430454878, 0.200351029031774
+    G = lambda t: a / b * np.exp(-b * t) - c * 0.5 * np.sqrt(np.pi / d) * erfc(np.sqrt(d) * t)
+    step = (top - thr) / (m - 1)
+    S = (G(thr + step * np.arange(m)) / G(thr)).astype(np.float32)
+    S[0] = 1.0
+    return S, step
+
+
+def stream_epilogue(musd, cand, level, left=4.0, thr=9.0, top=100.0, m=8192):
+    """musd [R,B,2] fp32; cand [R,B,nsamp] fp32 normals; level [R,B] fp32 in (0,1] -> t [R,B] fp32, in fp32 arithmetic:
+    first candidate z*sd+mu above `left` (else the first one); values >= thr are replaced by the prior's inverse survival
+    function at `level` (bisection on the fp32 table + linear interpolation)."""
+    mu, sd = musd[..., 0].astype(np.float32), musd[..., 1].astype(np.float32)
+    v = (cand * sd[..., None]).astype(np.float32) + mu[..., None]            # fp32 multiply, then fp32 add (no fma)
+    ok = v > np.float32(left)
+    first = np.take_along_axis(v, ok.argmax(-1)[..., None], -1)[..., 0]
+    t = first.astype(np.float32)
+    S, step = prior_survival_table(thr, top, m)
+    step = np.float32(step)
+    sel = t >= np.float32(thr)
+    lv = level[sel].astype(np.float32)
+    # lo = last knot with S[lo] >= v  (S is non-increasing): searchsorted on the reversed (ascending) table
+    lo = (m - np.searchsorted(S[::-1], lv, side="left") - 1).clip(0, m - 2)
+    hi = lo + 1
+    a, b = S[lo], S[hi]
+    frac = ((a - lv) / (a - b)).astype(np.float32)
+    val = np.float32(thr) + step * (lo.astype(np.float32) + frac)
+    tail = ~(lv > S[m - 1])
+    val = np.where(tail, np.float32(thr) + step * np.float32(m - 1), val).astype(np.float32)
+    t = t.copy()
+    t[sel] = val
+    return t

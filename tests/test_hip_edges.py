@@ -200,13 +200,16 @@ def test_sample_with_philox_rng(swag_states, tmp_path):
     m = srm.load_swag(str(p))
     m.load(m.w_avg)
     x = torch.tensor(synth(16, 100, 4))
+    N = 3200
     torch.manual_seed(0); np.random.seed(0)
-    a = m.sample(x, samples=200)
+    a = m.sample(x, samples=N)
     m.rng, m.philox_seed = "philox", 5
     np.random.seed(1)
-    b = m.sample(x, samples=200)
+    b = m.sample(x, samples=N)
     assert a.shape == b.shape == (16,)
-    assert np.abs(a - b).max() < 2.0  # means of 200 draws with std up to 6: SE of the difference <= 0.6
+    # each is a mean of N draws of mu + n * std with std <= 6: the SE of the difference is <= sqrt(2) * 6 / sqrt(N) = 0.15,
+    # so 0.6 is a 4-sigma bound for the worst possible system
+    assert np.abs(a - b).max() < 0.6, np.abs(a - b).max()
 
 
 def test_feature_pack_matches_reference(ops):
@@ -326,3 +329,76 @@ def test_hip_graph_capture_and_replay(ops, swag_states):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ops.multiswag(x, wa, w2, pd, idx, philox_seed=9, single_launch=False))
+
+
+def test_hundred_thousand_draws_in_one_call(ops, swag_states):
+    """The 'paper-ready' 5-planet setting is 10 000 samples x 10 chunks = 100 000 draws (figures/multiswag_5_planet.py:52-55,
+    295-298): more than a grid.y can hold.  One call == the same call in slabs of draws, bit for bit, in both launch modes."""
+    wa = dev(np.stack([swag_states[0]["w_avg"], swag_states[12]["w_avg"]]))
+    w2 = dev(np.stack([swag_states[0]["w2_avg"], swag_states[12]["w2_avg"]]))
+    pd = dev(np.stack([swag_states[0]["pre_D"], swag_states[12]["pre_D"]]))
+    B, nch, samples = 20, 10, 10_000
+    J = samples * nch
+    x = dev(synth(B, 100, 3))
+    idx = torch.as_tensor(np.random.default_rng(1).integers(0, 2, J).astype(np.int32))
+    W = ops.swag_draw(wa, w2, pd, idx, philox_seed=21)
+    assert W.shape == (J, 7583) and torch.isfinite(W).all()
+    for j0 in (0, 65_530, 99_990):                                  # rows straddling the old 65 535 limit
+        assert torch.equal(W[j0:j0 + 10], ops.swag_draw(wa, w2, pd, idx[j0:j0 + 10], philox_seed=21, draw_id0=j0))
+    del W
+    one = ops.multiswag(x, wa, w2, pd, idx, nchunks=nch, philox_seed=21, single_launch=False)
+    assert one.shape == (samples, B, 2) and torch.isfinite(one).all()
+    assert torch.equal(one, ops.multiswag(x, wa, w2, pd, idx, nchunks=nch, philox_seed=21, single_launch=True))
+    for s0, s1 in ((0, 100), (6_500, 6_600), (9_900, 10_000)):      # slabs of samples = slabs of draws at draw_id0 = s0 * nch
+        part = ops.multiswag(x, wa, w2, pd, idx[s0 * nch:s1 * nch], nchunks=nch, philox_seed=21, draw_id0=s0 * nch)
+        assert torch.equal(part, one[s0:s1])
+
+
+def test_two_streams_do_not_share_a_workspace(ops, swag_states):
+    """Each call allocates its own draw workspace: the same op running concurrently on two streams gives each its own result."""
+    wa = dev(np.stack([swag_states[0]["w_avg"], swag_states[12]["w_avg"]]))
+    w2 = dev(np.stack([swag_states[0]["w2_avg"], swag_states[12]["w2_avg"]]))
+    pd = dev(np.stack([swag_states[0]["pre_D"], swag_states[12]["pre_D"]]))
+    x = dev(synth(2048, 100, 5))
+    ia = torch.zeros(64, dtype=torch.int32)
+    ib = torch.ones(64, dtype=torch.int32)
+    want_a = ops.multiswag(x, wa, w2, pd, ia, philox_seed=1, single_launch=False)
+    want_b = ops.multiswag(x, wa, w2, pd, ib, philox_seed=2, single_launch=False)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            got_a = ops.multiswag(x, wa, w2, pd, ia, philox_seed=1, single_launch=False)
+        with torch.cuda.stream(sb):
+            got_b = ops.multiswag(x, wa, w2, pd, ib, philox_seed=2, single_launch=False)
+        torch.cuda.synchronize()
+        assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b)
+
+
+def test_mis_shaped_tensors_raise_before_any_launch(ops, swag_states):
+    wa = dev(swag_states[0]["w_avg"][None]); w2 = dev(swag_states[0]["w2_avg"][None]); pd = dev(swag_states[0]["pre_D"][None])
+    x = dev(synth(8, 100, 1))
+    idx = torch.zeros(4, dtype=torch.int32)
+    W = ops.swag_draw(wa, w2, pd, idx, philox_seed=1)
+    with pytest.raises(ValueError):
+        ops.forward(x, W[:, :7000].contiguous())
+    with pytest.raises(ValueError):
+        ops.forward(x, W[0])
+    with pytest.raises(ValueError):
+        ops.forward(x, W, eps=torch.zeros(4, 8, 2, 20).cuda(), eps_in=torch.zeros(4, 8, 100, 40).cuda(), eps_sum=torch.zeros(4, 8, 40).cuda())
+    with pytest.raises(ValueError):
+        ops.forward(x, W, eps=torch.zeros(4, 8, 2, 20).cuda(), eps_in=torch.zeros(4, 8, 100, 41).cuda())
+    with pytest.raises(ValueError):
+        ops.forward(x, W, nchunks=3)
+    with pytest.raises(ValueError):
+        ops.multiswag(x, wa[:, :100].contiguous(), w2, pd, idx)
+    with pytest.raises(ValueError):
+        ops.multiswag(x, wa, w2[:, :100].contiguous(), pd, idx)
+    with pytest.raises(ValueError):
+        ops.multiswag(x, wa, w2, pd, idx, nchunks=3)
+    with pytest.raises(ValueError):
+        ops.multiswag(x, wa, w2, pd, idx, z1=torch.zeros(4, 7583).cuda())
+    with pytest.raises(NotImplementedError):
+        ops.multiswag(x[..., :40].contiguous(), wa, w2, pd, idx)
+    mom = ops.moments(torch.zeros(3, 0, 2).cuda())                  # an empty shard (more ranks than systems)
+    assert mom.shape == (0, 4)

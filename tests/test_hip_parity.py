@@ -272,3 +272,25 @@ def test_error_codes(ops):
         ops.forward(torch.zeros(2, 99, 41, device="cuda"), torch.zeros(1, 7583, device="cuda"))
     with pytest.raises(N.NativeError):
         N.Plan(0, hidden=32)
+
+
+def test_all_thirty_pretrained_seeds(ops, orc):
+    """The real 30-member ensemble in ONE launch (seed_idx = 0..29, the reference's taped normals per member) against the
+    reference's own forward_swag_fast outputs (1e-5 relative, no exceedances), its sampled weights, and the oracle bit for bit
+    -- including the five members with a negative variance element (v50_3, 12, 22, 25, 26)."""
+    ens = load_golden("ensemble_v50.npz")
+    z = load_golden("case_all_seeds.npz")
+    wa, w2, pd = dev(ens["w_avg"]), dev(ens["w2_avg"]), dev(ens["pre_D"])
+    idx = torch.arange(30, dtype=torch.int32)
+    W = ops.swag_draw(wa, w2, pd, idx, dev(z["z1"]), dev(z["z2"]), scale=0.5).cpu().numpy()
+    assert np.abs(W.astype(np.float64) - z["w"]).max() <= 2e-6
+    for single in (False, True):
+        out = ops.multiswag(dev(z["x"]), wa, w2, pd, idx, dev(z["z1"]), dev(z["z2"]), dev(z["eps"]), single_launch=single).cpu().numpy()
+        nbad, mx = close_report(out, z["out"])
+        assert nbad == 0, (single, nbad, mx)
+    sched = kernel_schedule(ops, orc)
+    for i in (3, 12, 22, 25, 26, 0, 29):
+        w_orc = orc.swag_draw(ens["w_avg"][i], ens["w2_avg"][i], ens["pre_D"][i], z["z1"][i], z["z2"][i], scale=0.5)
+        assert np.array_equal(W[i], w_orc), i
+        o_k = orc.forward(z["x"], w_orc, z["eps"][i, :, 0], z["eps"][i, :, 1], sched=sched)
+        assert np.abs(out[i] - o_k).max() <= 2e-6, i

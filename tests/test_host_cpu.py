@@ -324,3 +324,21 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, PYTHONPATH=ROOT))
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain invocation starts two ranks itself (torch.distributed.run child, 127.0.0.1
+    rendezvous); --launcher-selftest makes the ranks stop after the rendezvous + an all-reduce of ones (no GPU here)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2
+    # under a launcher the rank count must agree with --gpus
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], cwd=ROOT, env=env2,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stdout + r.stderr)

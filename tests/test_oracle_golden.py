@@ -212,3 +212,26 @@ def test_statistics_epilogue_matches_reference_fragments():
     assert np.array_equal(np.min(rs, 2).T, z["outs"])
     from scipy.integrate import quad
     assert quad(stats.prior_pdf, a=9, b=np.inf)[0] == float(z["normalization"])
+
+
+def test_all_thirty_pretrained_seeds_match_reference():
+    """Every member of the pretrained ensemble (tests/golden/ensemble_v50.npz, converted states) under the reference's own
+    forward_swag_fast run (case_all_seeds.npz): oracle draw <= 2e-6 from the reference's sampled weights, outputs within the
+    1e-5 relative bar.  The five members with a negative w2_avg - w_avg^2 element are among them."""
+    ens = load_golden("ensemble_v50.npz")
+    z = load_golden("case_all_seeds.npz")
+    assert ens["w_avg"].shape == (30, 7583) and ens["pre_D"].shape == (30, 7583, 30)
+    neg = np.flatnonzero(ens["negative_variance_elements"])
+    assert neg.tolist() == [3, 12, 22, 25, 26]
+    for i in range(30):
+        var = ens["w2_avg"][i] - ens["w_avg"][i] ** 2
+        assert int((var < 0).sum()) == int(ens["negative_variance_elements"][i])
+        w = orc.swag_draw(ens["w_avg"][i], ens["w2_avg"][i], ens["pre_D"][i], z["z1"][i], z["z2"][i], scale=0.5)
+        assert np.isfinite(w).all() and np.abs(w.astype(np.float64) - z["w"][i]).max() <= 2e-6, i
+        out = orc.forward(z["x"], w, z["eps"][i, :, 0], z["eps"][i, :, 1])
+        nbad, mx = close_report(out, z["out"][i])
+        assert nbad == 0, (i, nbad, mx)
+    # the two single-seed fixtures are rows of the ensemble
+    for si in (0, 12):
+        st = load_golden(f"swag_v50_{si}.npz")
+        assert np.array_equal(st["w_avg"], ens["w_avg"][si]) and np.array_equal(st["pre_D"], ens["pre_D"][si])

@@ -1,0 +1,143 @@
+"""The streaming statistics epilogue: truncated-normal draw + prior resampling per evaluation, fused
+into the forward kernel's tail, min over trios + per-simulation quantile sketch in O(n_sims * bins) memory.
+Checked against the numpy restatement in oracle/stats.py, against the un-fused path bit for bit, and against exact order
+statistics of materialised samples at configs[1] size.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bnn_chaos_model_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def ens(swag_states):
+    d = lambda k: torch.as_tensor(np.stack([swag_states[0][k], swag_states[12][k]])).cuda()
+    return d("w_avg"), d("w2_avg"), d("pre_D")
+
+
+def synth(B, seed):
+    import bench
+    return bench.synthetic_x(B, torch.device("cuda"), seed)
+
+
+def test_epilogue_matches_the_oracle_restatement(ops):
+    """stats_draw on arbitrary (mu, std) pairs == oracle.stats.stream_epilogue fed the very normals / uniforms the kernel draws."""
+    from oracle import stats as ostats
+    rng = np.random.default_rng(3)
+    R, B = 7, 501
+    mu = rng.uniform(4.0, 12.0, (R, B)).astype(np.float32)
+    sd = rng.uniform(0.5, 6.0, (R, B)).astype(np.float32)
+    mu[0, :5] = 4.0; sd[0, :5] = 0.5            # half the candidates fail
+    mu[1, :5] = -40.0; sd[1, :5] = 0.5          # no candidate passes: the first one is returned (below `left`)
+    musd = torch.as_tensor(np.stack([mu, sd], -1)).cuda()
+    seed, row0, sys0 = 99, 12, 1_000_000_007
+    st = ops.stats_params()
+    got = ops.stats_draw(musd, st, philox_seed=seed, row_id0=row0, system_id0=sys0).cpu().numpy()
+    cand = ops.philox_normal(5, seed, row0, R, width=40, B=B, system_id0=sys0).cpu().numpy()
+    level = ops.philox_normal(6, seed, row0, R, B=B, system_id0=sys0).cpu().numpy()
+    want = ostats.stream_epilogue(musd.cpu().numpy(), cand, level)
+    assert np.array_equal(got, want), np.abs(got - want).max()
+    assert (got[1, :5] < 4).all() and (got[2:] > 4).all()
+    assert level.min() > 0 and level.max() <= 1
+    # no prior resampling: the truncated-normal draw alone
+    st2 = ops.stats_params(prior_threshold=None)
+    got2 = ops.stats_draw(musd, st2, philox_seed=seed, row_id0=row0, system_id0=sys0).cpu().numpy()
+    keep = got2 < 9
+    assert np.array_equal(got2[keep], got[keep]) and (got[~keep] >= 9).all()
+
+
+def test_prior_draws_follow_the_prior(ops):
+    """Values redrawn from the prior have its survival function (one-sample Kolmogorov-Smirnov at the 1e-3 level)."""
+    from oracle import stats as ostats
+    R, B = 64, 8192
+    musd = torch.zeros((R, B, 2), device="cuda")
+    musd[..., 0] = 11.5
+    musd[..., 1] = 0.5                                                    # nearly every draw lands above 9
+    t = ops.stats_draw(musd, philox_seed=5).cpu().numpy().ravel()
+    t = np.sort(t[t >= 9])
+    n = t.size
+    assert n > 0.99 * R * B
+    S, step = ostats.prior_survival_table()
+    cdf = 1.0 - np.interp(t, 9.0 + step * np.arange(S.size), S.astype(np.float64))
+    emp = (np.arange(n) + 0.5) / n
+    assert np.abs(cdf - emp).max() < 1.95 / np.sqrt(n)                   # K-S critical value at alpha = 0.001
+    assert t.max() < 60 and abs(np.median(t) - (9 + np.log(2) / 0.424033970670719)) < 0.02
+
+
+@pytest.mark.parametrize("nch", (1, 10))
+def test_fused_tail_equals_forward_then_epilogue(ops, ens, nch):
+    """multiswag_stats == stats_draw(multiswag): same bits; and invariant to system sharding and draw slabs."""
+    wa, w2, pd = ens
+    B, samples = 777, 12
+    J = samples * nch
+    x = synth(B, 11)
+    idx = torch.as_tensor((np.arange(J) % 2).astype(np.int32))
+    seed = 4242
+    t = ops.multiswag_stats(x, wa, w2, pd, idx, nchunks=nch, philox_seed=seed, draw_id0=3 * nch, system_id0=50_000)
+    musd = ops.multiswag(x, wa, w2, pd, idx, nchunks=nch, philox_seed=seed, draw_id0=3 * nch, system_id0=50_000)
+    assert t.shape == (samples, B)
+    assert torch.equal(t, ops.stats_draw(musd, philox_seed=seed, row_id0=3, system_id0=50_000))
+    if nch == 1:
+        part = ops.multiswag_stats(x[300:].contiguous(), wa, w2, pd, idx, philox_seed=seed, draw_id0=3, system_id0=50_300)
+        assert torch.equal(part, t[:, 300:])
+        part = ops.multiswag_stats(x, wa, w2, pd, idx[5:9], philox_seed=seed, draw_id0=8, system_id0=50_000)
+        assert torch.equal(part, t[5:9])
+
+
+def test_sketch_against_exact_percentiles_small(ops):
+    """min over trios + sketch percentiles vs numpy on materialised samples: within one bin width, mean to float64 rounding."""
+    rng = np.random.default_rng(8)
+    R, sims, group = 1000, 257, 3
+    t = rng.uniform(4.0, 9.0, (R, sims * group)).astype(np.float32)
+    heavy = rng.random((R, sims * group)) < 0.3
+    t[heavy] = (9.0 + rng.exponential(1 / 0.424, heavy.sum())).astype(np.float32)
+    sk = ops.QuantileSketch(sims * group, group=group)
+    tt = torch.as_tensor(t).cuda()
+    for r0 in range(0, R, 128):                                           # slabs of draws
+        sk.update(tt[r0:r0 + 128].contiguous())
+    q = (2.5, 16.0, 50.0, 84.0, 97.5, 0.0, 100.0)
+    got = sk.percentiles(q).cpu().numpy()
+    outs = t.reshape(R, sims, group).min(2).T                             # np.min(samps_time, 2).T (:428)
+    want = np.percentile(outs.astype(np.float64), q, axis=1).T
+    tol = np.vectorize(sk.resolution)(want)
+    assert (np.abs(got - want) <= tol * 1.0001).all(), np.abs(got - want).max()
+    assert np.allclose(sk.mean().cpu().numpy(), outs.astype(np.float64).mean(1), rtol=1e-12)
+    assert int(sk.hist.sum()) == R * sims and sk.count == R
+    # values below the first segment (a truncated-normal draw none of whose candidates passed) are reported as its lower edge
+    sk2 = ops.QuantileSketch(4)
+    sk2.update(torch.tensor([[3.0, 4.5, 4.5, 4.5], [3.5, 4.5, 4.5, 4.5], [5.0, 4.5, 4.5, 4.5]]).cuda())
+    got2 = sk2.percentiles((0.0, 50.0, 100.0)).cpu().numpy()
+    assert got2[0, 0] == 4.0 and got2[0, 1] == 4.0 and abs(got2[0, 2] - 5.0) < 1 / 128 and abs(got2[1, 1] - 4.5) < 1 / 128
+
+
+def test_streaming_bands_at_configs1_size(ops, ens):
+    """configs[1] size (10 000 systems x 3 000 draws): fused tail + sketch in slabs of 250 draws (never more than 10 MB of
+    samples alive) vs exact order statistics of the materialised samples: every band within one bin width."""
+    wa, w2, pd = ens
+    B, J, slab = 10_000, 3_000, 250
+    x = synth(B, 321)
+    idx = torch.as_tensor((np.arange(J) % 2).astype(np.int32)).cuda()
+    seed = 77
+    sk = ops.QuantileSketch(B)
+    for j0 in range(0, J, slab):
+        sk.update(ops.multiswag_stats(x, wa, w2, pd, idx[j0:j0 + slab], philox_seed=seed, draw_id0=j0))
+    q = (2.5, 16.0, 50.0, 84.0, 97.5)
+    got = sk.percentiles(q)
+    # exact: materialise everything (240 MB of pairs), epilogue, per-system percentiles by sorting
+    musd = ops.multiswag(x, wa, w2, pd, idx, philox_seed=seed)
+    t = ops.stats_draw(musd, philox_seed=seed)
+    want = torch.quantile(t.double(), torch.tensor(q, dtype=torch.float64, device="cuda") / 100.0, dim=0).T   # 'linear', as numpy
+    exact_kernel = ops.quantiles(torch.stack([t, t], 2).contiguous(), q)[:, 0, :]
+    assert torch.allclose(exact_kernel.double(), want, rtol=0, atol=1e-6)
+    err = (got.double() - want).abs().cpu().numpy()
+    tol = np.vectorize(sk.resolution)(want.cpu().numpy())
+    assert (err <= tol * 1.0001).all(), (err.max(), err.argmax())
+    assert np.median(err) < 0.004                                          # typically well inside a bin
+    assert torch.allclose(sk.mean(), t.double().mean(0), rtol=1e-12)
+    assert sk.hist.numel() * 4 + sk.mom.numel() * 8 < 40e6                # O(B * bins): 38 MB, whatever the number of draws
