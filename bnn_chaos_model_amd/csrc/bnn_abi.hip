@@ -540,7 +540,7 @@ static int pick_spc(const bnn_grid* g, int64_t csz) {
     return 64;
 }
 
-static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, bool fused, bool noisy, void* stream) {
+static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, bool fused, bool noisy, void* stream, int lowp = 0) {
     if (!pl || !g) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
     if (g->B < 0 || g->J < 0 || g->nchunks < 1) return fail(BNN_ERR_INVALID, "negative size");
     if (g->J % g->nchunks) return fail(BNN_ERR_INVALID, "J must be a multiple of nchunks");
@@ -563,7 +563,8 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     hipStream_t st = (hipStream_t)stream;
     const bool k31 = pl->tab[0].kin4 == 31;
     hipError_t e;
-    if (p.sink) e = launch_fwd_stats(k31, (unsigned)nblk, st, p);
+    if (lowp) e = launch_fwd_lowp(lowp, (unsigned)nblk, st, p);
+    else if (p.sink) e = launch_fwd_stats(k31, (unsigned)nblk, st, p);
     else if (noisy) e = launch_fwd_noisy((unsigned)nblk, st, p);
     else if (k31) e = launch_fwd_k31(fused, (unsigned)nblk, st, p);
     else e = launch_fwd_k41(fused, (unsigned)nblk, st, p);
@@ -611,6 +612,21 @@ int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, 
     p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
     p.out = out; p.pre_clamp = pre_clamp; p.summary = summary;
     return launch_forward(plan, grid, p, false, noisy, stream);
+}
+
+int bnn_forward_lowp_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps, uint64_t philox_seed,
+                         int64_t draw_id0, int64_t system_id0, int32_t precision, float* out, float* pre_clamp, float* summary, void* stream) {
+    if (!plan || !grid) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
+    if (precision < BNN_PREC_BF16 || precision > BNN_PREC_BF16X6) return fail(BNN_ERR_INVALID, "precision must be BNN_PREC_BF16, _BF16X3 or _BF16X6");
+    if (plan->tab[0].kin4 != 31) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels are built for the v50 column mask only");
+    if (grid->noisy) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels have no noisy form");
+    if (grid->B == 0 || grid->J == 0) return 0;
+    if (!W) return fail(BNN_ERR_INVALID, "W is NULL");
+    FwdParams p{};
+    p.x = x; p.W = W; p.eps = eps;
+    p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
+    p.out = out; p.pre_clamp = pre_clamp; p.summary = summary;
+    return launch_forward(plan, grid, p, false, false, stream, precision);
 }
 
 int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg, const float* w2_avg,

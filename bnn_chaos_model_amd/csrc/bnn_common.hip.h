@@ -17,6 +17,8 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
 #define DEVINL __device__ __forceinline__
 
+constexpr int SCR4 = 2 * 16 * S2;  // floats of LDS scratch per wave of a forward kernel: Philox normals + summaries of 16 systems
+
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11) and the normals derived from it.
 // Counters use GLOBAL draw / output-row / system ids, so results are invariant to sharding.

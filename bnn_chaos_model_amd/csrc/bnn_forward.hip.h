@@ -39,8 +39,8 @@ DEVINL void load_row(const float* __restrict__ rp, float (&xv)[KIN]) {
     }
 }
 
-constexpr int SCR4 = 2 * 16 * S2;  // floats of LDS scratch per wave: Philox normals + summaries of 16 systems
-constexpr int NSC4 = 96;           // LDS floats for the noise scales of the noisy forward: exp(logvar/2) for 41 inputs + 40 summaries
+constexpr int NSC4 = 96 + 2 * 56;  // LDS floats of the noisy forward: exp(logvar/2) for 41 inputs + 40 summaries (padded to 96), then
+                                   // per 6-column noise block, padded to 8: the input scales [7][8] and the column keep-masks [7][8]
 
 template <int KIN>
 constexpr size_t fwd_lds_bytes() { return sizeof(float) * (FLAT_LDS + MAXK + W4<KIN>::PAD + 4 * SCR4 + NSC4); }
@@ -59,8 +59,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, c = lane & 15;   // regress_nn (16x16x4) coordinates
-    const int sl = lane >> 2, ph = lane & 3;  // feature_nn (4x4x1) coordinates: system in the wave-batch, timestep phase
+    const int sl0 = lane >> 2, ph0 = lane & 3;  // feature_nn (4x4x1) coordinates: system in the wave-batch, timestep phase
 
     // work item: draw e, block `sub` of its chunk of systems (torch.chunk semantics).  Draw-fastest block order: workgroups that
     // are resident together work on the SAME systems under different draws, so x comes from HBM about once and from L2 after that.
@@ -100,19 +99,29 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     for (int i = tid; i < LY::PAD; i += 256) wl[i] = flat[p.tab_f4[i]];
     if constexpr (NOISY) {  // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
         if (tid < F + S2) nsc[tid] = expf(flat[OFF_INLV + tid] / 2.0f);
+        if (tid < 56) {     // the same input scales per noise block, and all-ones / zero bit masks for kept / zeroed columns
+            const int col = NIN_PER_BLOCK * (tid >> 3) + (tid & 7);
+            const bool live = (tid & 7) < NIN_PER_BLOCK && col < F;
+            nsc[96 + tid] = live ? expf(flat[OFF_INLV + col] / 2.0f) : 0.0f;
+            nsc[96 + 56 + tid] = __builtin_bit_cast(float, (live && !((p.zero_mask >> col) & 1ull)) ? 0xFFFFFFFFu : 0u);
+        }
     }
-    {   // regress_nn operands replace the flat vector in place: gather to registers, barrier, write
+    {   // regress_nn operands replace the flat vector in place: gather to registers, barrier, write.  All table entries are
+        // fetched first (branch-free, clamped), so the 25 global loads are in flight together.
         constexpr int PER = (NF2 + 3) / 4;
+        int idx[PER];
         float tmp[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            int f = wave + 4 * i;
-            tmp[i] = f < NF2 ? flat[p.tab_f2[f * 64 + lane]] : 0.0f;
+            const int f = wave + 4 * i;
+            idx[i] = p.tab_f2[(f < NF2 ? f : NF2 - 1) * 64 + lane];
         }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) tmp[i] = flat[idx[i]];
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            int f = wave + 4 * i;
+            const int f = wave + 4 * i;
             if (f < NF2) f2frag[f * 64 + lane] = tmp[i];
         }
         __syncthreads();
@@ -122,12 +131,12 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     const float nm1 = (float)(T - 1), nT = (float)T;
     const float half_n0 = (float)ntiles * 0.5f;
     const int64_t rowstride = (int64_t)T * F;
-    const f32x4* wqA1 = reinterpret_cast<const f32x4*>(wl + LY::L1A) + ph;
-    const f32x4* wqB1 = reinterpret_cast<const f32x4*>(wl + LY::L1B) + ph;
-    const f32x4* wqA2 = reinterpret_cast<const f32x4*>(wl + LY::L2A) + ph;
-    const f32x4* wqB2 = reinterpret_cast<const f32x4*>(wl + LY::L2B) + ph;
-    const f32x4* wqA3 = reinterpret_cast<const f32x4*>(wl + LY::L3A) + ph;
-    const f32x4* wqB3 = reinterpret_cast<const f32x4*>(wl + LY::L3B) + ph;
+    const f32x4* wqA1 = reinterpret_cast<const f32x4*>(wl + LY::L1A) + ph0;
+    const f32x4* wqB1 = reinterpret_cast<const f32x4*>(wl + LY::L1B) + ph0;
+    const f32x4* wqA2 = reinterpret_cast<const f32x4*>(wl + LY::L2A) + ph0;
+    const f32x4* wqB2 = reinterpret_cast<const f32x4*>(wl + LY::L2B) + ph0;
+    const f32x4* wqA3 = reinterpret_cast<const f32x4*>(wl + LY::L3A) + ph0;
+    const f32x4* wqB3 = reinterpret_cast<const f32x4*>(wl + LY::L3B) + ph0;
     const f32x4* bq1 = reinterpret_cast<const f32x4*>(wl + LY::B1);
     const f32x4* bq2 = reinterpret_cast<const f32x4*>(wl + LY::B2);
     const f32x4* bq3 = reinterpret_cast<const f32x4*>(wl + LY::B3);
@@ -135,10 +144,10 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     float* sumscr = epsscr + 16 * S2;
 
     for (int64_t wb0 = b0 + (int64_t)wave * 16; wb0 < b1; wb0 += 64) {
-        const int64_t sys = wb0 + sl;
-        const bool valid = sys < b1;
-        const int64_t sysc = valid ? sys : b1 - 1;
-        const float* rowp = p.x + sysc * rowstride + (int64_t)ph * F;
+        const int64_t sys0 = wb0 + sl0;
+        const bool valid0 = sys0 < b1;
+        const int64_t sysc0 = valid0 ? sys0 : b1 - 1;
+        const float* rowp = p.x + sysc0 * rowstride + (int64_t)ph0 * F;
 
         f32x4 mean[5], m2[5];
 #pragma unroll
@@ -165,39 +174,47 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                     q[kp][4] = wqB1[kp * 4];
                 };
                 // masks, then add_input_noise (:486-504): masked columns become pure noise.  This lane's row is timestep
-                // 4*it + ph of system sysc; its 41 normals are the 7 Philox blocks t*7 + 0..6, six normals each (or the explicit
+                // 4*it + ph0 of system sysc0; its 41 normals are the 7 Philox blocks t*7 + 0..6, six normals each (or the explicit
                 // tensor's row).  A block is generated right in front of the three column pairs that consume it, so that its
                 // registers are short-lived (the whole row's noise up front cost 13 spilled VGPRs).
                 const float* er = nullptr;
                 int tblk = 0;
                 if constexpr (NOISY) {
-                    const int t = 4 * it + ph;
+                    const int t = 4 * it + ph0;
                     tblk = t * NIN_BLOCKS;
-                    if (p.eps_in) er = p.eps_in + (r * p.B + sysc) * rowstride + (int64_t)t * F;
+                    if (p.eps_in) er = p.eps_in + (r * p.B + sysc0) * rowstride + (int64_t)t * F;
                 }
+                const bool explicit_noise = NOISY && p.eps_in != nullptr;  // wave-uniform
                 auto noise6 = [&](int blk) {
                     float n6[6];
-                    if (er) {
+                    if (explicit_noise) {
 #pragma unroll
                         for (int j = 0; j < 6; ++j) n6[j] = (6 * blk + j < F) ? er[6 * blk + j] : 0.0f;
                     } else {
-                        philox_in6(p.row_id0 + r, p.sys_id0 + sysc, tblk + blk, p.seed, n6);
+                        philox_in6(p.row_id0 + r, p.sys_id0 + sysc0, tblk + blk, p.seed, n6);
                     }
+                    const f32x4* nb = reinterpret_cast<const f32x4*>(nsc + 96 + 8 * blk);
+                    const f32x4 s0 = nb[0], s1 = nb[1], k0 = nb[14], k1 = nb[15];  // scales, keep-masks (56 floats further on)
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
                         const int col = 6 * blk + j;
                         if (col < KIN) {
-                            const float xm = ((p.zero_mask >> col) & 1ull) ? 0.0f : xv[col];
-                            xv[col] = xm + n6[j] * nsc[col];
+                            const float sc = j < 4 ? s0[j] : s1[j - 4], kp_ = j < 4 ? k0[j] : k1[j - 4];
+                            const float xm = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, xv[col]) & __builtin_bit_cast(uint32_t, kp_));
+                            xv[col] = xm + n6[j] * sc;   // x_masked + randn * exp(logvar / 2): a multiply, then an add (:445)
                         }
                     }
                 };
                 rd(0);
-                if constexpr (!NOISY) __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
 #pragma unroll
                 for (int kp = 0; kp < NP; ++kp) {
                     if constexpr (NOISY) {
-                        if (kp % 3 == 0) noise6(kp / 3);
+                        if (kp % 3 == 0) {  // a scheduling region of its own: neither the reads nor the MFMAs around it move across
+                            __builtin_amdgcn_sched_barrier(0);
+                            noise6(kp / 3);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                     if (kp + 1 < NP) rd(kp + 1);
                     const int k0 = 2 * kp, k1 = 2 * kp + 1;
@@ -211,10 +228,8 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                         h[4] = mfma4(q[kp][3].x, b1v, h[4]); h[5] = mfma4(q[kp][3].y, b1v, h[5]); h[6] = mfma4(q[kp][3].z, b1v, h[6]); h[7] = mfma4(q[kp][3].w, b1v, h[7]);
                         h[8] = mfma4(q[kp][4].z, b1v, h[8]); h[9] = mfma4(q[kp][4].w, b1v, h[9]);
                     }
-                    if constexpr (!NOISY) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
-                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
                 }
             }
 #pragma unroll
@@ -297,6 +312,16 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                     mean[n][i] = mn;
                 }
         }
+
+        // Everything below the tile loop works from coordinates RE-derived here from a laundered copy of the lane id, so that
+        // none of them (system ids, validity, pointers) is kept in a register -- or spilled -- across the loop.
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        const int g = lane_t >> 4, c = lane_t & 15;   // regress_nn (16x16x4) coordinates
+        const int sl = lane_t >> 2, ph = lane_t & 3;  // feature_nn coordinates again
+        const int64_t sys = wb0 + sl;
+        const bool valid = sys < b1;
+        const int64_t sysc = valid ? sys : b1 - 1;
 
         // merge the 4 lanes of a quad: equal-count Chan update, symmetric (all four lanes end with the same bits)
         {

@@ -1,0 +1,387 @@
+// bnn_lowp.hip.h -- OPT-IN reduced-precision forward kernels for BASELINE.json configs[4] ("bf16 vs fp32 tolerance sweep"):
+// feature_nn on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, fp32 accumulate), everything after the time pool (sampled
+// moments, regress_nn on the exact-fp32 16x16x4 path, soft_clamp) exactly as in the fp32 kernel.  Never the default, never the
+// headline: outputs differ from the reference by far more than the 1e-5 parity bar (the sweep in DESIGN.md says by how much).
+//
+//   NS = 1  "bf16":    x, weights, biases and activations rounded to bf16 (RNE), one product per layer
+//   NS = 2  "bf16x3":  every operand split into hi + lo bf16 parts (16 significant bits), 3 products  hi*hi + hi*lo + lo*hi
+//   NS = 3  "bf16x6":  three parts (24 significant bits = all of fp32), the 6 products of order <= 2: fp32-level error
+//
+// Data flow (D = W * X^T, so that a layer's accumulators ARE the next layer's B operand, no lane movement, no LDS):
+//   C/D   lane (g = lane>>4, c = lane&15), register r of m-tile mt  = out[neuron 16 mt + 4 g + r][data row c]
+//   B     lane (g, c), element j of k-step s                        = act[k(s, g, j)][data row c]
+//   A     lane (g, m = lane&15), element j of k-step s              = W[neuron 16 mt + m][k(s, g, j)]
+// The k order is free, so k(s, g, j) is chosen to be what the lane already holds:
+//   layer 1 (31 live columns + bias = 32 slots, ONE k-step): group g reads 8 consecutive floats of its row at column 8 + 8g;
+//            group 3 = columns 32..37, then column 0, then the constant 1.0 whose weight is the bias;
+//   layers 2, 3 (40 inputs = two k-steps, the second half empty): s = 0: j < 4 -> neuron 4g + j (m-tile 0), j >= 4 -> neuron
+//            16 + 4g + j - 4 (m-tile 1); s = 1: j < 4 -> neuron 32 + 4g + j (m-tile 2, neurons >= 40 are zero padding),
+//            j = 4 -> the constant 1.0 (bias), j > 4 -> 0.
+// A data row c = (system c>>2, timestep phase c&3): a tile is 4 systems x 4 timesteps, 25 tiles cover T = 100; the time pool is a
+// per-lane Welford over the lane's 25 timesteps + a DPP merge over the 4 phases, as in the fp32 kernel.
+// Weights live in registers for the whole workgroup (13 fragments x NS parts x 4 VGPRs).  13 (x1, x3, x6) MFMAs of 16 cycles per
+// 16 rows against 1 820 cycles of fp32 MFMA: the bf16 forms are bound by their vector work (ReLU, splits, pool), not the pipe.
+#pragma once
+#include "bnn_common.hip.h"
+
+namespace bnn {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+DEVINL uint32_t cvt_pk_bf16(float a, float b) {  // {bf16(b), bf16(a)}: a in the low half; round to nearest even
+    uint32_t o;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+DEVINL float bf16_lo_as_f32(uint32_t pk) { return __builtin_bit_cast(float, pk << 16); }
+DEVINL float bf16_hi_as_f32(uint32_t pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+
+// (a, b) -> NS packed parts; part p holds bf16 of what is left after parts < p (the subtractions are exact in fp32)
+template <int NS>
+DEVINL void split_pair(float a, float b, uint32_t (&out)[NS]) {
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+        out[p] = cvt_pk_bf16(a, b);
+        if (p + 1 < NS) {
+            a = a - bf16_lo_as_f32(out[p]);
+            b = b - bf16_hi_as_f32(out[p]);
+        }
+    }
+}
+
+template <int NS>
+struct Frag {  // one k-step of one operand: NS parts of 8 bf16
+    u32x4 part[NS];
+};
+
+DEVINL f32x4 mfma_bf16(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// sum over the products of order <= NS - 1, smallest terms first
+template <int NS>
+DEVINL f32x4 mfma_split(const Frag<NS>& a, const Frag<NS>& b, f32x4 c) {
+#pragma unroll
+    for (int ord = NS - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int i = 0; i <= ord; ++i) c = mfma_bf16(a.part[i], b.part[ord - i], c);
+    return c;
+}
+
+// index into the flat parameter vector (or ZERO_IDX) of the weight that A-fragment element j of lane (g, m) holds
+DEVINL int lowp_widx(int layer, int mt, int s, int g, int m, int j) {
+    const int n = 16 * mt + m;
+    if (layer == 0) {
+        if (n >= H) return ZERO_IDX;
+        if (g < 3) return OFF_W1 + n * F + 8 + 8 * g + j;
+        if (j < 6) return OFF_W1 + n * F + 32 + j;
+        return j == 6 ? OFF_W1 + n * F : OFF_B1 + n;
+    }
+    const int n_out = layer == 1 ? H : L;
+    if (n >= n_out) return ZERO_IDX;
+    const int off_w = layer == 1 ? OFF_W2 : OFF_W3, off_b = layer == 1 ? OFF_B2 : OFF_B3;
+    int k;
+    if (s == 0) k = j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4);
+    else {
+        if (j == 4) return g == 0 ? off_b + n : ZERO_IDX;
+        if (j > 4) return ZERO_IDX;
+        k = 32 + 4 * g + j;
+        if (k >= H) return ZERO_IDX;
+    }
+    return off_w + n * H + k;
+}
+
+template <int NS>
+DEVINL Frag<NS> lowp_wfrag(const float* flat, int layer, int mt, int s, int g, int m) {
+    Frag<NS> f;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+        uint32_t pk[NS];
+        split_pair<NS>(flat[lowp_widx(layer, mt, s, g, m, 2 * jp)], flat[lowp_widx(layer, mt, s, g, m, 2 * jp + 1)], pk);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) f.part[p][jp] = pk[p];
+    }
+    return f;
+}
+
+// ReLU + split of a layer's three accumulator tiles into the next layer's two B k-steps
+template <int NS>
+DEVINL void lowp_next_operand(const f32x4 (&acc)[3], Frag<NS>& b0, Frag<NS>& b1) {
+    f32x4 t0 = relu4(acc[0]), t1 = relu4(acc[1]), t2 = relu4(acc[2]);
+    uint32_t pk[NS];
+    split_pair<NS>(t0[0], t0[1], pk);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) b0.part[p][0] = pk[p];
+    split_pair<NS>(t0[2], t0[3], pk);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) b0.part[p][1] = pk[p];
+    split_pair<NS>(t1[0], t1[1], pk);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) b0.part[p][2] = pk[p];
+    split_pair<NS>(t1[2], t1[3], pk);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) b0.part[p][3] = pk[p];
+    split_pair<NS>(t2[0], t2[1], pk);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) b1.part[p][0] = pk[p];
+    split_pair<NS>(t2[2], t2[3], pk);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) b1.part[p][1] = pk[p];
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+        b1.part[p][2] = p == 0 ? 0x00003F80u : 0u;  // element 4 = bf16(1.0): the bias slot; element 5 = 0
+        b1.part[p][3] = 0u;
+    }
+}
+
+constexpr size_t lowp_lds_bytes() { return sizeof(float) * (FLAT_LDS + 4 * SCR4); }
+
+template <int NS>
+__global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* flat = lds;            // [FLAT_LDS] flat parameter vector + zero slot, later ...
+    float* f2frag = lds;          // ... [NF2][64] regress_nn operands in fragment order
+    float* scr = lds + FLAT_LDS;  // [4][SCR4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int sq = c >> 2, tph = c & 3;  // system within the tile, timestep phase
+
+    const int64_t id = blockIdx.x;
+    const int e = (int)(id % p.J);
+    const int64_t sub = id / p.J;
+    const int ch = e % p.nch;
+    const int64_t r = e / p.nch;
+    const int64_t seg0 = (int64_t)ch * p.csz;
+    const int64_t seg1 = (seg0 + p.csz < p.B) ? seg0 + p.csz : p.B;
+    const int64_t b0 = seg0 + sub * p.spc;
+    const int64_t b1 = (b0 + p.spc < seg1) ? b0 + p.spc : seg1;
+    if (b0 >= b1) return;
+
+    {
+        const float* We = p.W + (int64_t)e * D;
+        for (int i = tid; i < D; i += 256) flat[i] = We[i];
+        if (tid == 0) flat[ZERO_IDX] = 0.0f;
+    }
+    __syncthreads();
+    // feature_nn weights -> bf16 parts in registers (every wave builds its own copy)
+    Frag<NS> A1[3], A2[3][2], A3[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) A1[mt] = lowp_wfrag<NS>(flat, 0, mt, 0, g, c);
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) A2[mt][s] = lowp_wfrag<NS>(flat, 1, mt, s, g, c);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) A3[mt][s] = lowp_wfrag<NS>(flat, 2, mt, s, g, c);
+    {   // regress_nn operands (exact fp32) replace the flat vector in place
+        constexpr int PER = (NF2 + 3) / 4;
+        int idx[PER];
+        float tmp[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int f = wave + 4 * i;
+            idx[i] = p.tab_f2[(f < NF2 ? f : NF2 - 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) tmp[i] = flat[idx[i]];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int f = wave + 4 * i;
+            if (f < NF2) f2frag[f * 64 + lane] = tmp[i];
+        }
+        __syncthreads();
+    }
+
+    const int T = p.T, ntiles = p.ntiles;
+    const float nm1 = (float)(T - 1), nT = (float)T;
+    const float half_n0 = (float)ntiles * 0.5f;
+    const int64_t rowstride = (int64_t)T * F;
+    float* epsscr = scr + wave * SCR4;
+    float* sumscr = epsscr + 16 * S2;
+
+    for (int64_t wb0 = b0 + (int64_t)wave * 16; wb0 < b1; wb0 += 64) {
+        for (int sb = 0; sb < 4; ++sb) {  // four tiles' worth of systems: wb0 + 4 sb + sq
+            if (wb0 + 4 * sb >= b1) break;  // wave-uniform
+            const int64_t sys = wb0 + 4 * sb + sq;
+            const bool valid = sys < b1;
+            const int64_t sysc = valid ? sys : b1 - 1;
+            const float* rowbase = p.x + sysc * rowstride + (int64_t)tph * F;
+            const float* rp = rowbase + 8 + 8 * g;  // group 3 reads columns 32..39: 38, 39 are replaced below
+
+            f32x4 mean0 = {0, 0, 0, 0}, m20 = {0, 0, 0, 0}, mean1 = {0, 0, 0, 0}, m21 = {0, 0, 0, 0};
+            f32x4 xa = *reinterpret_cast<const f32x4u*>(rp), xb = *reinterpret_cast<const f32x4u*>(rp + 4);
+            float x0 = rowbase[0];
+            asm volatile("" ::: "memory");
+            for (int it = 0; it < ntiles; ++it) {
+                // layer-1 B operand (selects at use time, not at load time: the loads are a tile ahead)
+                Frag<NS> B1;
+                {
+                    const float v6 = g == 3 ? x0 : xb.z, v7 = g == 3 ? 1.0f : xb.w;
+                    uint32_t pk[NS];
+                    split_pair<NS>(xa.x, xa.y, pk);
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) B1.part[q][0] = pk[q];
+                    split_pair<NS>(xa.z, xa.w, pk);
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) B1.part[q][1] = pk[q];
+                    split_pair<NS>(xb.x, xb.y, pk);
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) B1.part[q][2] = pk[q];
+                    split_pair<NS>(v6, v7, pk);
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) B1.part[q][3] = pk[q];
+                }
+                {
+                    const int itn = (it + 1 < ntiles) ? it + 1 : it;
+                    const float* rn = rp + (int64_t)itn * 4 * F;
+                    xa = *reinterpret_cast<const f32x4u*>(rn);
+                    xb = *reinterpret_cast<const f32x4u*>(rn + 4);
+                    x0 = rowbase[(int64_t)itn * 4 * F];
+                    asm volatile("" ::: "memory");
+                }
+                f32x4 acc[3];
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) acc[mt] = mfma_split<NS>(A1[mt], B1, (f32x4){0, 0, 0, 0});
+                Frag<NS> Bs0, Bs1;
+                lowp_next_operand<NS>(acc, Bs0, Bs1);
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) {
+                    acc[mt] = mfma_split<NS>(A2[mt][0], Bs0, (f32x4){0, 0, 0, 0});
+                    acc[mt] = mfma_split<NS>(A2[mt][1], Bs1, acc[mt]);
+                }
+                lowp_next_operand<NS>(acc, Bs0, Bs1);
+                f32x4 y0 = mfma_split<NS>(A3[0][0], Bs0, (f32x4){0, 0, 0, 0});
+                y0 = mfma_split<NS>(A3[0][1], Bs1, y0);
+                f32x4 y1 = mfma_split<NS>(A3[1][0], Bs0, (f32x4){0, 0, 0, 0});
+                y1 = mfma_split<NS>(A3[1][1], Bs1, y1);
+                // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps.  y0[r] = neuron 4g + r,
+                // y1[r] = neuron 16 + 4g + r (a real neuron only for g = 0)
+                const float rcn = p.rcp_tab[it];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float dl = y0[i] - mean0[i];
+                    float mn = fmaf(dl, rcn, mean0[i]);
+                    m20[i] = fmaf(dl, y0[i] - mn, m20[i]);
+                    mean0[i] = mn;
+                    dl = y1[i] - mean1[i];
+                    mn = fmaf(dl, rcn, mean1[i]);
+                    m21[i] = fmaf(dl, y1[i] - mn, m21[i]);
+                    mean1[i] = mn;
+                }
+            }
+            // merge the 4 timestep phases (lanes c, c^1, c^2, c^3): equal-count Chan update, symmetric
+            {
+                float half_n = half_n0;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float om = st == 0 ? quad_perm<0xB1>(mean0[i]) : quad_perm<0x4E>(mean0[i]);
+                        float o2 = st == 0 ? quad_perm<0xB1>(m20[i]) : quad_perm<0x4E>(m20[i]);
+                        float dl = om - mean0[i];
+                        m20[i] = (m20[i] + o2) + (dl * dl) * half_n;
+                        mean0[i] = (mean0[i] + om) * 0.5f;
+                        om = st == 0 ? quad_perm<0xB1>(mean1[i]) : quad_perm<0x4E>(mean1[i]);
+                        o2 = st == 0 ? quad_perm<0xB1>(m21[i]) : quad_perm<0x4E>(m21[i]);
+                        dl = om - mean1[i];
+                        m21[i] = (m21[i] + o2) + (dl * dl) * half_n;
+                        mean1[i] = (mean1[i] + om) * 0.5f;
+                    }
+                    half_n = half_n * 2.0f;
+                }
+            }
+            // sampled moments (:420-431).  Lane (g, tph) finishes neuron 4g + tph and, for g = 0, neuron 16 + tph.
+            const int slot = 4 * sb + sq;  // this system's slot among the 16 of the wave-batch
+            if (p.eps == nullptr) {        // the system's 40 normals = ten Philox blocks, one per lane li < 10 of its 16 lanes
+                const int li = 4 * g + tph;
+                if (li < 10) *reinterpret_cast<f32x4*>(epsscr + slot * S2 + 4 * li) = philox_eps4(p.row_id0 + r, p.sys_id0 + sysc, li, p.seed);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                if (part == 1 && g != 0) continue;
+                const f32x4 mv = part == 0 ? mean0 : mean1, qv = part == 0 ? m20 : m21;
+                const int n = part == 0 ? 4 * g + tph : 16 + tph;
+                const float sample_mu = tph == 0 ? mv[0] : tph == 1 ? mv[1] : tph == 2 ? mv[2] : mv[3];
+                const float msum = tph == 0 ? qv[0] : tph == 1 ? qv[1] : tph == 2 ? qv[2] : qv[3];
+                float e1, e2;
+                if (p.eps) {
+                    const float* ep = p.eps + (r * p.B + sysc) * S2;
+                    e1 = ep[n]; e2 = ep[L + n];
+                } else {
+                    e1 = epsscr[slot * S2 + n]; e2 = epsscr[slot * S2 + L + n];
+                }
+                float sd = sqrtf(msum / nm1);
+                float sample_var = sd * sd;
+                float std_in_mu = sqrtf(sample_var / nT);
+                float std_in_var = sqrtf((2.0f * (sample_var * sample_var)) / nm1);
+                float mu_s = e1 * std_in_mu + sample_mu;
+                float var_s = e2 * std_in_var + sample_var;
+                float sd_s = sqrtf(fabsf(var_s) + 1e-5f);
+                sumscr[slot * S2 + n] = mu_s;
+                sumscr[slot * S2 + L + n] = sd_s;
+                if (p.summary && valid) {
+                    float* sp = p.summary + (r * p.B + sys) * S2 + n;
+                    sp[0] = mu_s;
+                    sp[L] = sd_s;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- regress_nn on the 16 systems of this wave-batch, exact fp32 (16x16x4 path): column c <-> system wb0 + c
+        const int64_t sysb = wb0 + c;
+        const bool validb = sysb < b1;
+        float skeep[10];
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) skeep[ks] = sumscr[c * S2 + kmap_summary(ks, g)];
+        const float* f2l = f2frag + lane;
+        auto W2f = [&](int f) { return f2l[f * 64]; };
+        f32x4 a4[3], a5[3], a6;
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a4[mt] = (f32x4){W2f(70 + mt * 4), W2f(71 + mt * 4), W2f(72 + mt * 4), W2f(73 + mt * 4)};
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(ks * 3 + mt), skeep[ks], a4[mt]);
+        a4[0] = relu4(a4[0]); a4[1] = relu4(a4[1]); a4[2] = relu4<2>(a4[2]);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a5[mt] = (f32x4){W2f(82 + mt * 4), W2f(83 + mt * 4), W2f(84 + mt * 4), W2f(85 + mt * 4)};
+#pragma unroll
+        for (int ks = 0; ks < NKH; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(30 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
+        a5[0] = relu4(a5[0]); a5[1] = relu4(a5[1]); a5[2] = relu4<2>(a5[2]);
+        a6 = (f32x4){W2f(94), W2f(95), W2f(96), W2f(97)};
+#pragma unroll
+        for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(60 + ks), a5[ks >> 2][ks & 3], a6);
+        if (g == 0 && validb) {
+            const f32x2 ms = soft_clamp2(a6[0], a6[1], p.std_lo, p.std_span);
+            const int64_t o = (r * p.B + sysb) * 2;
+            *reinterpret_cast<f32x2*>(p.out + o) = ms;
+            if (p.pre_clamp) *reinterpret_cast<f32x2*>(p.pre_clamp + o) = (f32x2){a6[0], a6[1]};
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int NS>
+inline hipError_t launch_lowp_form(unsigned nblk, hipStream_t st, const FwdParams& p) {
+    static bool attr_set[MAX_DEVICES];
+    const int slot = current_device_slot();
+    if (!attr_set[slot]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_lowp_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set[slot] = true;
+    }
+    hipLaunchKernelGGL((bnn_forward_lowp_kernel<NS>), dim3(nblk), dim3(256), lowp_lds_bytes(), st, p);
+    return hipGetLastError();
+}
+
+}  // namespace bnn

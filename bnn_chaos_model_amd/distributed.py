@@ -28,7 +28,7 @@ def shard_bounds(B, world, group=1):
 
 
 def all_gather_moments(local, B, group=None):
-    """local [B_r, M] (this rank's slice, in shard_bounds order) -> [B, M] on every rank.  One collective.
+    """local [B_r, M] (this rank's slice, in shard_bounds order) -> [B, M] on every rank.  One collective."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local

@@ -90,14 +90,19 @@ def swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, scale=0.5, philo
     return W
 
 
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
+
+
 @_on_device_of(0)
 def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0, draw_id0=0, system_id0=0, plan=None,
-            debug=False, systems_per_block=0, noisy=False):
+            debug=False, systems_per_block=0, noisy=False, precision="f32"):
     """VarModel.forward (spock_reg_model.py:486-528) for materialised weight vectors W[J,d] -> out[J/nchunks,B,2].
 
     eps [R,B,2,20] = the two randn_like of compute_summary_stats (:426-427) or None (Philox);
     eps_in [R,B,T,41] + eps_sum [R,B,40] switch on noisy_val=True (:444-450); noisy=True with no noise tensors at all
-    is noisy_val=True with every normal generated in-kernel (Philox)."""
+    is noisy_val=True with every normal generated in-kernel (Philox).
+    precision: "f32" (default: the parity path) or the OPT-IN reduced-precision forms "bf16" / "bf16x3" / "bf16x6"
+    (feature_nn on the bf16 matrix pipe; BASELINE configs[4] sweep; v50 mask, quiet forward only)."""
     plan = plan or get_plan()
     x, W = _f32(x, "x"), _f32(W, "W")
     if x.dim() != 3 or x.shape[2] != 41:
@@ -120,6 +125,14 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, 2 * LATENT), dtype=torch.float32, device=x.device) if debug else None
     g = _grid(B, T, J, nchunks, systems_per_block, noisy)
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+    if precision != "f32":
+        if noisy or eps_in is not None:
+            raise NotImplementedError("the reduced-precision kernels have no noisy form")
+        N.check(N.lib().bnn_forward_lowp_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(W), N.ptr(eps), int(philox_seed), int(draw_id0),
+                                             int(system_id0), PRECISIONS[precision], N.ptr(out), N.ptr(pre), N.ptr(summ), N.stream_ptr()))
+        return (out, pre, summ) if debug else out
     N.check(N.lib().bnn_forward_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(W), N.ptr(eps), N.ptr(eps_in), N.ptr(eps_sum),
                                     int(philox_seed), int(draw_id0), int(system_id0), N.ptr(out), N.ptr(pre), N.ptr(summ),
                                     N.stream_ptr()))
@@ -157,7 +170,7 @@ def _workspace(J, d, device):
 
 @_on_device_of(0)
 def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nchunks=1, scale=0.5, philox_seed=0,
-              draw_id0=0, system_id0=0, plan=None, debug=False, systems_per_block=0, out=None, single_launch=None):
+              draw_id0=0, system_id0=0, plan=None, debug=False, systems_per_block=0, out=None, single_launch=None, precision="f32"):
     """Fused SWAGModel.forward_swag_fast (spock_reg_model.py:878-908) over the MC loop of
     figures/multiswag_5_planet.py:295-298 -> out[J/nchunks, B, 2].
 
@@ -165,6 +178,14 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
     sampled once into a [J,d] workspace allocated for this call and read by the forward kernel of the same call (same
     bits, faster when a draw serves many workgroups).  None = choose by chunk size."""
     plan = plan or get_plan()
+    if precision != "f32":  # opt-in reduced precision: exact fp32 draw, then the bf16-pipe forward (same noise streams)
+        W = swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1, z2, scale=scale, philox_seed=philox_seed, draw_id0=draw_id0, plan=plan)
+        res = forward(x, W, eps=eps, nchunks=nchunks, philox_seed=philox_seed, draw_id0=draw_id0, system_id0=system_id0, plan=plan,
+                      debug=debug, systems_per_block=systems_per_block, precision=precision)
+        if out is not None and not debug:
+            out.copy_(res)
+            return out
+        return res
     x = _f32(x, "x")
     if x.dim() != 3 or x.shape[2] != 41:
         raise NotImplementedError("x must be [B, T, 41]")

@@ -111,6 +111,18 @@ int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, 
                     const float* eps_in, const float* eps_sum, uint64_t philox_seed, int64_t draw_id0,
                     int64_t system_id0, float* out, float* pre_clamp, float* summary, void* stream);
 
+/* OPT-IN reduced-precision forward for the precision sweep of BASELINE.json configs[4] (the reference's 5-planet script casts to
+ * fp32 at figures/multiswag_5_planet.py:287; a bf16 cast there is what this measures).  feature_nn runs on the bf16 matrix pipe
+ * with fp32 accumulation; pool, sampled moments and regress_nn stay exact fp32; same arguments and Philox streams as
+ * bnn_forward_f32, so outputs are comparable element by element.  v50 column mask only, no noisy form.
+ *   BNN_PREC_BF16    x, weights, activations rounded to bf16, 1 product per layer    (|d mu| up to ~1e-1: NOT within the 1e-5 bar)
+ *   BNN_PREC_BF16X3  operands split into hi + lo bf16 (16 significant bits), 3 products
+ *   BNN_PREC_BF16X6  three bf16 parts (24 bits), the 6 products of order <= 2: fp32-level error, not bit-reproducible vs fp32 */
+enum bnn_precision { BNN_PREC_F32 = 0, BNN_PREC_BF16 = 1, BNN_PREC_BF16X3 = 2, BNN_PREC_BF16X6 = 3 };
+int bnn_forward_lowp_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps,
+                         uint64_t philox_seed, int64_t draw_id0, int64_t system_id0, int32_t precision, float* out,
+                         float* pre_clamp, float* summary, void* stream);
+
 /* Fused SWAGModel.forward_swag_fast (spock_reg_model.py:878-908) over the MC driver loop
  * (figures/spock/regression.py:74-92 inside figures/multiswag_5_planet.py:295-298 /
  * figures/main_figures.py:154-156): per draw, sample the weights in the kernel prologue (same

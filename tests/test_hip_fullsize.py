@@ -113,3 +113,67 @@ def test_multiswag_sharded_driver_single_rank(full):
     assert torch.allclose(mom, want, rtol=1e-13, atol=0)  # slabs of 256 draws vs one launch: float64 sums, different association
     st = moments_to_mean_std(mom, 700)
     assert st["mean_mu"].min() >= 4 and st["mean_mu"].max() <= 12 and (st["std_mu"] >= 0).all()
+
+
+# ---- BASELINE.json configs[2] at FULL size: 1 000 000 systems x 100 draws = 1e8 evals; x has 4.1e9 elements (> 2^31) ----------
+B3, J3 = 1_000_000, 100
+
+
+@pytest.fixture(scope="module")
+def full_c3():
+    import bench
+    from bnn_chaos_model_amd import ops
+    dev = torch.device("cuda")
+    x = bench.synthetic_x(B3, dev, 777)
+    assert x.numel() > 2 ** 31
+    wa, w2, pd = bench.synthetic_ensemble(S, dev)
+    idx = (torch.arange(J3, dtype=torch.int32) % S).to(dev)
+    out = ops.multiswag(x, wa, w2, pd, idx, philox_seed=SEED + 1)
+    torch.cuda.synchronize()
+    yield dict(ops=ops, x=x, wa=wa, w2=w2, pd=pd, idx=idx, out=out)
+    del x, out
+    torch.cuda.empty_cache()
+
+
+def test_configs2_oracle_spot_checks_beyond_2_31_elements(full_c3):
+    """64 (draw, system) pairs of the 1e8 against the CPU oracle fed the very normals the kernel generated; the systems include
+    the first, the ones either side of element 2^31 of x, and the last two."""
+    from oracle import oracle as orc
+    o, f = full_c3["ops"], full_c3
+    out = f["out"]
+    assert out.shape == (J3, B3, 2) and torch.isfinite(out).all()
+    mu, sd = out[..., 0], out[..., 1]
+    assert mu.min() >= 4 and mu.max() <= 12 and sd.min() >= 0.5 and sd.max() <= 6
+    edge = 2 ** 31 // 4100                                      # system whose row holds element 2^31
+    rng = np.random.default_rng(6)
+    systems = [0, edge - 1, edge, edge + 1, B3 - 2, B3 - 1] + rng.integers(edge, B3, 2).tolist()
+    draws = [0, J3 - 1] + rng.integers(1, J3 - 1, 6).tolist()
+    plan = o.get_plan()
+    sched = orc.make_schedule([plan.layer_order(l) for l in range(6)], pool_parts=4)
+    wa, w2, pd = (t.cpu().numpy() for t in (f["wa"], f["w2"], f["pd"]))
+    z1 = o.philox_normal(0, SEED + 1, 0, J3, width=7583).cpu().numpy()
+    z2 = o.philox_normal(1, SEED + 1, 0, J3, width=30).cpu().numpy()
+    worst, n = 0.0, 0
+    for j in draws:
+        s = int(f["idx"][j])
+        w = orc.swag_draw(wa[s], w2[s], pd[s], z1[j], z2[j])
+        for b in systems:
+            eps = o.philox_normal(2, SEED + 1, int(j), 1, B=1, system_id0=int(b)).cpu().numpy()[0, 0]
+            ref = orc.forward(f["x"][b:b + 1].cpu().numpy(), w, eps[0:1], eps[1:2], sched=sched)[0]
+            worst = max(worst, np.abs(out[j, b].cpu().numpy() - ref).max())
+            n += 1
+    assert n == 64 and worst <= 2e-6, worst
+
+
+def test_configs2_sharding_and_launch_mode_invariance(full_c3):
+    """A slice that starts beyond element 2^31, evaluated on its own with its global offset, and the in-prologue-draw mode on a
+    slab of draws reproduce the one-launch result bit for bit."""
+    o, f = full_c3["ops"], full_c3
+    lo, hi = 900_000, 900_000 + 4096
+    part = o.multiswag(f["x"][lo:hi].contiguous(), f["wa"], f["w2"], f["pd"], f["idx"], philox_seed=SEED + 1, system_id0=lo)
+    assert torch.equal(part, f["out"][:, lo:hi])
+    got = o.multiswag(f["x"], f["wa"], f["w2"], f["pd"], f["idx"][40:44], philox_seed=SEED + 1, draw_id0=40, single_launch=True)
+    assert torch.equal(got, f["out"][40:44])
+    mom = o.moments(f["out"])
+    want = f["out"][:, -1000:, 0].double().sum(0)
+    assert torch.allclose(mom[-1000:, 0], want, rtol=1e-12, atol=0)
