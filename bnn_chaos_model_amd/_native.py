@@ -75,7 +75,7 @@ def lib():
     L.bnn_multiswag_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp,
                                     _vp, C.c_float, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp]
     L.bnn_moments_f64.argtypes = [_vp, C.c_int64, C.c_int64, _vp, C.c_int32, _vp]
-    L.bnn_truncnorm_f32.argtypes = [_vp, C.c_int64, _vp, C.c_int32, C.c_double, C.c_uint64, C.c_int64, _vp, _vp]
+    L.bnn_truncnorm_f32.argtypes = [_vp, C.c_int64, _vp, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_int64, _vp, _vp]
     L.bnn_prior_resample_f32.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, C.c_double, C.c_uint64, C.c_int64, _vp]
     L.bnn_regress_f32.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp]
     L.bnn_group_min_f32.argtypes = [_vp, C.c_int64, C.c_int32, _vp, _vp]

@@ -138,9 +138,10 @@ __global__ __launch_bounds__(256) void bnn_quantiles_kernel(const float* __restr
     }
 }
 
-// fast_truncnorm, right = inf: one thread per element, candidates in float64 exactly as numpy forms them
+// fast_truncnorm: one thread per element, candidates in float64 exactly as numpy forms them; the acceptance test is the
+// reference's (:352-358): right = inf -> v > left; left = inf -> v < right; else both
 __global__ void bnn_truncnorm_kernel(const float* __restrict__ musd, int64_t n, const double* __restrict__ normals, int nsamp, double left,
-                                     uint64_t seed, int64_t id0, float* __restrict__ out) {
+                                     double right, uint64_t seed, int64_t id0, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const f32x2 ms = *reinterpret_cast<const f32x2*>(musd + 2 * i);
@@ -157,7 +158,8 @@ __global__ void bnn_truncnorm_kernel(const float* __restrict__ musd, int64_t n, 
             const double z = normals ? normals[(int64_t)(s0 + k) * n + i] : (double)z4[k];
             const double v = z * scale + loc;  // rand_out * scale + loc (:347-350); no fma (-ffp-contract=off)
             if (s0 + k == 0) first = v;
-            if (v > left) { pick = v; found = true; break; }
+            const bool ok = right == INFINITY ? v > left : left == INFINITY ? v < right : (v > left && v < right);
+            if (ok) { pick = v; found = true; break; }
         }
     }
     out[i] = (float)(found ? pick : first);  // argmax of an all-False mask is 0 (:360-362)
@@ -656,13 +658,13 @@ int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x
     return launch_forward(plan, grid, p, true, false, stream);
 }
 
-int bnn_truncnorm_f32(const float* musd, int64_t n, const double* normals, int32_t nsamp, double left, uint64_t philox_seed, int64_t id0,
+int bnn_truncnorm_f32(const float* musd, int64_t n, const double* normals, int32_t nsamp, double left, double right, uint64_t philox_seed, int64_t id0,
                       float* out, void* stream) {
     if (n < 0 || nsamp < 1) return fail(BNN_ERR_INVALID, "bad n/nsamp");
     if (n == 0) return 0;
     if (!musd || !out) return fail(BNN_ERR_INVALID, "NULL argument");
     hipLaunchKernelGGL(bnn_truncnorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, musd, n, normals, (int)nsamp,
-                       left, philox_seed, id0, out);
+                       left, right, philox_seed, id0, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

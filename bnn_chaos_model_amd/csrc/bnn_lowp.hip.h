@@ -29,10 +29,13 @@ namespace bnn {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-DEVINL uint32_t cvt_pk_bf16(float a, float b) {  // {bf16(b), bf16(a)}: a in the low half; round to nearest even
-    uint32_t o;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
-    return o;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// {bf16(b), bf16(a)}: a in the low half; round to nearest even.  A vector conversion, NOT inline asm: hipcc emits one
+// v_cvt_pk_bf16_f32 for it and -- unlike for an asm statement -- inserts the wait states a following MFMA needs before it reads
+// the result (with the asm form the MFMAs read stale operands: NaNs).
+DEVINL uint32_t cvt_pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 DEVINL float bf16_lo_as_f32(uint32_t pk) { return __builtin_bit_cast(float, pk << 16); }
 DEVINL float bf16_hi_as_f32(uint32_t pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }

@@ -149,3 +149,33 @@ class FeatureRegressor(object):
         else:
             raise ValueError("rng must be 'torch' or 'philox'")
         return res if out is not None else res.to(X.device)
+
+    def predictive_bands(self, X, samples, chunks=1, trios=1, q=(50.0, 84.0, 16.0, 97.5, 2.5), philox_seed=0, system_id0=0,
+                         samples_per_launch=64, scale=0.5, stats=None, segments=None):
+        """Everything figures/multiswag_5_planet.py does between the features and the `cleaned` table (:295-298, 388-428,
+        484-489), streamed: the MC loop (one random ensemble member + one weight draw per chunk per sample), the truncated-normal
+        draw, the prior resampling past 9, the min over `trios` consecutive rows and, per simulation, the percentiles `q`
+        (default: median, l, u, ll, uu) and the average -- with neither [samples, B, 2] nor [samples, B] in memory beyond
+        `samples_per_launch` samples: the epilogue runs in the forward kernel's tail, a quantile sketch (ops.QuantileSketch,
+        one bin width of error) collects the draws.  Seed picks come from numpy's generator (regression.py:78, one per chunk per
+        sample, in the reference's order); all other noise is in-kernel Philox keyed by (philox_seed, sample, row).
+        Returns {"percentiles": [B / trios, len(q)], "average": [B / trios]} on the GPU."""
+        if X.dim() != 3 or X.shape[-1] != 41:
+            raise NotImplementedError("X must be [B, T, 41]")
+        g = _gpu()
+        wa, w2, pd = self.ensemble_state(g)
+        S = pd.shape[0]
+        m0 = self.swag_ensemble[0]
+        plan = ops.get_plan(m0.zero_mask(), m0.lowest)
+        B = X.shape[0]
+        nch = len(torch.chunk(torch.arange(B), chunks)) if B else 1
+        xg = X.detach().to(g, torch.float32).contiguous()
+        sk = ops.QuantileSketch(B, group=trios, segments=segments, device=g)
+        st = stats or ops.stats_params(device=g)
+        for s0 in range(0, samples, samples_per_launch):
+            ns = min(samples_per_launch, samples - s0)
+            seed_idx = np.array([np.random.randint(0, S) for _ in range(ns * nch)], np.int32)   # one pick per chunk per sample
+            t = ops.multiswag_stats(xg, wa, w2, pd, torch.as_tensor(seed_idx), st=st, nchunks=nch, scale=scale,
+                                    philox_seed=philox_seed, draw_id0=s0 * nch, system_id0=system_id0, plan=plan)
+            sk.update(t)
+        return {"percentiles": sk.percentiles(q), "average": sk.mean().float(), "sketch": sk}

@@ -1,6 +1,6 @@
 """Post-sampling statistics of the evaluation scripts on the GPU.
 
-    fast_truncnorm   figures/multiswag_5_planet.py:306-370 (= figures/main_figures.py:167-227), right = inf only
+    fast_truncnorm   figures/multiswag_5_planet.py:306-370 (= figures/main_figures.py:167-227)
     resample_prior   figures/multiswag_5_planet.py:396-422
     min_over_trios   figures/multiswag_5_planet.py:428
     percentiles      :484-489 and np.median of figures/main_figures.py:277-278  (ops.quantiles)
@@ -34,10 +34,9 @@ def prior_normalization():
 
 
 def fast_truncnorm(loc, scale=None, left=np.inf, right=np.inf, d=10000, nsamp=50, seed=0, rng="numpy"):
-    """First of `nsamp` Gaussian candidates above `left` (else the first candidate), elementwise; returns a tensor shaped like
+    """First of `nsamp` Gaussian candidates inside (left, right) (else the first candidate), elementwise, with the reference's
+    acceptance test (:352-358: right = inf -> v > left; left = inf -> v < right; else both); returns a tensor shaped like
     `scale` on the GPU.  `loc` may also be the [..., 2] (mu, std) tensor of the forward, with scale=None."""
-    if right != np.inf or left == np.inf:
-        raise NotImplementedError("only the one-sided form used by the scripts (left finite, right = inf) is built")
     g = _gpu()
     if scale is None:
         musd = torch.as_tensor(loc).to(g, torch.float32).contiguous()
@@ -57,7 +56,7 @@ def fast_truncnorm(loc, scale=None, left=np.inf, right=np.inf, d=10000, nsamp=50
         normals = torch.as_tensor(host).to(g)
     elif rng != "philox":
         raise ValueError("rng must be 'numpy' or 'philox'")
-    N.check(N.lib().bnn_truncnorm_f32(N.ptr(musd), n, N.ptr(normals), int(nsamp), float(left), int(seed), 0, N.ptr(out), N.stream_ptr()))
+    N.check(N.lib().bnn_truncnorm_f32(N.ptr(musd), n, N.ptr(normals), int(nsamp), float(left), float(right), int(seed), 0, N.ptr(out), N.stream_ptr()))
     return out.reshape(tuple(shape))
 
 

@@ -162,11 +162,13 @@ int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments,
  * R <= 16384 (one workgroup sorts one system's column in LDS). */
 int bnn_quantiles_f32(const float* samples, int64_t R, int64_t B, const double* host_q, int32_t nq, float* out, void* stream);
 
-/* fast_truncnorm with right = inf (figures/multiswag_5_planet.py:306-370, figures/main_figures.py:167-227):
+/* fast_truncnorm (figures/multiswag_5_planet.py:306-370, figures/main_figures.py:167-227); the scripts call it with left = 4,
+ * right = inf; the other two forms of its acceptance test (:352-358: left = inf -> v < right; both finite -> left < v < right)
+ * are built as well (pass INFINITY for an open side):
  *   musd [n,2] float32 = (loc, scale) pairs -- the [R,B,2] output of the forward as it stands;
  *   normals [nsamp, n] float64 (the reference's np.random.normal draws, element order) or NULL = in-kernel Philox;
- *   out [n] float32 = first of the nsamp candidates loc + scale*z (float64) that exceeds `left`, else the first one. */
-int bnn_truncnorm_f32(const float* musd, int64_t n, const double* normals, int32_t nsamp, double left, uint64_t philox_seed,
+ *   out [n] float32 = first of the nsamp candidates loc + scale*z (float64) inside the interval, else the first one. */
+int bnn_truncnorm_f32(const float* musd, int64_t n, const double* normals, int32_t nsamp, double left, double right, uint64_t philox_seed,
                       int64_t id0, float* out, void* stream);
 
 /* Prior resampling (figures/multiswag_5_planet.py:396-422): vals[i] >= threshold is replaced by inv_cdf(u[rank[i]]).

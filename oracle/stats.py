@@ -6,13 +6,18 @@ make_golden.py produces by executing the reference's own source fragments."""
 import numpy as np
 
 
-def truncnorm_first_good(loc, scale, normals, left):
-    """fast_truncnorm with right = inf: candidates = normals * scale + loc (float64), first one > left, else the first.
+def truncnorm_first_good(loc, scale, normals, left, right=np.inf):
+    """fast_truncnorm: candidates = normals * scale + loc (float64), first one inside the interval (:352-358), else the first.
     loc, scale: any shape (float32); normals [nsamp, n] float64 in flattened element order -> samples like scale."""
     sc = np.asarray(scale).reshape(-1)
     lc = np.asarray(loc).reshape(-1)
     rand_out = normals * sc[None] + lc[None]                      # :347-350
-    mask = rand_out > left                                        # :353-354
+    if right == np.inf:                                           # :352-358
+        mask = rand_out > left
+    elif left == np.inf:
+        mask = rand_out < right
+    else:
+        mask = (rand_out > left) & (rand_out < right)
     first_good = rand_out[mask.argmax(0), np.arange(sc.size)]     # :360-362
     out = np.zeros_like(sc)                                       # float32 like `scale` (:329)
     out[:] = first_good

@@ -342,3 +342,41 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], cwd=ROOT, env=env2,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stdout + r.stderr)
+
+
+def _gloo_bands_worker(rank, world, port, n_sims, trios, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from bnn_chaos_model_amd.distributed import all_gather_moments, shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B = n_sims * trios
+        lo, hi = shard_bounds(B, world, trios)[rank]
+        assert lo % trios == 0 and hi % trios == 0          # a simulation's trios stay on one rank
+        sims = torch.arange(lo // trios, hi // trios, dtype=torch.float32)
+        local = torch.stack([sims * 10 + k for k in range(6)], 1)   # stands in for [percentiles..., mean] of this rank's simulations
+        out = all_gather_moments(local, n_sims)
+        if rank == 0:
+            q.put(out.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_sims,world", ((10, 2), (7, 2), (5, 3), (2, 3)))
+def test_sharded_bands_gather_gloo(n_sims, world):
+    """The gather of MultiSwagSharded.predictive_quantiles on CPU ranks: simulations (groups of 3 trios) are sharded whole,
+    equal and ragged shards (and an empty one) reassemble in order with ONE all-gather."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + 10 * n_sims + world
+    procs = [ctx.Process(target=_gloo_bands_worker, args=(r, world, port, n_sims, 3, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([np.arange(n_sims, dtype=np.float32) * 10 + k for k in range(6)], 1)
+    assert np.array_equal(got, want)

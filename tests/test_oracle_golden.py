@@ -235,3 +235,13 @@ def test_all_thirty_pretrained_seeds_match_reference():
     for si in (0, 12):
         st = load_golden(f"swag_v50_{si}.npz")
         assert np.array_equal(st["w_avg"], ens["w_avg"][si]) and np.array_equal(st["pre_D"], ens["pre_D"][si])
+
+
+def test_truncnorm_two_sided_and_right_sided_forms():
+    """oracle/stats.truncnorm_first_good vs the reference's fast_truncnorm source for its other two acceptance tests."""
+    from oracle import stats
+    z = load_golden("case_truncnorm2.npz")
+    for name in ("two_sided", "right_only"):
+        got = stats.truncnorm_first_good(z["loc"], z["scale"], z[f"{name}_normals"], float(z[f"{name}_left"]), float(z[f"{name}_right"]))
+        assert got.dtype == np.float32 and np.array_equal(got, z[f"{name}_out"]), name
+    assert (z["two_sided_out"][0, :4] > 9).all()      # nothing inside (4, 9): the first candidate came back

@@ -141,3 +141,28 @@ def test_streaming_bands_at_configs1_size(ops, ens):
     assert np.median(err) < 0.004                                          # typically well inside a bin
     assert torch.allclose(sk.mean(), t.double().mean(0), rtol=1e-12)
     assert sk.hist.numel() * 4 + sk.mom.numel() * 8 < 40e6                # O(B * bins): 38 MB, whatever the number of draws
+
+
+def test_sharded_driver_bands_single_rank(ops, ens):
+    """MultiSwagSharded.predictive_quantiles (the 5-planet shape: trios of systems, min over the trio) at world size 1 ==
+    exact percentiles of the materialised post-epilogue samples within one bin width; the gather is a no-op here (the N > 1
+    gather is covered on CPU ranks by tests/test_host_cpu.py::test_sharded_bands_gather_gloo)."""
+    from bnn_chaos_model_amd.distributed import MultiSwagSharded
+    wa, w2, pd = ens
+    sims, J = 500, 600
+    x = synth(sims * 3, 9)
+    idx = torch.as_tensor((np.arange(J) % 2).astype(np.int32)).cuda()
+    drv = MultiSwagSharded(wa, w2, pd, draws_per_launch=128)
+    q = (2.5, 16.0, 50.0, 84.0, 97.5)
+    got = drv.predictive_quantiles(x, sims * 3, idx, q=q, philox_seed=13, trios=3)
+    assert got.shape == (sims, len(q) + 1)
+    t = ops.stats_draw(ops.multiswag(x, wa, w2, pd, idx, philox_seed=13), philox_seed=13)        # [J, sims*3]
+    outs = t.reshape(J, sims, 3).min(2).values.double()                                                  # np.min(samps_time, 2)
+    want = torch.quantile(outs, torch.tensor(q, dtype=torch.float64, device="cuda") / 100.0, dim=0).T
+    sk = ops.QuantileSketch(3, group=3)
+    tol = np.vectorize(sk.resolution)(want.cpu().numpy())
+    err = (got[:, :len(q)].double() - want).abs().cpu().numpy()
+    assert (err <= tol * 1.0001).all(), err.max()
+    assert torch.allclose(got[:, -1].double(), outs.mean(0), rtol=1e-6)
+    with pytest.raises(ValueError):
+        drv.predictive_quantiles(x[:-1], sims * 3, idx, trios=3)

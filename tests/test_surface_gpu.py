@@ -316,6 +316,16 @@ def test_five_planet_pipeline_end_to_end(ckpt_dir):
     np.random.seed(0)
     r2 = mod.run(str(ckpt_dir / "*v50*output.pkl"), sims=12, samples=40, rng="philox", seed=5)
     assert torch.equal(r["bands"], r2["bands"])  # counter-based noise: reproducible end to end
+    # the streaming form (statistics fused behind the forward kernel + quantile sketch): same distribution, different Philox
+    # streams; with 400 samples the medians of the two forms agree to a few standard errors
+    a = mod.run(str(ckpt_dir / "*v50*output.pkl"), sims=12, samples=400, rng="philox", seed=5)
+    st = mod.run(str(ckpt_dir / "*v50*output.pkl"), sims=12, samples=400, rng="philox", seed=5, streaming=True)
+    assert st["bands"].shape == (12, 5) and torch.isfinite(st["bands"]).all()
+    sb = st["bands"].cpu().numpy()
+    assert (sb[:, 4] <= sb[:, 2]).all() and (sb[:, 2] <= sb[:, 0]).all() and (sb[:, 0] <= sb[:, 1]).all() and (sb[:, 1] <= sb[:, 3]).all()
+    spread = (a["bands"][:, 1] - a["bands"][:, 2]).cpu().numpy() / 2 + 0.05     # ~1 sigma of the predictive distribution
+    assert (np.abs(sb[:, 0] - a["bands"][:, 0].cpu().numpy()) < 5 * 1.25 * spread / np.sqrt(400) + 0.02).all()
+    assert (np.abs(st["average"].cpu().numpy() - a["average"].cpu().numpy()) < 5 * spread / np.sqrt(400) + 0.3).all()
 
 
 def test_integration_bindings_run_the_callers_lines(ckpt_dir, inputs, monkeypatch):
@@ -398,3 +408,15 @@ def test_integration_bindings_run_the_callers_lines(ckpt_dir, inputs, monkeypatc
     assert raw.shape == (3, 32, 2) and np.isfinite(raw).all() and raw[..., 0].min() >= 4 and raw[..., 1].max() <= 6
     _preds = np.concatenate([raw], axis=1)
     assert np.median(_preds[..., 0], 0).shape == (32,)              # :277-278
+
+
+def test_fast_truncnorm_two_sided_and_right_sided():
+    """stats.fast_truncnorm with a finite right bound / an open left bound replays the reference (numpy generator consumed in
+    chunks of d elements, as the reference does) bit for bit."""
+    from bnn_chaos_model_amd import stats
+    z = load_golden("case_truncnorm2.npz")
+    for name in ("two_sided", "right_only"):
+        np.random.seed(6100)
+        got = stats.fast_truncnorm(z["loc"], z["scale"], left=float(z[f"{name}_left"]), right=float(z[f"{name}_right"]),
+                                   d=int(z["d"]), nsamp=int(z["nsamp"])).cpu().numpy()
+        assert np.array_equal(got, z[f"{name}_out"]), name
