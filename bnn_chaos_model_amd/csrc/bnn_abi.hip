@@ -555,6 +555,7 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     p.csz = (g->B + g->nchunks - 1) / g->nchunks;
     p.spc = pick_spc(g, p.csz);
     p.row_id0 = p.draw_id0 / g->nchunks;
+    p.xcd_order = (g->nchunks > 1 || (double)g->B * g->T * F * sizeof(float) > 256.0 * 1024 * 1024) ? 1 : 0;
     p.tab_f2 = pl->d_f2; p.tab_f4 = noisy ? pl->d_f4n : pl->d_f4; p.rcp_tab = pl->d_rcp;
     p.zero_mask = pl->arch.zero_mask;
     p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);

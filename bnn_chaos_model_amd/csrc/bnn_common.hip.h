@@ -20,6 +20,36 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 constexpr int SCR4 = 2 * 16 * S2;  // floats of LDS scratch per wave of a forward kernel: Philox normals + summaries of 16 systems
 
 // ------------------------------------------------------------------------------------------------
+// Work item of a forward workgroup: (draw e, block `sub` of the chunk of systems that draw covers).
+// The grid holds nsub * J workgroups.  Work order w: output row r = w % R fastest (R = J / nch draws share a chunk), then the
+// block of systems, then the chunk -- so consecutive w are the SAME systems under different draws.  Workgroups are dealt to
+// the 8 XCDs round-robin by block id (MI355X_MICROARCH.md; a speed assumption only, never correctness), and each XCD has its own
+// 4 MiB L2, so XCD k takes the k-th CONTIGUOUS eighth of the work order: the workgroups resident on one XCD then stream the same
+// few hundred systems through that XCD's L2 together, and x comes from HBM once.  (With the plain order id -> (draw, block) every
+// XCD touched every active block of systems; at nchunks = 10 that was ten 8 MB regions per 4 MiB L2, all of the x traffic fell
+// through to the Infinity Cache and the bf16 kernels sat at its 8 TB/s.)  The host switches it on (p.xcd_order) when draws are
+// chunked or x is larger than the Infinity Cache; for a dense grid over an x that the Infinity Cache holds (configs[1]: 164 MB)
+// the plain order measured 1.4 % faster (same-box A/B), at configs[2] (16.4 GB) the XCD order 2.2 % faster.
+// ------------------------------------------------------------------------------------------------
+struct WorkItem {
+    int e;        // draw
+    int64_t sub;  // block of systems within the draw's chunk
+};
+DEVINL WorkItem work_item(const FwdParams& p) {
+    const int64_t nblk = gridDim.x, b = blockIdx.x;
+    const int64_t per = nblk >> 3;
+    const int64_t w = (p.xcd_order && b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;
+    const int R = p.J / p.nch;
+    const int64_t nsub = nblk / p.J;
+    const int r = (int)(w % R);
+    const int64_t t = w / R;
+    WorkItem wi;
+    wi.sub = t % nsub;
+    wi.e = r * p.nch + (int)(t / nsub);
+    return wi;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11) and the normals derived from it.
 // Counters use GLOBAL draw / output-row / system ids, so results are invariant to sharding.
 // ------------------------------------------------------------------------------------------------

@@ -61,11 +61,12 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sl0 = lane >> 2, ph0 = lane & 3;  // feature_nn (4x4x1) coordinates: system in the wave-batch, timestep phase
 
-    // work item: draw e, block `sub` of its chunk of systems (torch.chunk semantics).  Draw-fastest block order: workgroups that
-    // are resident together work on the SAME systems under different draws, so x comes from HBM about once and from L2 after that.
-    const int64_t id = blockIdx.x;
-    const int e = (int)(id % p.J);
-    const int64_t sub = id / p.J;
+    // work item: draw e, block `sub` of its chunk of systems (torch.chunk semantics); XCD-aware draw-fastest order
+    // (work_item, bnn_common.hip.h): the workgroups resident on one XCD work on the SAME systems under different draws, so x
+    // comes from HBM once and from that XCD's L2 after that.
+    const WorkItem wi = work_item(p);
+    const int e = wi.e;
+    const int64_t sub = wi.sub;
     const int ch = e % p.nch;
     const int64_t r = e / p.nch;  // output row
     const int64_t seg0 = (int64_t)ch * p.csz;

@@ -31,6 +31,7 @@ struct FwdParams {
     int32_t J, nch;
     int64_t csz;
     int32_t spc;  // systems per workgroup (multiple of 64)
+    int32_t xcd_order;  // 1: XCD k takes the k-th contiguous eighth of the work order (work_item, bnn_common.hip.h)
     int32_t K, S;
     const float* W;  // [J,d] materialised draws (unfused) or nullptr
     const float* w_avg;

@@ -108,9 +108,24 @@ DEVINL Frag<NS> lowp_wfrag(const float* flat, int layer, int mt, int s, int g, i
     return f;
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+DEVINL uint32_t relu_pk_bf16(uint32_t pk) {  // ReLU on two packed bf16: one v_pk_max_i16 (negative floats are negative int16s)
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), z));
+}
+
 // ReLU + split of a layer's three accumulator tiles into the next layer's two B k-steps
 template <int NS>
 DEVINL void lowp_next_operand(const f32x4 (&acc)[3], Frag<NS>& b0, Frag<NS>& b1) {
+    if constexpr (NS == 1) {  // round first, then ReLU on the packed pairs: bf16(relu(v)) == relu(bf16(v)), half the instructions
+        b0.part[0][0] = relu_pk_bf16(cvt_pk_bf16(acc[0][0], acc[0][1]));
+        b0.part[0][1] = relu_pk_bf16(cvt_pk_bf16(acc[0][2], acc[0][3]));
+        b0.part[0][2] = relu_pk_bf16(cvt_pk_bf16(acc[1][0], acc[1][1]));
+        b0.part[0][3] = relu_pk_bf16(cvt_pk_bf16(acc[1][2], acc[1][3]));
+        b1.part[0][0] = relu_pk_bf16(cvt_pk_bf16(acc[2][0], acc[2][1]));
+        b1.part[0][1] = relu_pk_bf16(cvt_pk_bf16(acc[2][2], acc[2][3]));
+        return;  // elements 4..7 of b1 (the constant 1.0 of the bias slot, zeros) are set once by the caller
+    }
     f32x4 t0 = relu4(acc[0]), t1 = relu4(acc[1]), t2 = relu4(acc[2]);
     uint32_t pk[NS];
     split_pair<NS>(t0[0], t0[1], pk);
@@ -131,14 +146,13 @@ DEVINL void lowp_next_operand(const f32x4 (&acc)[3], Frag<NS>& b0, Frag<NS>& b1)
     split_pair<NS>(t2[2], t2[3], pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b1.part[p][1] = pk[p];
-#pragma unroll
-    for (int p = 0; p < NS; ++p) {
-        b1.part[p][2] = p == 0 ? 0x00003F80u : 0u;  // element 4 = bf16(1.0): the bias slot; element 5 = 0
-        b1.part[p][3] = 0u;
-    }
 }
 
-constexpr size_t lowp_lds_bytes() { return sizeof(float) * (FLAT_LDS + 4 * SCR4); }
+// per wave: [XST] x-tile staging buffer (4 systems x 4 rows x 41 floats = 656; doubles as the Philox scratch of the finish)
+// + [16 * S2] summaries of the wave-batch
+constexpr int XST = 4 * 4 * F;                     // 656 floats, a multiple of 4
+constexpr int SCRL = XST + 16 * S2 + 4;            // + one float that holds the constant 1.0 of the bias slot (padded to 16 B)
+constexpr size_t lowp_lds_bytes() { return sizeof(float) * (FLAT_LDS + 4 * SCRL); }
 
 template <int NS>
 __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParams p) {
@@ -152,9 +166,9 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
     const int g = lane >> 4, c = lane & 15;
     const int sq = c >> 2, tph = c & 3;  // system within the tile, timestep phase
 
-    const int64_t id = blockIdx.x;
-    const int e = (int)(id % p.J);
-    const int64_t sub = id / p.J;
+    const WorkItem wi = work_item(p);
+    const int e = wi.e;
+    const int64_t sub = wi.sub;
     const int ch = e % p.nch;
     const int64_t r = e / p.nch;
     const int64_t seg0 = (int64_t)ch * p.csz;
@@ -205,8 +219,26 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
     const float nm1 = (float)(T - 1), nT = (float)T;
     const float half_n0 = (float)ntiles * 0.5f;
     const int64_t rowstride = (int64_t)T * F;
-    float* epsscr = scr + wave * SCR4;
-    float* sumscr = epsscr + 16 * S2;
+    float* epsscr = scr + wave * SCRL;  // Philox normals of the finish; the x-tile staging buffer during the tile loop
+    float* sumscr = epsscr + XST;
+    float* xst = epsscr;
+    float* one_slot = sumscr + 16 * S2;
+    if (lane == 0) one_slot[0] = 1.0f;
+    static_assert(XST >= 16 * S2 && XST % 4 == 0, "staging buffer covers the Philox scratch and stays 16-byte aligned");
+    // x tile staging (global -> registers -> LDS -> fragment registers).  A lane's fragment is 8 floats of ONE row, and lanes
+    // that are neighbours in the wave hold DIFFERENT rows (164 B apart), so loading fragments straight from global memory makes
+    // every lane touch its own cache line: 64 lines per wave-instruction, and the kernel ran at exactly one tile per ~190 cycles
+    // per CU -- the L1's rate for that pattern, not the matrix or vector pipes'.  The four systems' 4-row spans of a tile are each
+    // 656 contiguous, 16-byte-aligned bytes: 164 chunks of 16 B, fetched by consecutive lanes (3 loads per lane, the last one
+    // partly idle), written to LDS as they are, and read back per fragment.
+    int stq[3];  // chunk id -> (span = system of the tile, offset within the span) for the three rounds; -1 = no chunk
+    int sto[3];
+#pragma unroll
+    for (int rnd = 0; rnd < 3; ++rnd) {
+        const int q = lane + 64 * rnd;
+        stq[rnd] = q < 4 * F ? q / F : -1;
+        sto[rnd] = 4 * (q % F);
+    }
 
     for (int64_t wb0 = b0 + (int64_t)wave * 16; wb0 < b1; wb0 += 64) {
         for (int sb = 0; sb < 4; ++sb) {  // four tiles' worth of systems: wb0 + 4 sb + sq
@@ -214,44 +246,80 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
             const int64_t sys = wb0 + 4 * sb + sq;
             const bool valid = sys < b1;
             const int64_t sysc = valid ? sys : b1 - 1;
-            const float* rowbase = p.x + sysc * rowstride + (int64_t)tph * F;
-            const float* rp = rowbase + 8 + 8 * g;  // group 3 reads columns 32..39: 38, 39 are replaced below
+            // staging chunk addresses = wave-uniform base of the tile (scalar registers, advanced on the scalar unit) + a per-lane
+            // 32-bit offset that does not change over the tiles: no vector address arithmetic in the loop
+            const float* tbase = p.x + (wb0 + 4 * sb) * rowstride;
+            uint32_t soff[3];
+#pragma unroll
+            for (int rnd = 0; rnd < 3; ++rnd) {
+                int64_t ss = wb0 + 4 * sb + (stq[rnd] < 0 ? 0 : stq[rnd]);
+                ss = ss < b1 ? ss : b1 - 1;  // >= wb0 + 4 sb: the offset is not negative
+                soff[rnd] = (uint32_t)((ss - (wb0 + 4 * sb)) * rowstride + sto[rnd]);
+            }
+            // this lane's fragment in the staging buffer: 6 floats at column 8 + 8g of its row, then (groups 0-2) the next two
+            // or (group 3) column 0 and the constant 1.0 -- per-lane addresses instead of selects on the loaded values
+            const float* fr = xst + sq * (4 * F) + tph * F;
+            const float* fr6 = g == 3 ? fr : fr + 8 + 8 * g + 6;
+            const float* fr7 = g == 3 ? one_slot : fr + 8 + 8 * g + 7;
 
             f32x4 mean0 = {0, 0, 0, 0}, m20 = {0, 0, 0, 0}, mean1 = {0, 0, 0, 0}, m21 = {0, 0, 0, 0};
-            f32x4 xa = *reinterpret_cast<const f32x4u*>(rp), xb = *reinterpret_cast<const f32x4u*>(rp + 4);
-            float x0 = rowbase[0];
-            asm volatile("" ::: "memory");
-            for (int it = 0; it < ntiles; ++it) {
-                // layer-1 B operand (selects at use time, not at load time: the loads are a tile ahead)
+            // Three tiles are kept in flight per wave (one tile = 2.6 KB; with ONE in flight the kernel ran at exactly
+            // tile bytes / loaded memory latency (~2 200 cycles) per wave, whatever the arithmetic): three register slots P, Q, R
+            // rotate by unrolling the tile loop three times.
+            constexpr int DEPTH = NS == 3 ? 1 : 3;  // the six-product form has no registers to spare (and is bound by its arithmetic)
+            f32x4 s0[3], s1[3], s2[3];
+            auto fetch = [&](int it, f32x4 (&slot)[3]) {
+                const int itc = it < ntiles ? it : ntiles - 1;
+#pragma unroll
+                for (int rnd = 0; rnd < 3; ++rnd)
+                    if (stq[rnd] >= 0) slot[rnd] = *reinterpret_cast<const f32x4*>(tbase + (int64_t)itc * 4 * F + soff[rnd]);
+            };
+            auto stage = [&](const f32x4 (&slot)[3]) {
+#pragma unroll
+                for (int rnd = 0; rnd < 3; ++rnd)
+                    if (stq[rnd] >= 0) *reinterpret_cast<f32x4*>(xst + 4 * (lane + 64 * rnd)) = slot[rnd];
+            };
+            fetch(0, s0);
+            if constexpr (DEPTH == 3) {
+                fetch(1, s1);
+                fetch(2, s2);
+            }
+            stage(s0);
+            Frag<NS> Bs0, Bs1;  // B operands of layers 2 and 3; the constant half of Bs1 (bias slot, padding) is written once
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                Bs1.part[q][2] = q == 0 ? 0x00003F80u : 0u;  // element 4 = bf16(1.0), element 5 = 0
+                Bs1.part[q][3] = 0u;
+            }
+            // one tile: LDS holds tile `it`; P holds tile it+1, R is free (gets tile it+3); at the end P goes to LDS
+            auto tile = [&](int it, const f32x4 (&P)[3], f32x4 (&R)[3]) {
+
+                // layer-1 B operand from the staged tile: 8 floats of this lane's row at column 8 + 8g (group 3: 32..37, then
+                // column 0 and the constant 1.0 of the bias slot)
                 Frag<NS> B1;
                 {
-                    const float v6 = g == 3 ? x0 : xb.z, v7 = g == 3 ? 1.0f : xb.w;
+                    float v[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) v[j] = fr[8 + 8 * g + j];
+                    const float v6 = *fr6, v7 = *fr7;
                     uint32_t pk[NS];
-                    split_pair<NS>(xa.x, xa.y, pk);
+                    split_pair<NS>(v[0], v[1], pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][0] = pk[q];
-                    split_pair<NS>(xa.z, xa.w, pk);
+                    split_pair<NS>(v[2], v[3], pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][1] = pk[q];
-                    split_pair<NS>(xb.x, xb.y, pk);
+                    split_pair<NS>(v[4], v[5], pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][2] = pk[q];
                     split_pair<NS>(v6, v7, pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][3] = pk[q];
                 }
-                {
-                    const int itn = (it + 1 < ntiles) ? it + 1 : it;
-                    const float* rn = rp + (int64_t)itn * 4 * F;
-                    xa = *reinterpret_cast<const f32x4u*>(rn);
-                    xb = *reinterpret_cast<const f32x4u*>(rn + 4);
-                    x0 = rowbase[(int64_t)itn * 4 * F];
-                    asm volatile("" ::: "memory");
-                }
+                fetch(it + DEPTH, R);  // DEPTH tiles ahead: in flight while this tile (and the next two) compute
                 f32x4 acc[3];
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) acc[mt] = mfma_split<NS>(A1[mt], B1, (f32x4){0, 0, 0, 0});
-                Frag<NS> Bs0, Bs1;
                 lowp_next_operand<NS>(acc, Bs0, Bs1);
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) {
@@ -263,21 +331,57 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
                 y0 = mfma_split<NS>(A3[0][1], Bs1, y0);
                 f32x4 y1 = mfma_split<NS>(A3[1][0], Bs0, (f32x4){0, 0, 0, 0});
                 y1 = mfma_split<NS>(A3[1][1], Bs1, y1);
-                // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps.  y0[r] = neuron 4g + r,
-                // y1[r] = neuron 16 + 4g + r (a real neuron only for g = 0)
-                const float rcn = p.rcp_tab[it];
+                // torch.mean / torch.std over time (:418-419).  y0[r] = neuron 4g + r, y1[r] = neuron 16 + 4g + r (a real neuron
+                // only for g = 0).  NS >= 2: Welford over this lane's timesteps, as in the fp32 kernel.  NS = 1: plain sums of y and
+                // y^2 (half the instructions; their fp32 cancellation error, ~1e-5 relative on the variance, is far below bf16's own).
+                if constexpr (NS == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        mean0[i] += y0[i];
+                        m20[i] = fmaf(y0[i], y0[i], m20[i]);
+                        mean1[i] += y1[i];
+                        m21[i] = fmaf(y1[i], y1[i], m21[i]);
+                    }
+                } else {
+                    const float rcn = p.rcp_tab[it];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float dl = y0[i] - mean0[i];
+                        float mn = fmaf(dl, rcn, mean0[i]);
+                        m20[i] = fmaf(dl, y0[i] - mn, m20[i]);
+                        mean0[i] = mn;
+                        dl = y1[i] - mean1[i];
+                        mn = fmaf(dl, rcn, mean1[i]);
+                        m21[i] = fmaf(dl, y1[i] - mn, m21[i]);
+                        mean1[i] = mn;
+                    }
+                }
+                // this tile's fragment reads were issued at its top: the buffer is free for the next tile.  The barrier keeps the
+                // writes (and the wait for the loads they need) HERE, a whole tile of work after the loads were issued: left alone,
+                // the scheduler hoists them to just behind the loads and every tile waits out a full memory latency.
+                __builtin_amdgcn_sched_barrier(0);
+                stage(P);
+            };
+            if constexpr (DEPTH == 3) {
+                for (int it = 0; it < ntiles; it += 3) {
+                    tile(it, s1, s0);
+                    if (it + 1 < ntiles) tile(it + 1, s2, s1);
+                    if (it + 2 < ntiles) tile(it + 2, s0, s2);
+                }
+            } else {
+                for (int it = 0; it < ntiles; ++it) tile(it, s0, s0);
+            }
+            if constexpr (NS == 1) {  // sums over the 4 timestep phases, then mean and M2 = sum y^2 - (sum y)^2 / T
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float dl = y0[i] - mean0[i];
-                    float mn = fmaf(dl, rcn, mean0[i]);
-                    m20[i] = fmaf(dl, y0[i] - mn, m20[i]);
-                    mean0[i] = mn;
-                    dl = y1[i] - mean1[i];
-                    mn = fmaf(dl, rcn, mean1[i]);
-                    m21[i] = fmaf(dl, y1[i] - mn, m21[i]);
-                    mean1[i] = mn;
+                    float a = mean0[i] + quad_perm<0xB1>(mean0[i]), b = m20[i] + quad_perm<0xB1>(m20[i]);
+                    a = a + quad_perm<0x4E>(a); b = b + quad_perm<0x4E>(b);
+                    mean0[i] = a / nT; m20[i] = fmaxf(b - a * mean0[i], 0.0f);  // cancellation can leave a tiny negative number
+                    a = mean1[i] + quad_perm<0xB1>(mean1[i]); b = m21[i] + quad_perm<0xB1>(m21[i]);
+                    a = a + quad_perm<0x4E>(a); b = b + quad_perm<0x4E>(b);
+                    mean1[i] = a / nT; m21[i] = fmaxf(b - a * mean1[i], 0.0f);
                 }
-            }
+            } else {
             // merge the 4 timestep phases (lanes c, c^1, c^2, c^3): equal-count Chan update, symmetric
             {
                 float half_n = half_n0;
@@ -298,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
                     }
                     half_n = half_n * 2.0f;
                 }
+            }
             }
             // sampled moments (:420-431).  Lane (g, tph) finishes neuron 4g + tph and, for g = 0, neuron 16 + tph.
             const int slot = 4 * sb + sq;  // this system's slot among the 16 of the wave-batch

@@ -1,6 +1,6 @@
-"""BASELINE.json configs[4] asks for a bf16-vs-fp32 tolerance sweep.  No bf16 kernel is built (the metric is fp32); this
-CPU test measures, with the pinned oracle, what rounding the inputs and/or the weights to bf16 (fp32 accumulation) does to
-the outputs, so the number is on record before a reduced-precision engine is considered."""
+"""BASELINE.json configs[4] asks for a bf16-vs-fp32 tolerance sweep.  The GPU side of it is tests/test_lowp.py (the opt-in
+bf16 / split-bf16 kernels of bnn_lowp.hip.h); this CPU test keeps the oracle-side record: what rounding the inputs and/or the
+weights to bf16 (fp32 accumulation, fp32 activations) does to the outputs of the pinned oracle."""
 import numpy as np
 
 from conftest import load_golden, tape
@@ -28,5 +28,5 @@ def test_bf16_rounding_error_budget(inputs, capsys):
     with capsys.disabled():
         for name, emu, esd, med in rows:
             print(f"\n  bf16 sweep [{name:13s}] max |d mu| = {emu:.3e}   max |d std| = {esd:.3e}   median |d mu| = {med:.3e}", end="")
-    # three to four orders of magnitude above the 1e-5 parity bar: a bf16-input engine cannot be the headline path
+    # three to four orders of magnitude above the 1e-5 parity bar: a bf16-operand kernel can only be an opt-in approximate mode
     assert rows[2][1] > 1e-3 and rows[2][1] < 2.0
