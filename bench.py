@@ -37,8 +37,17 @@ WORKLOADS = {
     "c2": dict(systems=10_000, seeds=30, samples=100, name="configs[1]: 30-seed MultiSWAG, 10k systems x 100 MC samples, fp32"),
     # forward(noisy_val=True) with every normal generated in-kernel; not a BASELINE config
     "noisy": dict(systems=10_000, seeds=30, samples=10, noisy=True, name="f4: forward(noisy_val=True), 10k systems x 300 draws, in-kernel Philox noise"),
+    # BASELINE.json configs[4], one GPU's share: 125 000 five-planet systems = 375 000 rows, 100 samples x 10 chunks, one random
+    # ensemble member + one weight draw per chunk per sample (figures/multiswag_5_planet.py:295-298).  fp32 by default;
+    # --precision bf16 | bf16x3 | bf16x6 runs the OPT-IN reduced-precision forward (never the default, never the headline).
+    "c5": dict(systems=375_000, seeds=30, samples=100, chunks=10, name="configs[4] share: 5-planet shapes, 375k rows x 100 samples x 10 chunks"),
     "tiny": dict(systems=512, seeds=30, samples=2, name="smoke-sized grid"),
 }
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+DTYPE_OF = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate (feature_nn); f32 elsewhere",
+            "bf16x3": "split-bf16 x3 (16 significant bits), f32 accumulate (feature_nn); f32 elsewhere",
+            "bf16x6": "split-bf16 x6 (24 significant bits), f32 accumulate (feature_nn); f32 elsewhere"}
+PRODUCTS_OF = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6}
 
 
 def synthetic_x(B, device, seed):
@@ -209,6 +218,7 @@ def parse(argv=None):
     ap.add_argument("--unfused", action="store_true", help="separate ops.swag_draw + ops.forward calls")
     ap.add_argument("--single-launch", action="store_true", help="in-kernel draw in every workgroup prologue (no workspace)")
     ap.add_argument("--spb", type=int, default=0, help="systems per workgroup (0 = auto)")
+    ap.add_argument("--precision", default="f32", choices=sorted(DTYPE_OF), help="opt-in reduced-precision forward (workload c5 / c3 / c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-systems", type=int, default=8192, help="systems of the batch the CPU baselines are timed on")
     ap.add_argument("--allow-gloo", action="store_true", help="accept a gloo moments gather when RCCL cannot start (the line says degraded)")
@@ -282,13 +292,21 @@ def main():
     if args.samples:
         wl["samples"] = args.samples
     B, S, M = wl["systems"], wl["seeds"], wl["samples"]
-    J = wl.get("draws", S * M)
+    nch = wl.get("chunks", 1)
+    J = wl.get("draws", S * M) if nch == 1 else M * nch
     noisy = bool(wl.get("noisy"))
+    lowp = args.precision != "f32"
+    if lowp and (noisy or args.unfused or args.single_launch):
+        sys.exit("--precision applies to the fused quiet forward only")
 
     x = synthetic_x(B, dev, seed=123 + rank)          # this rank's shard: global systems [rank*B, (rank+1)*B)
     wa, w2, pd = synthetic_ensemble(S, dev)           # replicated ensemble (29 MB)
-    seed_idx = (torch.arange(J, dtype=torch.int32) % S).to(dev)  # dense grid: every seed x every sample
-    out = torch.empty((J, B, 2), dtype=torch.float32, device=dev)
+    if nch == 1:
+        seed_idx = (torch.arange(J, dtype=torch.int32) % S).to(dev)  # dense grid: every seed x every sample
+    else:                                                            # one random member per chunk per sample (regression.py:78)
+        import numpy as np
+        seed_idx = torch.as_tensor(np.random.default_rng(7).integers(0, S, J).astype(np.int32)).to(dev)
+    out = torch.empty((J // nch, B, 2), dtype=torch.float32, device=dev)
     plan = ops.get_plan()
     W_noisy = ops.swag_draw(wa, w2, pd, seed_idx, philox_seed=99, plan=plan) if noisy else None
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -303,8 +321,9 @@ def main():
             W = ops.swag_draw(wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, plan=plan)
             o = ops.forward(x, W, philox_seed=99, draw_id0=0, system_id0=rank * B, plan=plan, systems_per_block=args.spb)
         else:
-            o = ops.multiswag(x, wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, system_id0=rank * B, plan=plan, out=out,
-                              systems_per_block=args.spb, single_launch=args.single_launch)
+            o = ops.multiswag(x, wa, w2, pd, seed_idx, nchunks=nch, philox_seed=99, draw_id0=0, system_id0=rank * B, plan=plan,
+                              out=None if lowp else out, systems_per_block=args.spb, single_launch=args.single_launch,
+                              precision=args.precision)
         if timed:
             ev1[i].record()
         mom = ops.moments(o)
@@ -331,10 +350,10 @@ def main():
         dt = float(t.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
 
-    evals_per_step = world * B * J
+    evals_per_step = world * B * (J // nch)   # every system under every sample (a chunked draw covers 1/nch of the systems)
     value = evals_per_step * args.steps / dt
     if rank == 0:
-        evals_per_launch = B * J
+        evals_per_launch = B * (J // nch)
         kin = 41 if noisy else 31
         ach_tflops = evals_per_launch * ALG_FLOP_PER_EVAL / (kern_ms * 1e-3) / 1e12
         exe_tflops = evals_per_launch * EXEC_FLOP_PER_EVAL[kin] / (kern_ms * 1e-3) / 1e12
@@ -351,11 +370,13 @@ def main():
         kernel = ("bnn_forward_kernel<41,noisy> (ops.forward, noisy_val=True, in-kernel Philox)" if noisy else
                   "ops.swag_draw + ops.forward" if args.unfused else
                   ("multiswag, in-kernel draw per workgroup" if args.single_launch else "multiswag, draw-once workspace + forward"))
+        if lowp:
+            kernel = f"bnn_forward_lowp_kernel ({args.precision}): exact fp32 draw + feature_nn on the bf16 matrix pipe, {PRODUCTS_OF[args.precision]} product(s) per layer"
         res = {
             "metric": "system x MC-sample forward evals/sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "systems_per_gpu": B, "seeds": S, "mc_samples": M, "draws": J, "timesteps": 100,
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_OF[args.precision], "data": "synthetic",
+            "config": {"workload": wl["name"], "systems_per_gpu": B, "seeds": S, "mc_samples": M, "draws": J, "chunks": nch, "timesteps": 100,
                        "features": 41, "noise": "in-kernel Philox4x32-10", "kernel": kernel,
                        "sharding": f"systems over {world} rank(s), all-gather of moments",
                        "collective": (dist.get_backend() if world > 1 else "none"), "degraded": degraded, "ranks_seen": ranks_seen},
@@ -367,6 +388,13 @@ def main():
                                  "(the v50 mask drops 10 of 41 input columns); kernel_ms = HIP events around the draw + forward launches",
                          "hbm_algorithmic_GBs": ach_gbs, "hbm_frac_of_8TBs": ach_gbs / PEAK_HBM_GBS},
         }
+        if lowp:   # priced against the bf16 matrix pipe; issued flops = algorithmic x products; these forms are vector-issue bound
+            peak = PEAK_BF16_MFMA_TFLOPS
+            iss = exe_tflops * PRODUCTS_OF[args.precision]
+            res["roofline"].update({"peak": peak, "frac": ach_tflops / peak, "achieved_executed": iss, "frac_executed": iss / peak, "traffic": None,
+                                    "note": "opt-in reduced precision (DESIGN.md 4.6): outputs are NOT within the 1e-5 parity bar; frac = algorithmic "
+                                            "flop/eval over the dense bf16 MFMA peak, frac_executed counts the split products; the kernels are "
+                                            "bound by vector issue (convert / ReLU / split / pool), not by the matrix pipe or HBM"})
         if not args.no_cpu_baseline and world == 1:
             ns = min(B, args.cpu_sample_systems)
             xs = x[:ns].cpu().numpy()
