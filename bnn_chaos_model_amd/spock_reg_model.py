@@ -327,9 +327,20 @@ class VarModel:
         return self._forward_gpu(x, self._w[None], noisy=bool(noisy_val))
 
     def sample(self, x, samples=10):
-        """VarModel.sample (:530-545): mean over `samples` noisy forwards of mu + N(0,1)*std -> float64 ndarray [B]."""
+        """VarModel.sample (:530-545): mean over `samples` noisy forwards of mu + N(0,1)*std -> float64 ndarray [B].
+        rng = "torch": the reference's loop, call for call (CPU generators).  rng = "philox": the `samples` noisy forwards are
+        ONE launch (one output row per sample, all noise in-kernel); numpy's randn(B) per sample is drawn as the reference does."""
         x = x.cpu()
         init_device = self._device
+        if self.rng == "philox":
+            self._check_x(x)
+            g = _gpu()
+            xg = x.detach().to(g, torch.float32).contiguous()
+            W = self._w[None].to(g).expand(samples, -1).contiguous()
+            out = ops.forward(xg, W, philox_seed=self.philox_seed, draw_id0=self._next_philox_id(samples), plan=self._plan(),
+                              noisy=True).cpu().numpy()                                    # [samples, B, 2]
+            all_samp = [out[s, :, 0] + np.random.randn(out.shape[1]) * out[s, :, 1] for s in range(samples)]
+            return np.average(all_samp, axis=0)
         self.cpu()  # the reference forces CPU here, so its noise comes from the CPU generators
         all_samp = []
         for _ in range(samples):

@@ -1,4 +1,5 @@
-"""PyTorch custom-op registration of the three hot-path entry points (torch.ops.bnn_chaos.*).
+"""PyTorch custom-op registration of the hot-path entry points (torch.ops.bnn_chaos.*): swag_draw, forward, multiswag,
+multiswag_moments, multiswag_stats.
 
 BASELINE.json's north_star asks for "PyTorch-ROCm custom ops": these are thin torch.library wrappers over
 bnn_chaos_model_amd.ops (ctypes -> C ABI -> HIP kernels) with shape-only fake implementations, so the ops can be
@@ -52,3 +53,36 @@ def multiswag(x: torch.Tensor, w_avg: torch.Tensor, w2_avg: torch.Tensor, pre_D:
 @multiswag.register_fake
 def _(x, w_avg, w2_avg, pre_D, seed_idx, z1, z2, eps, nchunks, scale, philox_seed, draw_id0, system_id0):
     return x.new_empty((seed_idx.numel() // nchunks, x.shape[0], 2))
+
+
+@torch.library.custom_op(f"{LIB}::multiswag_moments", mutates_args=())
+def multiswag_moments(x: torch.Tensor, w_avg: torch.Tensor, w2_avg: torch.Tensor, pre_D: torch.Tensor, seed_idx: torch.Tensor,
+                      scale: float, philox_seed: int, draw_id0: int, system_id0: int, draws_per_launch: int) -> torch.Tensor:
+    """Predictive moments of the dense (systems x draws) grid -> float64 [B, 4] (sum mu, sum mu^2, sum std, sum std^2), the draws
+    evaluated in slabs of `draws_per_launch` so that [J,B,2] is never materialised (the multi-GPU gather payload)."""
+    mom = None
+    J = seed_idx.numel()
+    for j0 in range(0, J, max(int(draws_per_launch), 1)):
+        s = ops.multiswag(x, w_avg, w2_avg, pre_D, seed_idx[j0:j0 + draws_per_launch], scale=scale, philox_seed=philox_seed,
+                          draw_id0=draw_id0 + j0, system_id0=system_id0)
+        mom = ops.moments(s, mom)
+    return mom if mom is not None else x.new_zeros((x.shape[0], 4), dtype=torch.float64)
+
+
+@multiswag_moments.register_fake
+def _(x, w_avg, w2_avg, pre_D, seed_idx, scale, philox_seed, draw_id0, system_id0, draws_per_launch):
+    return x.new_empty((x.shape[0], 4), dtype=torch.float64)
+
+
+@torch.library.custom_op(f"{LIB}::multiswag_stats", mutates_args=())
+def multiswag_stats(x: torch.Tensor, w_avg: torch.Tensor, w2_avg: torch.Tensor, pre_D: torch.Tensor, seed_idx: torch.Tensor,
+                    nchunks: int, scale: float, philox_seed: int, draw_id0: int, system_id0: int) -> torch.Tensor:
+    """multiswag with the scripts' statistics epilogue (truncated-normal draw at 4, prior resampling at 9;
+    figures/multiswag_5_planet.py:388-422) fused into the kernel tail -> t [J/nchunks, B]."""
+    return ops.multiswag_stats(x, w_avg, w2_avg, pre_D, seed_idx, nchunks=nchunks, scale=scale, philox_seed=philox_seed,
+                               draw_id0=draw_id0, system_id0=system_id0)
+
+
+@multiswag_stats.register_fake
+def _(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, scale, philox_seed, draw_id0, system_id0):
+    return x.new_empty((seed_idx.numel() // nchunks, x.shape[0]))

@@ -210,6 +210,17 @@ def test_sample_with_philox_rng(swag_states, tmp_path):
     # each is a mean of N draws of mu + n * std with std <= 6: the SE of the difference is <= sqrt(2) * 6 / sqrt(N) = 0.15,
     # so 0.6 is a 4-sigma bound for the worst possible system
     assert np.abs(a - b).max() < 0.6, np.abs(a - b).max()
+    # the philox form is ONE launch for all samples and equals the sample-by-sample loop of noisy forwards bit for bit
+    m._philox_calls = 100
+    np.random.seed(2)
+    one = m.sample(x, samples=7)
+    m._philox_calls = 100
+    np.random.seed(2)
+    acc = []
+    for _ in range(7):
+        o = m(x).detach().cpu().numpy()
+        acc.append(o[:, 0] + np.random.randn(16) * o[:, 1])
+    assert np.array_equal(one, np.average(acc, axis=0))
 
 
 def test_feature_pack_matches_reference(ops):

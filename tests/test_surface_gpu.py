@@ -245,6 +245,10 @@ def test_torch_custom_ops(swag_states, inputs):
                                            torch.empty((1, 7583, 30), device="cuda"), torch.empty(6, dtype=torch.int32, device="cuda"),
                                            None, None, None, 2, 0.5, 0, 0, 0)
         assert fo.shape == (3, 7, 2)
+    mom = torch.ops.bnn_chaos.multiswag_moments(x, wa, w2, pd, idx, 0.5, 42, 0, 0, 2)     # slabs of 2 draws
+    assert torch.allclose(mom, ops.moments(b), rtol=1e-13, atol=0)
+    t = torch.ops.bnn_chaos.multiswag_stats(x, wa, w2, pd, idx, 1, 0.5, 42, 0, 0)
+    assert torch.equal(t, ops.stats_draw(b, philox_seed=42))
 
 
 def test_statistics_epilogue_replays_reference():
