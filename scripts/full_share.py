@@ -3,8 +3,11 @@
 
   c4: 10M systems x 3000 draws over 8 GPUs -> 1.25M systems (20.5 GB of x) per GPU, draws in slabs of 250 reduced to
       float64 moments (MultiSwagSharded.local_moments): samples never exceed 2.5 GB.
+  c4q: the same share, but what the scripts consume instead of moments: statistics epilogue fused in the forward tail, per-system
+      quantile sketch (MultiSwagSharded.local_bands): median / 68 % / 95 % bands + mean of the post-epilogue times.
   c5: x [1e6, 3, 100, 41] over 8 GPUs -> 375k rows (6.15 GB) per GPU, 10 chunks x 100 samples: one (seed, draw) per chunk
       per sample, samples [100, 375k, 2] kept (the scripts consume them).
+  c5q: the same share streamed: FeatureRegressor-style bands per 5-planet system (min over its 3 trios), nothing kept.
 """
 import os
 import sys
@@ -42,6 +45,37 @@ if which == "c4":
     assert torch.isfinite(mom).all()
     print(f"c4 share: {B} systems x {J} draws = {B * J:.3g} evals in {dt:.2f} s = {B * J / dt:.4g} evals/s; "
           f"peak GPU memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+elif which == "c4q":
+    B, J = 1_250_000, 3000
+    x = big_x(B)
+    idx = (torch.arange(J, dtype=torch.int32) % 30).to(dev)
+    drv = MultiSwagSharded(wa, w2, pd, draws_per_launch=250)
+    q = (2.5, 16.0, 50.0, 84.0, 97.5)
+    drv.local_bands(x[:10_000], idx[:250], q, 7, 0)  # warm-up
+    torch.cuda.reset_peak_memory_stats()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    bands = drv.local_bands(x, idx, q, philox_seed=7, system_id0=0)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    assert bands.shape == (B, 6) and torch.isfinite(bands).all()
+    print(f"c4q share: {B} systems x {J} draws = {B * J:.3g} evals -> bands [B,5] + mean in {dt:.2f} s = {B * J / dt:.4g} evals/s; "
+          f"peak GPU memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB (x = {x.numel() * 4 / 2**30:.1f} GiB, sketch = "
+          f"{945 * 4 * B / 2**30:.1f} GiB)", flush=True)
+elif which == "c5q":
+    import numpy as np
+    B, chunks, samples, trios = 375_000, 10, 100, 3
+    x = big_x(B)
+    sk = ops.QuantileSketch(B, group=trios)
+    st = ops.stats_params()
+    rng = np.random.default_rng(0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for s0 in range(0, samples, 25):
+        idx = torch.as_tensor(rng.integers(0, 30, 25 * chunks).astype(np.int32))
+        sk.update(ops.multiswag_stats(x, wa, w2, pd, idx, st=st, nchunks=chunks, philox_seed=3, draw_id0=s0 * chunks))
+    bands = sk.percentiles((2.5, 16.0, 50.0, 84.0, 97.5))
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    assert bands.shape == (B // trios, 5) and torch.isfinite(bands).all()
+    print(f"c5q share: {B} rows x {samples} samples ({chunks} chunks) = {B * samples:.3g} evals -> bands per 5-planet system in "
+          f"{dt * 1e3:.1f} ms = {B * samples / dt:.4g} evals/s; peak GPU memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
 else:
     B, chunks, samples = 375_000, 10, 100
     x = big_x(B)
