@@ -359,7 +359,9 @@ __global__ void bnn_sketch_update_kernel(const float* __restrict__ tv, int64_t R
             const float w = p[j];
             v = (w < v || w != w) ? w : v;  // np.min propagates NaN
         }
-        hist[(int64_t)sketch_bin(sk, v) * n_sims + i] += 1u;
+        // no-return atomic: fire and forget (a plain load-add-store would chain every draw of the slab behind a memory round trip);
+        // one thread owns the simulation, so there is no contention
+        atomicAdd(&hist[(int64_t)sketch_bin(sk, v) * n_sims + i], 1u);
         s1 += (double)v;
         s2 += (double)v * (double)v;
     }
