@@ -901,5 +901,56 @@ int bnn_sketch_quantiles_f32(const uint32_t* hist, int64_t n_sims, const bnn_ske
     return 0;
 }
 
+// ---- slab drivers: the whole (systems x draws) grid reduced on the fly, nothing of size J x B ever in memory --------------------
+// Both evaluate the draws in slabs of `draws_per_launch` (a multiple of nchunks) through caller-provided scratch, on `stream`,
+// without synchronising: moments -> [B,4] float64; bands -> the quantile sketch (hist, mom) of the post-epilogue times.
+static int slab_args(const bnn_plan* plan, const bnn_grid* grid, int32_t draws_per_launch) {
+    if (!plan || !grid) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
+    if (grid->nchunks < 1 || grid->J < 0 || grid->J % grid->nchunks) return fail(BNN_ERR_INVALID, "J must be a multiple of nchunks");
+    if (draws_per_launch < grid->nchunks || draws_per_launch % grid->nchunks) return fail(BNN_ERR_INVALID, "draws_per_launch must be a positive multiple of nchunks");
+    return 0;
+}
+
+int bnn_multiswag_moments_f64(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg, const float* w2_avg,
+                              const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx, float scale, uint64_t philox_seed,
+                              int64_t draw_id0, int64_t system_id0, int32_t draws_per_launch, float* W_workspace, float* out_workspace,
+                              double* moments, void* stream) {
+    int rc = slab_args(plan, grid, draws_per_launch);
+    if (rc) return rc;
+    if (grid->B == 0) return 0;
+    if (!moments || !out_workspace || !W_workspace) return fail(BNN_ERR_INVALID, "NULL workspace / moments");
+    HIP_TRY(hipMemsetAsync(moments, 0, sizeof(double) * 4 * (size_t)grid->B, (hipStream_t)stream));
+    for (int32_t j0 = 0; j0 < grid->J; j0 += draws_per_launch) {
+        bnn_grid g = *grid;
+        g.J = grid->J - j0 < draws_per_launch ? grid->J - j0 : draws_per_launch;
+        rc = bnn_multiswag_f32(plan, &g, x, w_avg, w2_avg, pre_D, S, K, seed_idx + j0, nullptr, nullptr, nullptr, scale, philox_seed,
+                               draw_id0 + j0, system_id0, W_workspace, out_workspace, nullptr, nullptr, stream);
+        if (rc) return rc;
+        rc = bnn_moments_f64(out_workspace, g.J / g.nchunks, g.B, moments, 1, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int bnn_multiswag_bands_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg, const float* w2_avg,
+                            const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx, float scale, uint64_t philox_seed,
+                            int64_t draw_id0, int64_t system_id0, int32_t draws_per_launch, float* W_workspace, float* t_workspace,
+                            const bnn_stats* st, int32_t group, const bnn_sketch* sk, uint32_t* hist, double* mom, void* stream) {
+    int rc = slab_args(plan, grid, draws_per_launch);
+    if (rc) return rc;
+    if (grid->B == 0) return 0;
+    if (!t_workspace || !W_workspace || !hist || !mom) return fail(BNN_ERR_INVALID, "NULL workspace / sketch");
+    for (int32_t j0 = 0; j0 < grid->J; j0 += draws_per_launch) {
+        bnn_grid g = *grid;
+        g.J = grid->J - j0 < draws_per_launch ? grid->J - j0 : draws_per_launch;
+        rc = bnn_multiswag_stats_f32(plan, &g, x, w_avg, w2_avg, pre_D, S, K, seed_idx + j0, nullptr, nullptr, nullptr, scale,
+                                     philox_seed, draw_id0 + j0, system_id0, W_workspace, st, t_workspace, stream);
+        if (rc) return rc;
+        rc = bnn_sketch_update_u32(t_workspace, g.J / g.nchunks, g.B, group, sk, hist, mom, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 }  // extern "C"
 

@@ -84,17 +84,11 @@ class MultiSwagSharded:
         self.draws_per_launch = int(draws_per_launch)
 
     def local_moments(self, x_local, seed_idx, philox_seed, system_id0, scale=0.5):
-        """x_local [B_r,T,41] on this rank's GPU; seed_idx [J] (identical on every rank) -> float64 [B_r,4]."""
-        ops = self.ops
+        """x_local [B_r,T,41] on this rank's GPU; seed_idx [J] (identical on every rank) -> float64 [B_r,4].
+        One native call: the draws are evaluated in slabs of `draws_per_launch`, samples[J_slab, B_r, 2] stays small at C4 scale."""
         wa, w2, pd = self.state
-        J = seed_idx.numel()
-        mom = None
-        for j0 in range(0, J, self.draws_per_launch):  # slabs keep samples[J_slab, B_r, 2] small at C4 scale
-            idx = seed_idx[j0: j0 + self.draws_per_launch]
-            s = ops.multiswag(x_local, wa, w2, pd, idx, scale=scale, philox_seed=philox_seed, draw_id0=j0,
-                              system_id0=system_id0, plan=self.plan)
-            mom = ops.moments(s, mom)
-        return mom
+        return self.ops.multiswag_moments(x_local, wa, w2, pd, seed_idx, scale=scale, philox_seed=philox_seed, system_id0=system_id0,
+                                          draws_per_launch=self.draws_per_launch, plan=self.plan)
 
     def predictive_moments(self, x_local, B_total, seed_idx, philox_seed=0, scale=0.5):
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -113,11 +107,8 @@ class MultiSwagSharded:
         wa, w2, pd = self.state
         sk = ops.QuantileSketch(x_local.shape[0], group=trios, segments=segments, device=x_local.device)
         st = stats or ops.stats_params(device=x_local.device)
-        J = seed_idx.numel()
-        for j0 in range(0, J, self.draws_per_launch):
-            idx = seed_idx[j0: j0 + self.draws_per_launch]
-            sk.update(ops.multiswag_stats(x_local, wa, w2, pd, idx, st=st, scale=scale, philox_seed=philox_seed, draw_id0=j0,
-                                          system_id0=system_id0, plan=self.plan))
+        ops.multiswag_bands(x_local, wa, w2, pd, seed_idx, sk, st=st, scale=scale, philox_seed=philox_seed, system_id0=system_id0,
+                            draws_per_launch=self.draws_per_launch, plan=self.plan)
         if sk.n_sims == 0:
             return torch.empty((0, len(q) + 1), dtype=torch.float32, device=x_local.device)
         return torch.cat([sk.percentiles(q), sk.mean().float()[:, None]], 1)

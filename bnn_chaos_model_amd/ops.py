@@ -428,3 +428,59 @@ class QuantileSketch:
 
     def mean(self):
         return self.mom[:, 0] / max(self.count, 1)
+
+
+# ---- slab drivers in the native library: the whole grid reduced on the fly ---------------------------------------------------------
+def _slab_common(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, draws_per_launch, draw_id0, plan):
+    plan = plan or get_plan()
+    x = _f32(x, "x")
+    if x.dim() != 3 or x.shape[2] != 41:
+        raise NotImplementedError("x must be [B, T, 41]")
+    w_avg, w2_avg, pre_D, S, d, K = _ensemble(plan, w_avg, w2_avg, pre_D)
+    _check_same_device(x, w_avg=w_avg, w2_avg=w2_avg, pre_D=pre_D)
+    seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()
+    J = seed_idx.numel()
+    _check_grid(J, nchunks, draw_id0)
+    dpl = max(nchunks, (int(draws_per_launch) // nchunks) * nchunks)
+    dpl = min(dpl, max(J, nchunks))
+    return plan, x, w_avg, w2_avg, pre_D, S, d, K, seed_idx, J, dpl
+
+
+@_on_device_of(0)
+def multiswag_moments(x, w_avg, w2_avg, pre_D, seed_idx, nchunks=1, scale=0.5, philox_seed=0, draw_id0=0, system_id0=0,
+                      draws_per_launch=256, plan=None):
+    """Predictive moments of the whole grid -> float64 [B,4] (sum mu, sum mu^2, sum std, sum std^2 over the output rows), the
+    draws evaluated `draws_per_launch` at a time inside ONE native call (bnn_multiswag_moments_f64): [J,B,2] never exists."""
+    plan, x, w_avg, w2_avg, pre_D, S, d, K, seed_idx, J, dpl = _slab_common(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, draws_per_launch, draw_id0, plan)
+    B, T, _ = x.shape
+    mom = torch.empty((B, 4), dtype=torch.float64, device=x.device)
+    ws = _workspace(dpl, d, x.device)
+    outw = torch.empty((dpl // nchunks, B, 2), dtype=torch.float32, device=x.device)
+    g = _grid(B, T, J, nchunks, 0)
+    N.check(N.lib().bnn_multiswag_moments_f64(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
+                                              N.ptr(seed_idx), float(scale), int(philox_seed), int(draw_id0), int(system_id0), dpl,
+                                              N.ptr(ws), N.ptr(outw), N.ptr(mom), N.stream_ptr()))
+    if B and J == 0:
+        mom.zero_()
+    return mom
+
+
+@_on_device_of(0)
+def multiswag_bands(x, w_avg, w2_avg, pre_D, seed_idx, sketch, st=None, nchunks=1, scale=0.5, philox_seed=0, draw_id0=0,
+                    system_id0=0, draws_per_launch=256, plan=None):
+    """The whole grid streamed into `sketch` (a QuantileSketch over x's systems) inside ONE native call
+    (bnn_multiswag_bands_f32): statistics epilogue in the forward tail, min over the sketch's group, histogram update."""
+    plan, x, w_avg, w2_avg, pre_D, S, d, K, seed_idx, J, dpl = _slab_common(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, draws_per_launch, draw_id0, plan)
+    B, T, _ = x.shape
+    if sketch.n_sims * sketch.group != B or sketch.hist.device != x.device:
+        raise ValueError("the sketch must cover x's systems on x's device")
+    st = st or stats_params(device=x.device)
+    ws = _workspace(dpl, d, x.device)
+    tw = torch.empty((dpl // nchunks, B), dtype=torch.float32, device=x.device)
+    g = _grid(B, T, J, nchunks, 0)
+    N.check(N.lib().bnn_multiswag_bands_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
+                                            N.ptr(seed_idx), float(scale), int(philox_seed), int(draw_id0), int(system_id0), dpl,
+                                            N.ptr(ws), N.ptr(tw), C.byref(st), sketch.group, C.byref(sketch.spec), N.ptr(sketch.hist),
+                                            N.ptr(sketch.mom), N.stream_ptr()))
+    sketch.count += J // nchunks
+    return sketch

@@ -172,10 +172,7 @@ class FeatureRegressor(object):
         xg = X.detach().to(g, torch.float32).contiguous()
         sk = ops.QuantileSketch(B, group=trios, segments=segments, device=g)
         st = stats or ops.stats_params(device=g)
-        for s0 in range(0, samples, samples_per_launch):
-            ns = min(samples_per_launch, samples - s0)
-            seed_idx = np.array([np.random.randint(0, S) for _ in range(ns * nch)], np.int32)   # one pick per chunk per sample
-            t = ops.multiswag_stats(xg, wa, w2, pd, torch.as_tensor(seed_idx), st=st, nchunks=nch, scale=scale,
-                                    philox_seed=philox_seed, draw_id0=s0 * nch, system_id0=system_id0, plan=plan)
-            sk.update(t)
+        seed_idx = np.array([np.random.randint(0, S) for _ in range(samples * nch)], np.int32)   # one pick per chunk per sample
+        ops.multiswag_bands(xg, wa, w2, pd, torch.as_tensor(seed_idx), sk, st=st, nchunks=nch, scale=scale, philox_seed=philox_seed,
+                            system_id0=system_id0, draws_per_launch=samples_per_launch * nch, plan=plan)
         return {"percentiles": sk.percentiles(q), "average": sk.mean().float(), "sketch": sk}

@@ -244,6 +244,23 @@ int bnn_sketch_update_u32(const float* t, int64_t R, int64_t B, int32_t group, c
 int bnn_sketch_quantiles_f32(const uint32_t* hist, int64_t n_sims, const bnn_sketch* sk, const double* host_q, int32_t nq,
                              float* out, void* stream);
 
+/* Slab drivers (host loops over the kernels above; enqueue only, no synchronisation): the (systems x draws) grid of `grid`
+ * evaluated `draws_per_launch` draws at a time (a positive multiple of nchunks) through caller-provided scratch
+ *   W_workspace [draws_per_launch, d];  out_workspace [draws_per_launch/nchunks, B, 2]  resp.  t_workspace [draws_per_launch/nchunks, B]
+ * and reduced on the fly, so nothing of size J x B exists: the multi-GPU payloads of SURVEY.md section 8e.
+ *   bnn_multiswag_moments_f64: moments [B,4] float64 (overwritten) = sum mu, sum mu^2, sum std, sum std^2 over the output rows;
+ *   bnn_multiswag_bands_f32:   the quantile sketch (hist, mom; accumulated, zeroed by the caller) of the post-epilogue times
+ *                              (statistics fused in the forward tail, min over `group` consecutive systems); read it with
+ *                              bnn_sketch_quantiles_f32.  Philox noise only (the replay forms need explicit noise per call). */
+int bnn_multiswag_moments_f64(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg, const float* w2_avg,
+                              const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx, float scale, uint64_t philox_seed,
+                              int64_t draw_id0, int64_t system_id0, int32_t draws_per_launch, float* W_workspace,
+                              float* out_workspace, double* moments, void* stream);
+int bnn_multiswag_bands_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* w_avg, const float* w2_avg,
+                            const float* pre_D, int32_t S, int32_t K, const int32_t* seed_idx, float scale, uint64_t philox_seed,
+                            int64_t draw_id0, int64_t system_id0, int32_t draws_per_launch, float* W_workspace, float* t_workspace,
+                            const bnn_stats* st, int32_t group, const bnn_sketch* sk, uint32_t* hist, double* mom, void* stream);
+
 /* Raw Philox4x32-10 blocks for known-answer tests: out[n][4] = philox(ctr = {c0+i, c1, c2, c3}, key). */
 int bnn_philox_raw_u32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int64_t n,
                        uint32_t* out, void* stream);

@@ -166,3 +166,29 @@ def test_sharded_driver_bands_single_rank(ops, ens):
     assert torch.allclose(got[:, -1].double(), outs.mean(0), rtol=1e-6)
     with pytest.raises(ValueError):
         drv.predictive_quantiles(x[:-1], sims * 3, idx, trios=3)
+
+
+def test_native_slab_drivers(ops, ens):
+    """bnn_multiswag_moments_f64 / bnn_multiswag_bands_f32 (the slab loops inside the library) == the same slabs driven from
+    Python, for a dense grid and for chunked draws; empty inputs are no-ops."""
+    wa, w2, pd = ens
+    B, nch, samples = 999, 3, 40
+    J = samples * nch
+    x = synth(B, 4)
+    idx = torch.as_tensor((np.arange(J) % 2).astype(np.int32)).cuda()
+    mom = ops.multiswag_moments(x, wa, w2, pd, idx, nchunks=nch, philox_seed=5, draws_per_launch=33, system_id0=10)   # slabs of 33 -> 33 draws
+    want = ops.moments(ops.multiswag(x, wa, w2, pd, idx, nchunks=nch, philox_seed=5, system_id0=10))
+    assert torch.allclose(mom, want, rtol=1e-13, atol=0)
+    sk = ops.QuantileSketch(B, group=3)
+    ops.multiswag_bands(x, wa, w2, pd, idx, sk, nchunks=nch, philox_seed=5, draws_per_launch=30, system_id0=10)
+    sk2 = ops.QuantileSketch(B, group=3)
+    sk2.update(ops.multiswag_stats(x, wa, w2, pd, idx, nchunks=nch, philox_seed=5, system_id0=10))
+    assert torch.equal(sk.hist, sk2.hist) and sk.count == samples == sk2.count
+    assert torch.allclose(sk.mom, sk2.mom, rtol=1e-13, atol=0)
+    # empty shard / no draws
+    e = ops.multiswag_moments(x[:0], wa, w2, pd, idx, nchunks=nch, philox_seed=5)
+    assert e.shape == (0, 4)
+    z = ops.multiswag_moments(x, wa, w2, pd, idx[:0], philox_seed=5)
+    assert z.shape == (B, 4) and (z == 0).all()
+    with pytest.raises(ValueError):
+        ops.multiswag_bands(x, wa, w2, pd, idx, ops.QuantileSketch(B - 3, group=3))
