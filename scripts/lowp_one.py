@@ -1,5 +1,7 @@
+"""One forward of the 5-planet share in one arithmetic (f32 | bf16 | bf16x3 | bf16x6), for profiling runs (scripts/lowp_pmc.sh).
+   usage: python scripts/lowp_one.py [precision] [nchunks]"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 import bench
 from bnn_chaos_model_amd import ops

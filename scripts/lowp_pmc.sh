@@ -1,10 +1,11 @@
 #!/bin/bash
+# PMC passes (separate counter groups, kernel-trace only) over scripts/lowp_one.py: bash scripts/lowp_pmc.sh bf16 10
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_lowp; rm -rf $OUT; mkdir -p $OUT
 i=0
 for ctr in "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python3 scripts/dbg/lowp_one.py "$@" > $OUT/p$i.log 2> $OUT/p$i.err || echo "pass $i failed"
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python3 scripts/lowp_one.py "$@" > $OUT/p$i.log 2> $OUT/p$i.err || echo "pass $i failed"
 done
 python3 - <<'PY'
 import csv, glob, collections
