@@ -86,3 +86,24 @@ def test_lowp_is_invariant_to_sharding_and_refuses_what_it_does_not_build(ops, s
     from bnn_chaos_model_amd import _native as N
     with pytest.raises(N.NativeError):   # another column mask: not built
         ops.forward(x, W, precision="bf16", plan=ops.get_plan(zero_mask=1 << 7))
+
+
+@pytest.mark.parametrize("T", (8, 36))
+def test_other_series_lengths(ops, swag_states, T):
+    """T is a run-time size (a multiple of 4): the reduced-precision kernels agree with their emulation for short series too, and
+    with the fp32 path at fp32 level for the six-product form."""
+    from oracle import lowp
+    rng = np.random.default_rng(T)
+    B = 23
+    x = (rng.standard_normal((B, 1, 41)) + 0.1 * rng.standard_normal((B, T, 41))).astype(np.float32)
+    w = swag_states[12]["w_avg"]
+    eps = np.zeros((1, B, 2, 20), np.float32)
+    f32, _, s32 = ops.forward(dev(x), dev(w[None]), eps=dev(eps), debug=True)
+    for prec, ns, tol in (("bf16", 1, 3e-4), ("bf16x6", 3, 2e-5)):
+        out, _, summ = ops.forward(dev(x), dev(w[None]), eps=dev(eps), debug=True, precision=prec)
+        lat = lowp.feature_nn(x, w, ns)
+        want = lowp.pooled_summary(lat)
+        got = summ.cpu().numpy()[0].astype(np.float64)
+        scale = np.abs(want).max(1, keepdims=True)
+        assert (np.abs(got - want) <= tol * scale).all(), (prec, (np.abs(got - want) / scale).max())
+    assert (out - f32).abs().max() < 1e-4 and (summ - s32).abs().max() < 1e-4 * s32.abs().max()
