@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* flat = lds;            // [FLAT_LDS] flat parameter vector + zero slot, later ...
     float* f2frag = lds;          // ... [NF2][64] regress_nn operands in fragment order
-    float* scr = lds + FLAT_LDS;  // [4][SCR4]
+    float* scr = lds + FLAT_LDS;  // [4][SCRL] per-wave scratch: x-tile staging / Philox normals, summaries, the constant 1.0
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
