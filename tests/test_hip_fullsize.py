@@ -177,3 +177,30 @@ def test_configs2_sharding_and_launch_mode_invariance(full_c3):
     mom = o.moments(f["out"])
     want = f["out"][:, -1000:, 0].double().sum(0)
     assert torch.allclose(mom[-1000:, 0], want, rtol=1e-12, atol=0)
+
+
+def test_noisy_forward_oracle_spot_checks(full):
+    """forward(noisy_val=True) with every normal generated in-kernel, 10 000 systems x 64 draws: 48 (draw, system) pairs against
+    the CPU oracle fed the very normals the kernel generated (input noise: six normals per Philox block; pool and summary noise)."""
+    from oracle import oracle as orc
+    o, f = full["ops"], full
+    Jn = 64
+    W = o.swag_draw(f["wa"], f["w2"], f["pd"], f["idx"][:Jn], philox_seed=SEED + 2)
+    out = o.forward(f["x"], W, philox_seed=SEED + 2, draw_id0=5, system_id0=123_456, noisy=True)
+    assert out.shape == (Jn, B, 2) and torch.isfinite(out).all()
+    rng = np.random.default_rng(9)
+    draws = [0, Jn - 1] + rng.integers(1, Jn - 1, 4).tolist()
+    systems = [0, B - 1] + rng.integers(1, B - 1, 6).tolist()
+    plan = o.get_plan()
+    sched = orc.make_schedule([plan.layer_order(l, noisy=True) for l in range(6)], pool_parts=4)
+    Wc = W.cpu().numpy()
+    worst = 0.0
+    for j in draws:
+        for b in systems:
+            kw = dict(B=1, system_id0=123_456 + int(b))
+            eps = o.philox_normal(2, SEED + 2, 5 + int(j), 1, **kw).cpu().numpy()[0, 0]
+            e_in = o.philox_normal(3, SEED + 2, 5 + int(j), 1, width=100, **kw).cpu().numpy()[0]
+            e_sum = o.philox_normal(4, SEED + 2, 5 + int(j), 1, **kw).cpu().numpy()[0]
+            ref = orc.forward(f["x"][b:b + 1].cpu().numpy(), Wc[j], eps[0:1], eps[1:2], eps_in=e_in, eps_sum=e_sum, sched=sched)[0]
+            worst = max(worst, np.abs(out[j, b].cpu().numpy() - ref).max())
+    assert worst <= 2e-6, worst
