@@ -39,15 +39,17 @@ WORKLOADS = {
     "noisy": dict(systems=10_000, seeds=30, samples=10, noisy=True, name="f4: forward(noisy_val=True), 10k systems x 300 draws, in-kernel Philox noise"),
     # BASELINE.json configs[4], one GPU's share: 125 000 five-planet systems = 375 000 rows, 100 samples x 10 chunks, one random
     # ensemble member + one weight draw per chunk per sample (figures/multiswag_5_planet.py:295-298).  fp32 by default;
-    # --precision bf16 | bf16x3 | bf16x6 runs the OPT-IN reduced-precision forward (never the default, never the headline).
+    # --precision bf16 | bf16x3 | bf16x6 | f16 | f16x3 runs the OPT-IN reduced-precision forward (never the default, never the headline).
     "c5": dict(systems=375_000, seeds=30, samples=100, chunks=10, name="configs[4] share: 5-planet shapes, 375k rows x 100 samples x 10 chunks"),
     "tiny": dict(systems=512, seeds=30, samples=2, name="smoke-sized grid"),
 }
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 DTYPE_OF = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate (feature_nn); f32 elsewhere",
             "bf16x3": "split-bf16 x3 (16 significant bits), f32 accumulate (feature_nn); f32 elsewhere",
-            "bf16x6": "split-bf16 x6 (24 significant bits), f32 accumulate (feature_nn); f32 elsewhere"}
-PRODUCTS_OF = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6}
+            "bf16x6": "split-bf16 x6 (24 significant bits), f32 accumulate (feature_nn); f32 elsewhere",
+            "f16": "f16 operands, f32 accumulate (feature_nn); f32 elsewhere",
+            "f16x3": "split-f16 x3 (22 significant bits), f32 accumulate (feature_nn); f32 elsewhere"}
+PRODUCTS_OF = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16": 1, "f16x3": 3}
 
 
 def synthetic_x(B, device, seed):

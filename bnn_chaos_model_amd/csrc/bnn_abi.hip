@@ -622,7 +622,7 @@ int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, 
 int bnn_forward_lowp_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps, uint64_t philox_seed,
                          int64_t draw_id0, int64_t system_id0, int32_t precision, float* out, float* pre_clamp, float* summary, void* stream) {
     if (!plan || !grid) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
-    if (precision < BNN_PREC_BF16 || precision > BNN_PREC_BF16X6) return fail(BNN_ERR_INVALID, "precision must be BNN_PREC_BF16, _BF16X3 or _BF16X6");
+    if (precision < BNN_PREC_BF16 || precision > BNN_PREC_F16X3) return fail(BNN_ERR_INVALID, "precision must be one of BNN_PREC_BF16 .. BNN_PREC_F16X3");
     if (plan->tab[0].kin4 != 31) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels are built for the v50 column mask only");
     if (grid->noisy) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels have no noisy form");
     if (grid->B == 0 || grid->J == 0) return 0;

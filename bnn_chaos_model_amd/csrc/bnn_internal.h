@@ -67,7 +67,7 @@ hipError_t launch_fwd_k31(bool fused, unsigned nblk, hipStream_t st, const FwdPa
 hipError_t launch_fwd_k41(bool fused, unsigned nblk, hipStream_t st, const FwdParams& p);
 hipError_t launch_fwd_noisy(unsigned nblk, hipStream_t st, const FwdParams& p);
 hipError_t launch_fwd_stats(bool k31, unsigned nblk, hipStream_t st, const FwdParams& p);  // quiet forward + fused statistics tail
-hipError_t launch_fwd_lowp(int nsplit, unsigned nblk, hipStream_t st, const FwdParams& p);  // bf16 matrix pipe, 1 / 2 / 3 operand parts
+hipError_t launch_fwd_lowp(int precision, unsigned nblk, hipStream_t st, const FwdParams& p);  // bf16 / half matrix pipe (bnn_precision)
 
 constexpr int MAX_DEVICES = 64;
 inline int current_device_slot() {

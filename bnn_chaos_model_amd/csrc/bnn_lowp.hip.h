@@ -30,25 +30,40 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// {bf16(b), bf16(a)}: a in the low half; round to nearest even.  A vector conversion, NOT inline asm: hipcc emits one
-// v_cvt_pk_bf16_f32 for it and -- unlike for an asm statement -- inserts the wait states a following MFMA needs before it reads
-// the result (with the asm form the MFMAs read stale operands: NaNs).
-DEVINL uint32_t cvt_pk_bf16(float a, float b) {
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// Element type of the matrix operands: H = false bfloat16 (8 significant bits, fp32's exponent range), H = true IEEE half (11
+// significant bits, |v| < 65 504: values beyond that become inf).  Packing: {elem(b), elem(a)}, a in the low half, round to nearest
+// even.  A vector conversion, NOT inline asm: hipcc emits one v_cvt_pk_* for it and -- unlike for an asm statement -- inserts the
+// wait states a following MFMA needs before it reads the result (with the asm form the MFMAs read stale operands: NaNs).
+template <bool H>
+DEVINL uint32_t cvt_pk(float a, float b) {
     const f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    if constexpr (H) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
-DEVINL float bf16_lo_as_f32(uint32_t pk) { return __builtin_bit_cast(float, pk << 16); }
-DEVINL float bf16_hi_as_f32(uint32_t pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+template <bool H>
+DEVINL float lo_as_f32(uint32_t pk) {
+    if constexpr (H) return (float)__builtin_bit_cast(f16x2, pk).x;
+    else return __builtin_bit_cast(float, pk << 16);
+}
+template <bool H>
+DEVINL float hi_as_f32(uint32_t pk) {
+    if constexpr (H) return (float)__builtin_bit_cast(f16x2, pk).y;
+    else return __builtin_bit_cast(float, pk & 0xffff0000u);
+}
+template <bool H>
+constexpr uint32_t ONE_LO = H ? 0x00003C00u : 0x00003F80u;  // {0, 1.0}: the constant 1.0 of a bias slot in the low half
 
 // (a, b) -> NS packed parts; part p holds bf16 of what is left after parts < p (the subtractions are exact in fp32)
-template <int NS>
+template <int NS, bool H>
 DEVINL void split_pair(float a, float b, uint32_t (&out)[NS]) {
 #pragma unroll
     for (int p = 0; p < NS; ++p) {
-        out[p] = cvt_pk_bf16(a, b);
+        out[p] = cvt_pk<H>(a, b);
         if (p + 1 < NS) {
-            a = a - bf16_lo_as_f32(out[p]);
-            b = b - bf16_hi_as_f32(out[p]);
+            a = a - lo_as_f32<H>(out[p]);
+            b = b - hi_as_f32<H>(out[p]);
         }
     }
 }
@@ -58,17 +73,19 @@ struct Frag {  // one k-step of one operand: NS parts of 8 bf16
     u32x4 part[NS];
 };
 
-DEVINL f32x4 mfma_bf16(const u32x4& a, const u32x4& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+template <bool H>
+DEVINL f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c) {
+    if constexpr (H) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // sum over the products of order <= NS - 1, smallest terms first
-template <int NS>
+template <int NS, bool H>
 DEVINL f32x4 mfma_split(const Frag<NS>& a, const Frag<NS>& b, f32x4 c) {
 #pragma unroll
     for (int ord = NS - 1; ord >= 0; --ord)
 #pragma unroll
-        for (int i = 0; i <= ord; ++i) c = mfma_bf16(a.part[i], b.part[ord - i], c);
+        for (int i = 0; i <= ord; ++i) c = mfma16<H>(a.part[i], b.part[ord - i], c);
     return c;
 }
 
@@ -95,13 +112,13 @@ DEVINL int lowp_widx(int layer, int mt, int s, int g, int m, int j) {
     return off_w + n * H + k;
 }
 
-template <int NS>
+template <int NS, bool H>
 DEVINL Frag<NS> lowp_wfrag(const float* flat, int layer, int mt, int s, int g, int m) {
     Frag<NS> f;
 #pragma unroll
     for (int jp = 0; jp < 4; ++jp) {
         uint32_t pk[NS];
-        split_pair<NS>(flat[lowp_widx(layer, mt, s, g, m, 2 * jp)], flat[lowp_widx(layer, mt, s, g, m, 2 * jp + 1)], pk);
+        split_pair<NS, H>(flat[lowp_widx(layer, mt, s, g, m, 2 * jp)], flat[lowp_widx(layer, mt, s, g, m, 2 * jp + 1)], pk);
 #pragma unroll
         for (int p = 0; p < NS; ++p) f.part[p][jp] = pk[p];
     }
@@ -109,41 +126,41 @@ DEVINL Frag<NS> lowp_wfrag(const float* flat, int layer, int mt, int s, int g, i
 }
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-DEVINL uint32_t relu_pk_bf16(uint32_t pk) {  // ReLU on two packed bf16: one v_pk_max_i16 (negative floats are negative int16s)
+DEVINL uint32_t relu_pk16(uint32_t pk) {  // ReLU on two packed bf16 / half: one v_pk_max_i16 (negative floats are negative int16s)
     const s16x2 z = {0, 0};
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), z));
 }
 
 // ReLU + split of a layer's three accumulator tiles into the next layer's two B k-steps
-template <int NS>
+template <int NS, bool H>
 DEVINL void lowp_next_operand(const f32x4 (&acc)[3], Frag<NS>& b0, Frag<NS>& b1) {
     if constexpr (NS == 1) {  // round first, then ReLU on the packed pairs: bf16(relu(v)) == relu(bf16(v)), half the instructions
-        b0.part[0][0] = relu_pk_bf16(cvt_pk_bf16(acc[0][0], acc[0][1]));
-        b0.part[0][1] = relu_pk_bf16(cvt_pk_bf16(acc[0][2], acc[0][3]));
-        b0.part[0][2] = relu_pk_bf16(cvt_pk_bf16(acc[1][0], acc[1][1]));
-        b0.part[0][3] = relu_pk_bf16(cvt_pk_bf16(acc[1][2], acc[1][3]));
-        b1.part[0][0] = relu_pk_bf16(cvt_pk_bf16(acc[2][0], acc[2][1]));
-        b1.part[0][1] = relu_pk_bf16(cvt_pk_bf16(acc[2][2], acc[2][3]));
+        b0.part[0][0] = relu_pk16(cvt_pk<H>(acc[0][0], acc[0][1]));
+        b0.part[0][1] = relu_pk16(cvt_pk<H>(acc[0][2], acc[0][3]));
+        b0.part[0][2] = relu_pk16(cvt_pk<H>(acc[1][0], acc[1][1]));
+        b0.part[0][3] = relu_pk16(cvt_pk<H>(acc[1][2], acc[1][3]));
+        b1.part[0][0] = relu_pk16(cvt_pk<H>(acc[2][0], acc[2][1]));
+        b1.part[0][1] = relu_pk16(cvt_pk<H>(acc[2][2], acc[2][3]));
         return;  // elements 4..7 of b1 (the constant 1.0 of the bias slot, zeros) are set once by the caller
     }
     f32x4 t0 = relu4(acc[0]), t1 = relu4(acc[1]), t2 = relu4(acc[2]);
     uint32_t pk[NS];
-    split_pair<NS>(t0[0], t0[1], pk);
+    split_pair<NS, H>(t0[0], t0[1], pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b0.part[p][0] = pk[p];
-    split_pair<NS>(t0[2], t0[3], pk);
+    split_pair<NS, H>(t0[2], t0[3], pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b0.part[p][1] = pk[p];
-    split_pair<NS>(t1[0], t1[1], pk);
+    split_pair<NS, H>(t1[0], t1[1], pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b0.part[p][2] = pk[p];
-    split_pair<NS>(t1[2], t1[3], pk);
+    split_pair<NS, H>(t1[2], t1[3], pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b0.part[p][3] = pk[p];
-    split_pair<NS>(t2[0], t2[1], pk);
+    split_pair<NS, H>(t2[0], t2[1], pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b1.part[p][0] = pk[p];
-    split_pair<NS>(t2[2], t2[3], pk);
+    split_pair<NS, H>(t2[2], t2[3], pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b1.part[p][1] = pk[p];
 }
@@ -154,7 +171,7 @@ constexpr int XST = 4 * 4 * F;                     // 656 floats, a multiple of 
 constexpr int SCRL = XST + 16 * S2 + 4;            // + one float that holds the constant 1.0 of the bias slot (padded to 16 B)
 constexpr size_t lowp_lds_bytes() { return sizeof(float) * (FLAT_LDS + 4 * SCRL); }
 
-template <int NS>
+template <int NS, bool H>
 __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* flat = lds;            // [FLAT_LDS] flat parameter vector + zero slot, later ...
@@ -186,15 +203,15 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
     // feature_nn weights -> bf16 parts in registers (every wave builds its own copy)
     Frag<NS> A1[3], A2[3][2], A3[2][2];
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) A1[mt] = lowp_wfrag<NS>(flat, 0, mt, 0, g, c);
+    for (int mt = 0; mt < 3; ++mt) A1[mt] = lowp_wfrag<NS, H>(flat, 0, mt, 0, g, c);
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) A2[mt][s] = lowp_wfrag<NS>(flat, 1, mt, s, g, c);
+        for (int s = 0; s < 2; ++s) A2[mt][s] = lowp_wfrag<NS, H>(flat, 1, mt, s, g, c);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) A3[mt][s] = lowp_wfrag<NS>(flat, 2, mt, s, g, c);
+        for (int s = 0; s < 2; ++s) A3[mt][s] = lowp_wfrag<NS, H>(flat, 2, mt, s, g, c);
     {   // regress_nn operands (exact fp32) replace the flat vector in place
         constexpr int PER = (NF2 + 3) / 4;
         int idx[PER];
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
             Frag<NS> Bs0, Bs1;  // B operands of layers 2 and 3; the constant half of Bs1 (bias slot, padding) is written once
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                Bs1.part[q][2] = q == 0 ? 0x00003F80u : 0u;  // element 4 = bf16(1.0), element 5 = 0
+                Bs1.part[q][2] = q == 0 ? ONE_LO<H> : 0u;  // element 4 = 1.0, element 5 = 0
                 Bs1.part[q][3] = 0u;
             }
             // one tile: LDS holds tile `it`; P holds tile it+1, R is free (gets tile it+3); at the end P goes to LDS
@@ -303,34 +320,34 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
                     for (int j = 0; j < 6; ++j) v[j] = fr[8 + 8 * g + j];
                     const float v6 = *fr6, v7 = *fr7;
                     uint32_t pk[NS];
-                    split_pair<NS>(v[0], v[1], pk);
+                    split_pair<NS, H>(v[0], v[1], pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][0] = pk[q];
-                    split_pair<NS>(v[2], v[3], pk);
+                    split_pair<NS, H>(v[2], v[3], pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][1] = pk[q];
-                    split_pair<NS>(v[4], v[5], pk);
+                    split_pair<NS, H>(v[4], v[5], pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][2] = pk[q];
-                    split_pair<NS>(v6, v7, pk);
+                    split_pair<NS, H>(v6, v7, pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][3] = pk[q];
                 }
                 fetch(it + DEPTH, R);  // DEPTH tiles ahead: in flight while this tile (and the next two) compute
                 f32x4 acc[3];
 #pragma unroll
-                for (int mt = 0; mt < 3; ++mt) acc[mt] = mfma_split<NS>(A1[mt], B1, (f32x4){0, 0, 0, 0});
-                lowp_next_operand<NS>(acc, Bs0, Bs1);
+                for (int mt = 0; mt < 3; ++mt) acc[mt] = mfma_split<NS, H>(A1[mt], B1, (f32x4){0, 0, 0, 0});
+                lowp_next_operand<NS, H>(acc, Bs0, Bs1);
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) {
-                    acc[mt] = mfma_split<NS>(A2[mt][0], Bs0, (f32x4){0, 0, 0, 0});
-                    acc[mt] = mfma_split<NS>(A2[mt][1], Bs1, acc[mt]);
+                    acc[mt] = mfma_split<NS, H>(A2[mt][0], Bs0, (f32x4){0, 0, 0, 0});
+                    acc[mt] = mfma_split<NS, H>(A2[mt][1], Bs1, acc[mt]);
                 }
-                lowp_next_operand<NS>(acc, Bs0, Bs1);
-                f32x4 y0 = mfma_split<NS>(A3[0][0], Bs0, (f32x4){0, 0, 0, 0});
-                y0 = mfma_split<NS>(A3[0][1], Bs1, y0);
-                f32x4 y1 = mfma_split<NS>(A3[1][0], Bs0, (f32x4){0, 0, 0, 0});
-                y1 = mfma_split<NS>(A3[1][1], Bs1, y1);
+                lowp_next_operand<NS, H>(acc, Bs0, Bs1);
+                f32x4 y0 = mfma_split<NS, H>(A3[0][0], Bs0, (f32x4){0, 0, 0, 0});
+                y0 = mfma_split<NS, H>(A3[0][1], Bs1, y0);
+                f32x4 y1 = mfma_split<NS, H>(A3[1][0], Bs0, (f32x4){0, 0, 0, 0});
+                y1 = mfma_split<NS, H>(A3[1][1], Bs1, y1);
                 // torch.mean / torch.std over time (:418-419).  y0[r] = neuron 4g + r, y1[r] = neuron 16 + 4g + r (a real neuron
                 // only for g = 0).  NS >= 2: Welford over this lane's timesteps, as in the fp32 kernel.  NS = 1: plain sums of y and
                 // y^2 (half the instructions; their fp32 cancellation error, ~1e-5 relative on the variance, is far below bf16's own).
@@ -479,16 +496,16 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
     }
 }
 
-template <int NS>
+template <int NS, bool H>
 inline hipError_t launch_lowp_form(unsigned nblk, hipStream_t st, const FwdParams& p) {
     static bool attr_set[MAX_DEVICES];
     const int slot = current_device_slot();
     if (!attr_set[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_lowp_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_lowp_kernel<NS, H>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr_set[slot] = true;
     }
-    hipLaunchKernelGGL((bnn_forward_lowp_kernel<NS>), dim3(nblk), dim3(256), lowp_lds_bytes(), st, p);
+    hipLaunchKernelGGL((bnn_forward_lowp_kernel<NS, H>), dim3(nblk), dim3(256), lowp_lds_bytes(), st, p);
     return hipGetLastError();
 }
 

@@ -90,7 +90,7 @@ def swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, scale=0.5, philo
     return W
 
 
-PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16": 4, "f16x3": 5}
 
 
 @_on_device_of(0)
@@ -101,8 +101,8 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     eps [R,B,2,20] = the two randn_like of compute_summary_stats (:426-427) or None (Philox);
     eps_in [R,B,T,41] + eps_sum [R,B,40] switch on noisy_val=True (:444-450); noisy=True with no noise tensors at all
     is noisy_val=True with every normal generated in-kernel (Philox).
-    precision: "f32" (default: the parity path) or the OPT-IN reduced-precision forms "bf16" / "bf16x3" / "bf16x6"
-    (feature_nn on the bf16 matrix pipe; BASELINE configs[4] sweep; v50 mask, quiet forward only)."""
+    precision: "f32" (default: the parity path) or the OPT-IN reduced-precision forms "bf16" / "bf16x3" / "bf16x6" / "f16" /
+    "f16x3" (feature_nn on the bf16 / half matrix pipe; BASELINE configs[4] sweep; v50 mask, quiet forward only)."""
     plan = plan or get_plan()
     x, W = _f32(x, "x"), _f32(W, "W")
     if x.dim() != 3 or x.shape[2] != 41:

@@ -117,8 +117,10 @@ int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, 
  * bnn_forward_f32, so outputs are comparable element by element.  v50 column mask only, no noisy form.
  *   BNN_PREC_BF16    x, weights, activations rounded to bf16, 1 product per layer    (|d mu| up to ~1e-1: NOT within the 1e-5 bar)
  *   BNN_PREC_BF16X3  operands split into hi + lo bf16 (16 significant bits), 3 products
- *   BNN_PREC_BF16X6  three bf16 parts (24 bits), the 6 products of order <= 2: fp32-level error, not bit-reproducible vs fp32 */
-enum bnn_precision { BNN_PREC_F32 = 0, BNN_PREC_BF16 = 1, BNN_PREC_BF16X3 = 2, BNN_PREC_BF16X6 = 3 };
+ *   BNN_PREC_BF16X6  three bf16 parts (24 bits), the 6 products of order <= 2: fp32-level error, not bit-reproducible vs fp32
+ *   BNN_PREC_F16     IEEE half operands (11 significant bits), 1 product; operands must stay below 65 504 in magnitude
+ *   BNN_PREC_F16X3   half operands split hi + lo (22 significant bits), 3 products: close to fp32 at the cost of bf16x3 */
+enum bnn_precision { BNN_PREC_F32 = 0, BNN_PREC_BF16 = 1, BNN_PREC_BF16X3 = 2, BNN_PREC_BF16X6 = 3, BNN_PREC_F16 = 4, BNN_PREC_F16X3 = 5 };
 int bnn_forward_lowp_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps,
                          uint64_t philox_seed, int64_t draw_id0, int64_t system_id0, int32_t precision, float* out,
                          float* pre_clamp, float* summary, void* stream);

@@ -25,7 +25,7 @@ J = args.samples * args.chunks
 idx = torch.as_tensor(np.random.default_rng(0).integers(0, 30, J).astype(np.int32)).to(dev)
 W = ops.swag_draw(wa, w2, pd, idx, philox_seed=7)
 ref = None
-for prec in ("f32", "bf16x6", "bf16x3", "bf16"):
+for prec in ("f32", "bf16x6", "f16x3", "bf16x3", "f16", "bf16"):
     for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = ops.forward(x, W, nchunks=args.chunks, philox_seed=7, precision=prec)

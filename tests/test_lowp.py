@@ -21,8 +21,11 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("prec,ns,tol", (("bf16", 1, 2e-4), ("bf16x3", 2, 2e-5), ("bf16x6", 3, 2e-5)))
-def test_pooled_summary_matches_the_emulation(ops, inputs, prec, ns, tol):
+FORMS = {"bf16": (1, "bf16"), "bf16x3": (2, "bf16"), "bf16x6": (3, "bf16"), "f16": (1, "f16"), "f16x3": (2, "f16")}
+
+
+@pytest.mark.parametrize("prec,tol", (("bf16", 2e-4), ("bf16x3", 2e-5), ("bf16x6", 2e-5), ("f16", 1e-4), ("f16x3", 2e-5)))
+def test_pooled_summary_matches_the_emulation(ops, inputs, prec, tol):
     """With the two pool-noise draws set to zero the kernel's summary is [time mean | sqrt(var + 1e-5)] of the latents: compare
     with the float64 emulation of the same operand splitting.  What is left is fp32 accumulation inside the matrix pipe and in
     the pool (Welford), orders of magnitude below the effect of the splitting itself for bf16."""
@@ -32,7 +35,8 @@ def test_pooled_summary_matches_the_emulation(ops, inputs, prec, ns, tol):
     B = x.shape[0]
     eps = np.zeros((1, B, 2, 20), np.float32)
     out, pre, summ = ops.forward(dev(x), dev(z["w"][None]), eps=dev(eps), debug=True, precision=prec)
-    want = lowp.pooled_summary(lowp.feature_nn(x, z["w"], ns))
+    ns, fmt = FORMS[prec]
+    want = lowp.pooled_summary(lowp.feature_nn(x, z["w"], ns, fmt))
     got = summ.cpu().numpy()[0].astype(np.float64)
     scale = np.abs(want).max(1, keepdims=True)
     assert (np.abs(got - want) <= tol * scale).all(), (np.abs(got - want) / scale).max()
@@ -50,7 +54,7 @@ def test_precision_sweep_against_fp32_and_reference(ops, inputs, swag_states, ca
     eps = np.stack([tp[2][1], tp[3][1]], axis=1)[None]
     f32 = ops.forward(dev(x), dev(z["w"][None]), eps=dev(eps)).cpu().numpy()[0].astype(np.float64)
     rows = {}
-    for prec in ("bf16", "bf16x3", "bf16x6"):
+    for prec in FORMS:
         o = ops.forward(dev(x), dev(z["w"][None]), eps=dev(eps), precision=prec).cpu().numpy()[0].astype(np.float64)
         d = np.abs(o - f32)
         rel_ref = (np.abs(o - z["out"]) / np.abs(z["out"])).max()
@@ -61,6 +65,8 @@ def test_precision_sweep_against_fp32_and_reference(ops, inputs, swag_states, ca
     assert 1e-4 < rows["bf16"][0] < 1.0            # plain bf16: three to four orders of magnitude above the parity bar
     assert rows["bf16x3"][0] < rows["bf16"][0] / 20  # 16 significant bits
     assert rows["bf16x6"][0] < 2e-5 and rows["bf16x6"][3] < 1e-5   # 24 bits: fp32-level error; within the bar on this fixture
+    assert rows["f16"][0] < rows["bf16"][0] / 3                    # 11 significant bits against 8
+    assert rows["f16x3"][0] < rows["bf16x3"][0] / 8 and rows["f16x3"][0] < 5e-5   # 22 bits: close to fp32 at the cost of bf16x3
 
 
 def test_lowp_is_invariant_to_sharding_and_refuses_what_it_does_not_build(ops, swag_states):
@@ -70,14 +76,14 @@ def test_lowp_is_invariant_to_sharding_and_refuses_what_it_does_not_build(ops, s
     pd = dev(np.stack([swag_states[0]["pre_D"], swag_states[12]["pre_D"]]))
     x = bench.synthetic_x(700, torch.device("cuda"), 5)
     idx = torch.as_tensor((np.arange(20) % 2).astype(np.int32))
-    for prec in ("bf16", "bf16x3", "bf16x6"):
+    for prec in FORMS:
         a = ops.multiswag(x, wa, w2, pd, idx, nchunks=10, philox_seed=3, system_id0=1000, precision=prec)
         assert a.shape == (2, 700, 2) and torch.isfinite(a).all()
         full = ops.multiswag(x, wa, w2, pd, idx, philox_seed=3, system_id0=1000, precision=prec)
         part = ops.multiswag(x[333:].contiguous(), wa, w2, pd, idx, philox_seed=3, system_id0=1333, precision=prec)
         assert torch.equal(part, full[:, 333:])
         f32 = ops.multiswag(x, wa, w2, pd, idx, philox_seed=3, system_id0=1000)
-        assert (full - f32).abs().max() < (1.0 if prec == "bf16" else 0.05)
+        assert (full - f32).abs().max() < (1.0 if prec in ("bf16", "f16") else 0.05)
     W = ops.swag_draw(wa, w2, pd, idx, philox_seed=3)
     with pytest.raises(NotImplementedError):
         ops.forward(x, W, noisy=True, precision="bf16")
@@ -99,9 +105,10 @@ def test_other_series_lengths(ops, swag_states, T):
     w = swag_states[12]["w_avg"]
     eps = np.zeros((1, B, 2, 20), np.float32)
     f32, _, s32 = ops.forward(dev(x), dev(w[None]), eps=dev(eps), debug=True)
-    for prec, ns, tol in (("bf16", 1, 3e-4), ("bf16x6", 3, 2e-5)):
+    for prec, tol in (("bf16", 3e-4), ("f16x3", 2e-5), ("bf16x6", 2e-5)):
         out, _, summ = ops.forward(dev(x), dev(w[None]), eps=dev(eps), debug=True, precision=prec)
-        lat = lowp.feature_nn(x, w, ns)
+        ns, fmt = FORMS[prec]
+        lat = lowp.feature_nn(x, w, ns, fmt)
         want = lowp.pooled_summary(lat)
         got = summ.cpu().numpy()[0].astype(np.float64)
         scale = np.abs(want).max(1, keepdims=True)
