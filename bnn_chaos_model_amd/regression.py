@@ -98,7 +98,7 @@ class FeatureRegressor(object):
         return self._stacked
 
     def sample_full_swag_many(self, X, samples, chunks=1, rng="torch", philox_seed=0, draw_id0=0, system_id0=0,
-                              scale=0.5, out=None):
+                              scale=0.5, out=None, precision="f32"):
         """The whole MC loop in one launch:
 
             torch.cat([torch.cat([self.sample_full_swag(Xpart) for Xpart in torch.chunk(X, chunks)])[None]
@@ -106,7 +106,9 @@ class FeatureRegressor(object):
 
         -> [samples, B, 2].  rng="torch" consumes numpy's and torch's global generators exactly as that loop does
         (one randint + randn((1,d)) + randn((K,1)) + 2 randn_like([Bc,20]) per chunk per sample);
-        rng="philox" draws the seed picks from numpy and everything else in-kernel."""
+        rng="philox" draws the seed picks from numpy and everything else in-kernel.
+        precision: "f32" (the parity path) or an OPT-IN reduced-precision form of ops.forward ("f16x3": fp32-level error at ~1.9x
+        the throughput; "bf16", "f16", ...: approximate) -- DESIGN.md section 4.6."""
         if X.dim() != 3 or X.shape[-1] != 41:
             raise NotImplementedError("X must be [B, T, 41]")
         g = _gpu()
@@ -140,12 +142,12 @@ class FeatureRegressor(object):
                 eps[s_, lo:lo + n, 0] = torch.randn(n, 20, device=X.device)         # :426
                 eps[s_, lo:lo + n, 1] = torch.randn(n, 20, device=X.device)         # :427
             res = ops.multiswag(xg, wa, w2, pd, torch.as_tensor(seed_idx), z1.to(g).contiguous(), z2.to(g).contiguous(),
-                                eps.to(g).contiguous(), nchunks=nch, scale=scale, plan=plan, out=out)
+                                eps.to(g).contiguous(), nchunks=nch, scale=scale, plan=plan, out=out, precision=precision)
         elif rng == "philox":
             for e in range(J):
                 seed_idx[e] = np.random.randint(0, S)
             res = ops.multiswag(xg, wa, w2, pd, torch.as_tensor(seed_idx), nchunks=nch, scale=scale, philox_seed=philox_seed,
-                                draw_id0=draw_id0, system_id0=system_id0, plan=plan, out=out)
+                                draw_id0=draw_id0, system_id0=system_id0, plan=plan, out=out, precision=precision)
         else:
             raise ValueError("rng must be 'torch' or 'philox'")
         return res if out is not None else res.to(X.device)

@@ -114,3 +114,23 @@ def test_other_series_lengths(ops, swag_states, T):
         scale = np.abs(want).max(1, keepdims=True)
         assert (np.abs(got - want) <= tol * scale).all(), (prec, (np.abs(got - want) / scale).max())
     assert (out - f32).abs().max() < 1e-4 and (summ - s32).abs().max() < 1e-4 * s32.abs().max()
+
+
+def test_surface_passes_precision_through(swag_states, tmp_path, inputs):
+    """FeatureRegressor.sample_full_swag_many(precision=...) is ops.multiswag(precision=...): f16x3 stays at fp32 level on the
+    5-planet loop shape, with the reference's RNG consumption."""
+    import json
+    from bnn_chaos_model_amd import checkpoint
+    from bnn_chaos_model_amd.regression import FeatureRegressor
+    for i in (0, 12):
+        z = load_golden(f"swag_v50_{i}.npz")
+        checkpoint.write_swag_file(str(tmp_path / f"s_v50_{i:02d}_output.pkl"), json.loads(str(z["hparams_json"])), json.loads(str(z["swa_params_json"])),
+                                   torch.tensor(z["w_avg"]), torch.tensor(z["w2_avg"]), torch.tensor(z["pre_D"]))
+    fr = FeatureRegressor(cuda=False, filebase=str(tmp_path / "*v50*output.pkl"), sort=True)
+    x = torch.tensor(inputs["slow"][:30])
+    outs = {}
+    for prec in ("f32", "f16x3", "bf16"):
+        np.random.seed(1); torch.manual_seed(1)
+        outs[prec] = fr.sample_full_swag_many(x, samples=4, chunks=10, precision=prec)
+    assert (outs["f16x3"] - outs["f32"]).abs().max() < 2e-5
+    assert 1e-5 < (outs["bf16"] - outs["f32"]).abs().max() < 1.0
