@@ -174,6 +174,12 @@ constexpr size_t lowp_lds_bytes() { return sizeof(float) * (FLAT_LDS + 4 * SCRL)
 template <int NS, bool H>
 __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if constexpr (H) {
+        // MODE.FP16_OVFL = 1: conversions to half saturate at +-65 504 instead of producing inf (hwreg MODE = id 1, bit 23, 1 bit).
+        // Values out of half's range are then WRONG but finite -- e.g. the scripts' constant-4 fill of unstable systems
+        // (figures/multiswag_5_planet.py:215) standardises the three mass columns to 1.9e5; their outputs are discarded there.
+        __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);
+    }
     float* flat = lds;            // [FLAT_LDS] flat parameter vector + zero slot, later ...
     float* f2frag = lds;          // ... [NF2][64] regress_nn operands in fragment order
     float* scr = lds + FLAT_LDS;  // [4][SCRL] per-wave scratch: x-tile staging / Philox normals, summaries, the constant 1.0

@@ -119,6 +119,7 @@ int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, 
  *   BNN_PREC_BF16X3  operands split into hi + lo bf16 (16 significant bits), 3 products
  *   BNN_PREC_BF16X6  three bf16 parts (24 bits), the 6 products of order <= 2: fp32-level error, not bit-reproducible vs fp32
  *   BNN_PREC_F16     IEEE half operands (11 significant bits), 1 product; operands must stay below 65 504 in magnitude
+ *                    (larger values saturate: finite but wrong; e.g. the scripts' constant-4 fill of unstable systems)
  *   BNN_PREC_F16X3   half operands split hi + lo (22 significant bits), 3 products: close to fp32 at the cost of bf16x3 */
 enum bnn_precision { BNN_PREC_F32 = 0, BNN_PREC_BF16 = 1, BNN_PREC_BF16X3 = 2, BNN_PREC_BF16X6 = 3, BNN_PREC_F16 = 4, BNN_PREC_F16X3 = 5 };
 int bnn_forward_lowp_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps,

@@ -134,3 +134,19 @@ def test_surface_passes_precision_through(swag_states, tmp_path, inputs):
         outs[prec] = fr.sample_full_swag_many(x, samples=4, chunks=10, precision=prec)
     assert (outs["f16x3"] - outs["f32"]).abs().max() < 2e-5
     assert 1e-5 < (outs["bf16"] - outs["f32"]).abs().max() < 1.0
+
+
+def test_half_forms_saturate_out_of_range_inputs(ops, inputs):
+    """IEEE half has no exponent headroom: the scripts' constant-4 fill of unstable systems standardises the mass columns to
+    1.9e5 > 65 504.  The half forms then saturate (MODE.FP16_OVFL: finite, but wrong -- those rows' outputs are discarded by the
+    script); the bfloat16 forms keep fp32's range and stay accurate on the same input."""
+    z = load_golden("case_swagfast_v50_0_const4.npz")
+    tp = tape(z)
+    x = inputs["const4"]
+    assert np.abs(x).max() > 65504
+    eps = np.stack([tp[2][1], tp[3][1]], axis=1)[None]
+    for prec in ("f16", "f16x3"):
+        o = ops.forward(dev(x), dev(z["w"][None]), eps=dev(eps), precision=prec)
+        assert torch.isfinite(o).all()
+    o = ops.forward(dev(x), dev(z["w"][None]), eps=dev(eps), precision="bf16x6").cpu().numpy()[0]
+    assert (np.abs(o - z["out"]) <= 1e-5 * np.abs(z["out"])).all()
