@@ -6,7 +6,14 @@ One "step" = one pass of the hot path over one batch: every system of the batch 
 the timed region.  Default workload = BASELINE.json configs[2], the largest single-GPU configuration:
 1 000 000 systems x 100 MC samples (x = 16.4 GB, far beyond the 256 MiB Infinity Cache).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|noisy|tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5|noisy|tiny]
+
+  c3 (default)  configs[2]: 1M systems x 100 samples per GPU, samples kept, moments gathered
+  c4            configs[3], one GPU's share: 1.25M systems x 3000 draws (30 seeds x 100) through the native slab driver
+                (bnn_multiswag_moments_f64: 250 draws per launch, float64 moments), then the ONE all-gather of moments
+  c5            configs[4], one GPU's share: 125 000 five-planet systems = 375 000 rows x 100 samples x 10 chunks; under --gpus N the
+                shards are WHOLE simulations (3 trios each), every rank reduces its samples to per-simulation bands and the bands
+                are gathered
 
 --gpus N > 1 from a plain invocation launches N rank processes itself (a torch.distributed.run child, started BEFORE this
 process touches the GPU); under torch.distributed.run (WORLD_SIZE set) it is a rank.  One rank per GPU over RCCL: systems
@@ -40,7 +47,12 @@ WORKLOADS = {
     # BASELINE.json configs[4], one GPU's share: 125 000 five-planet systems = 375 000 rows, 100 samples x 10 chunks, one random
     # ensemble member + one weight draw per chunk per sample (figures/multiswag_5_planet.py:295-298).  fp32 by default;
     # --precision bf16 | bf16x3 | bf16x6 | f16 | f16x3 runs the OPT-IN reduced-precision forward (never the default, never the headline).
-    "c5": dict(systems=375_000, seeds=30, samples=100, chunks=10, name="configs[4] share: 5-planet shapes, 375k rows x 100 samples x 10 chunks"),
+    "c5": dict(systems=375_000, seeds=30, samples=100, chunks=10, trios=3, steps=10, warmup=2,
+               name="configs[4] share: 5-planet shapes, 125k simulations x 3 trios = 375k rows x 100 samples x 10 chunks -> bands per simulation"),
+    # BASELINE.json configs[3], one GPU's share: 10M systems / 8 = 1.25M systems (x = 20.5 GB) x 30 seeds x 100 samples = 3000 draws,
+    # reduced to float64 predictive moments slab by slab (distributed.MultiSwagSharded.local_moments -> bnn_multiswag_moments_f64)
+    "c4": dict(systems=1_250_000, seeds=30, samples=100, slab=250, steps=3, warmup=1,
+               name="configs[3] share: 1.25M systems x 30 seeds x 100 samples (3000 draws in slabs of 250) -> float64 moments, all-gather"),
     "tiny": dict(systems=512, seeds=30, samples=2, name="smoke-sized grid"),
 }
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
@@ -212,8 +224,8 @@ def launch_ranks(n, argv):
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 10; 3 for c4, whose step is ~23 s)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 2; 1 for c4)")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--systems", type=int, default=0, help="systems per GPU (overrides the workload)")
     ap.add_argument("--samples", type=int, default=0)
@@ -225,7 +237,14 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample-systems", type=int, default=8192, help="systems of the batch the CPU baselines are timed on")
     ap.add_argument("--allow-gloo", action="store_true", help="accept a gloo moments gather when RCCL cannot start (the line says degraded)")
     ap.add_argument("--launcher-selftest", action="store_true", help="ranks only rendezvous (gloo, CPU) and report; no GPU work")
-    return ap.parse_args(argv)
+    ap.add_argument("--rendezvous-timeout", type=float, default=120.0, help="seconds a rank waits for the others in init_process_group")
+    args = ap.parse_args(argv)
+    wl = WORKLOADS[args.workload]
+    if args.steps is None:
+        args.steps = wl.get("steps", 10)
+    if args.warmup is None:
+        args.warmup = wl.get("warmup", 2)
+    return args
 
 
 def main():
@@ -238,11 +257,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    import datetime
+
     import torch
     import torch.distributed as dist
+    pg_timeout = datetime.timedelta(seconds=args.rendezvous_timeout)   # a missing rank fails the job in seconds, not in 10-30 minutes
 
     if args.launcher_selftest:
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=pg_timeout)
         ones = torch.ones(1)
         dist.all_reduce(ones)
         if rank == 0:
@@ -251,7 +273,7 @@ def main():
         return
 
     from bnn_chaos_model_amd import ops
-    from bnn_chaos_model_amd.distributed import all_gather_moments
+    from bnn_chaos_model_amd.distributed import all_gather_moments, shard_bounds
 
     # BNN_BENCH_REHEARSE=1: every rank on cuda:0 with gloo -- exercises the N>1 code path on a one-GPU box
     rehearse = os.environ.get("BNN_BENCH_REHEARSE") == "1"
@@ -264,11 +286,11 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
             degraded = True
         else:
             try:
-                dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+                dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)   # RCCL over xGMI
                 probe = torch.ones(1, dtype=torch.float64, device=dev)
                 dist.all_reduce(probe)                            # fail here, not inside the timed region
                 torch.cuda.synchronize()
@@ -282,11 +304,12 @@ def main():
                     dist.destroy_process_group()
                 except Exception:
                     pass
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=pg_timeout)
                 degraded = True
         ones = torch.ones(1, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
+    on_nccl = world > 1 and dist.get_backend() == "nccl"
 
     wl = dict(WORKLOADS[args.workload])
     if args.systems:
@@ -295,43 +318,83 @@ def main():
         wl["samples"] = args.samples
     B, S, M = wl["systems"], wl["seeds"], wl["samples"]
     nch = wl.get("chunks", 1)
+    trios = wl.get("trios", 1)
+    slab = wl.get("slab", 0)                      # > 0: the native slab driver reduces the draws to moments on the fly (c4)
+    if B % trios:
+        sys.exit(f"--systems must be a multiple of {trios} for workload {args.workload} (whole simulations per rank)")
     J = wl.get("draws", S * M) if nch == 1 else M * nch
+    R = J // nch                                  # output rows = samples per system
     noisy = bool(wl.get("noisy"))
     lowp = args.precision != "f32"
-    if lowp and (noisy or args.unfused or args.single_launch):
-        sys.exit("--precision applies to the fused quiet forward only")
+    if lowp and (noisy or args.unfused or args.single_launch or slab):
+        sys.exit("--precision applies to the fused quiet forward with kept samples only (workloads c3, c2, c5)")
 
-    x = synthetic_x(B, dev, seed=123 + rank)          # this rank's shard: global systems [rank*B, (rank+1)*B)
+    # Weak scaling: every rank holds B systems (B / trios whole simulations); this rank's global systems are [lo, hi).
+    lo, hi = shard_bounds(world * B, world, trios)[rank]
+    assert hi - lo == B
+    x = synthetic_x(B, dev, seed=123 + rank)          # this rank's shard
     wa, w2, pd = synthetic_ensemble(S, dev)           # replicated ensemble (29 MB)
     if nch == 1:
         seed_idx = (torch.arange(J, dtype=torch.int32) % S).to(dev)  # dense grid: every seed x every sample
     else:                                                            # one random member per chunk per sample (regression.py:78)
         import numpy as np
         seed_idx = torch.as_tensor(np.random.default_rng(7).integers(0, S, J).astype(np.int32)).to(dev)
-    out = torch.empty((J // nch, B, 2), dtype=torch.float32, device=dev)
+    out = None if slab else torch.empty((R, B, 2), dtype=torch.float32, device=dev)
     plan = ops.get_plan()
     W_noisy = ops.swag_draw(wa, w2, pd, seed_idx, philox_seed=99, plan=plan) if noisy else None
+    sketch = ops.QuantileSketch(B, group=trios, device=dev) if trios > 1 else None
+    stats = ops.stats_params(device=dev) if trios > 1 else None
+    BANDS_Q = (2.5, 16.0, 50.0, 84.0, 97.5)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    gv0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    gv1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    gather_host_ms = []
+
+    def gather(local, n_total, i, timed):
+        """The path's one exchange.  RCCL: HIP events on the current stream bracket it (the collective's stream is joined to the
+        current stream on both sides); gloo (rehearsal / degraded): staged through the host, so a host clock around it."""
+        if world == 1:
+            return local
+        if on_nccl:
+            if timed:
+                gv0[i].record()
+            res = all_gather_moments(local, n_total)
+            if timed:
+                gv1[i].record()
+            return res
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        res = all_gather_moments(local, n_total)
+        if timed:
+            gather_host_ms.append((time.perf_counter() - t) * 1e3)
+        return res
 
     def step(i, timed):
         if timed:
             ev0[i].record()          # on torch's current stream = the stream the ops launch on (ops.N.stream_ptr())
+        if slab:                     # c4: slabs of draws -> float64 moments inside ONE native call
+            mom = ops.multiswag_moments(x, wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, system_id0=lo, draws_per_launch=slab, plan=plan)
+            if timed:
+                ev1[i].record()
+            return gather(mom, world * B, i, timed)
         if noisy:
-            o = ops.forward(x, W_noisy, philox_seed=99, draw_id0=0, system_id0=rank * B, plan=plan, noisy=True, systems_per_block=args.spb)
+            o = ops.forward(x, W_noisy, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan, noisy=True, systems_per_block=args.spb)
         elif args.unfused:
             W = ops.swag_draw(wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, plan=plan)
-            o = ops.forward(x, W, philox_seed=99, draw_id0=0, system_id0=rank * B, plan=plan, systems_per_block=args.spb)
+            o = ops.forward(x, W, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan, systems_per_block=args.spb)
         else:
-            o = ops.multiswag(x, wa, w2, pd, seed_idx, nchunks=nch, philox_seed=99, draw_id0=0, system_id0=rank * B, plan=plan,
+            o = ops.multiswag(x, wa, w2, pd, seed_idx, nchunks=nch, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan,
                               out=None if lowp else out, systems_per_block=args.spb, single_launch=args.single_launch,
                               precision=args.precision)
         if timed:
             ev1[i].record()
-        mom = ops.moments(o)
-        if world > 1:
-            mom = all_gather_moments(mom, world * B)  # the path's one exchange: [B,4] float64 per rank
-        return mom
+        if trios > 1:   # c5: what the 5-planet script does with the samples (multiswag_5_planet.py:388-428, 484-489), per simulation
+            sketch.hist.zero_(); sketch.mom.zero_(); sketch.count = 0
+            sketch.update(ops.stats_draw(o, st=stats, philox_seed=99, row_id0=0, system_id0=lo))   # truncnorm + prior, min over trios
+            bands = torch.cat([sketch.percentiles(BANDS_Q), sketch.mean().float()[:, None]], 1)   # [sims, 6]
+            return gather(bands, world * B // trios, i, timed)
+        return gather(ops.moments(o), world * B, i, timed)  # [B,4] float64 per rank
 
     def fence():
         if world > 1:
@@ -343,51 +406,74 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        mom = step(i, True)
+        res_last = step(i, True)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    if world > 1:
+        gather_ms = (sum(a.elapsed_time(b) for a, b in zip(gv0, gv1)) if on_nccl else sum(gather_host_ms)) / args.steps
+        cdev = dev if on_nccl else "cpu"
+        t = torch.tensor([dt, gather_ms], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, gather_ms = float(t[0].item()), float(t[1].item())
+        km = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(km, torch.tensor([kern_ms], dtype=torch.float64, device=cdev))
+        kern_ms_ranks = [float(v.item()) for v in km]
+    else:
+        gather_ms, kern_ms_ranks = 0.0, [kern_ms]
+    expect_rows = world * B // trios
+    if res_last.shape[0] != expect_rows:
+        sys.exit(f"[bench] rank {rank}: gathered {res_last.shape[0]} rows, expected {expect_rows}")
 
-    evals_per_step = world * B * (J // nch)   # every system under every sample (a chunked draw covers 1/nch of the systems)
+    evals_per_step = world * B * R   # every system under every sample (a chunked draw covers 1/nch of the systems)
     value = evals_per_step * args.steps / dt
     if rank == 0:
-        evals_per_launch = B * (J // nch)
+        evals_per_launch = B * R
         kin = 41 if noisy else 31
         ach_tflops = evals_per_launch * ALG_FLOP_PER_EVAL / (kern_ms * 1e-3) / 1e12
         exe_tflops = evals_per_launch * EXEC_FLOP_PER_EVAL[kin] / (kern_ms * 1e-3) / 1e12
         ach_gbs = evals_per_launch * ALG_BYTES_PER_EVAL / (kern_ms * 1e-3) / 1e9
+        # HBM bytes per launch: NOT measured in this run.  The PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, gfx950
+        # correction of MI355X_MICROARCH.md) run the same command under the profiler (scripts/profile_r03.sh) and leave the
+        # per-launch figure in profiles/pmc_traffic.json; it is quoted here with its source so that the line is self-describing.
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):   # HBM bytes per launch from the rocprofv3 PMC passes of this same command (scripts/profile_r02.sh)
+        if os.path.exists(tf):
             try:
                 rec = json.load(open(tf)).get(args.workload)
-                if rec and rec.get("systems") == B and rec.get("draws") == J:
+                if rec and rec.get("systems") == B and rec.get("draws") == J and not lowp:
                     traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
             except Exception:
                 traffic = None
         kernel = ("bnn_forward_kernel<41,noisy> (ops.forward, noisy_val=True, in-kernel Philox)" if noisy else
                   "ops.swag_draw + ops.forward" if args.unfused else
+                  f"bnn_multiswag_moments_f64: {slab} draws per launch (draw + forward + moments kernels), {J // slab} launches per step" if slab else
                   ("multiswag, in-kernel draw per workgroup" if args.single_launch else "multiswag, draw-once workspace + forward"))
         if lowp:
             kernel = f"bnn_forward_lowp_kernel ({args.precision}): exact fp32 draw + feature_nn on the bf16 matrix pipe, {PRODUCTS_OF[args.precision]} product(s) per layer"
+        payload = ("bands [sims, 5 percentiles + mean] float32" if trios > 1 else "moments [systems, 4] float64")
         res = {
             "metric": "system x MC-sample forward evals/sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_OF[args.precision], "data": "synthetic",
             "config": {"workload": wl["name"], "systems_per_gpu": B, "seeds": S, "mc_samples": M, "draws": J, "chunks": nch, "timesteps": 100,
                        "features": 41, "noise": "in-kernel Philox4x32-10", "kernel": kernel,
-                       "sharding": f"systems over {world} rank(s), all-gather of moments",
-                       "collective": (dist.get_backend() if world > 1 else "none"), "degraded": degraded, "ranks_seen": ranks_seen},
+                       "sharding": (f"whole simulations ({trios} trios each) over {world} rank(s), all-gather of {payload}" if trios > 1 else
+                                    f"systems over {world} rank(s), all-gather of {payload}"),
+                       "collective": (dist.get_backend() if world > 1 else "none"), "degraded": degraded, "ranks_seen": ranks_seen,
+                       "gather_ms": gather_ms, "gather_bytes_per_rank": int(res_last.shape[0] // world * res_last.shape[1] * res_last.element_size()),
+                       "kernel_ms_min": min(kern_ms_ranks), "kernel_ms_max": max(kern_ms_ranks),
+                       "timing_note": "ms_per_step = wall clock of the whole step, max over ranks; kernel_ms_* = HIP events around the compute "
+                                      "launches per rank (min / max over ranks); gather_ms = the all-gather alone, max over ranks"},
             "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_measured_in_run": False,
+                         "traffic_source": traffic_src,
                          "achieved_executed": exe_tflops, "frac_executed": exe_tflops / PEAK_F32_MFMA_TFLOPS,
                          "kernel_ms": kern_ms, "flop_per_eval": ALG_FLOP_PER_EVAL, "flop_per_eval_executed": EXEC_FLOP_PER_EVAL[kin],
                          "note": "frac counts the algorithm's 814 560 flop/eval (SURVEY 8d); frac_executed counts the MACs the kernel issues "
-                                 "(the v50 mask drops 10 of 41 input columns); kernel_ms = HIP events around the draw + forward launches",
+                                 "(the v50 mask drops 10 of 41 input columns); kernel_ms = HIP events around the compute launches of a step "
+                                 "(rank 0); traffic = HBM bytes per launch from separate rocprofv3 PMC passes of this command, null when "
+                                 "no such pass is on file for this workload",
                          "hbm_algorithmic_GBs": ach_gbs, "hbm_frac_of_8TBs": ach_gbs / PEAK_HBM_GBS},
         }
         if lowp:   # priced against the bf16 matrix pipe; issued flops = algorithmic x products; these forms are vector-issue bound

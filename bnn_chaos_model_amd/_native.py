@@ -53,11 +53,24 @@ def lib():
         return _lib
     if not os.environ.get("BNN_CHAOS_SO"):
         from .csrc import build as _b
-        try:
-            _b.build()
-        except Exception:
-            if not os.path.exists(SO_PATH):  # no compiler AND no library: nothing to run (there is no CPU fallback)
-                raise
+        if _b.stale():
+            # The library on disk was not built from the sources next to it.  Rebuild; a COMPILE error always propagates (a stale
+            # binary must never stand in for sources that do not build).  Only a missing compiler is survivable, and only when
+            # BNN_CHAOS_ALLOW_STALE=1 says so explicitly -- then the mismatch is announced, never silent.
+            try:
+                _b.hipcc()
+                have_cc = True
+            except RuntimeError:
+                have_cc = False
+            if have_cc:
+                _b.build()
+            elif os.path.exists(SO_PATH) and os.environ.get("BNN_CHAOS_ALLOW_STALE") == "1":
+                import warnings
+                warnings.warn(f"{SO_PATH} does not match the sources next to it (source hash differs) and hipcc is not available to "
+                              "rebuild it; loading it because BNN_CHAOS_ALLOW_STALE=1", RuntimeWarning, stacklevel=2)
+            else:
+                raise RuntimeError(f"{SO_PATH} is missing or was built from other sources than the ones next to it, and hipcc was not "
+                                   "found to rebuild it (there is no CPU fallback; set BNN_CHAOS_ALLOW_STALE=1 to load a stale library)")
     L = C.CDLL(SO_PATH)
     L.bnn_last_error.restype = C.c_char_p
     L.bnn_plan_create.argtypes = [C.POINTER(BnnArch), C.POINTER(_vp)]

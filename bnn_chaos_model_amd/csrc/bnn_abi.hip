@@ -433,7 +433,7 @@ struct bnn_plan {
     bnn_arch arch;
     Tables tab[2];  // [0] = arch mask, [1] = all 41 columns (noisy forward)
     int16_t* d_f2 = nullptr;   // regress_nn fragment gather table
-    int16_t* d_f4 = nullptr;   // feature_nn 4x4x1 image table for the plan's mask
+    int16_t* d_f4 = nullptr;   // feature_nn weight-register table (4x4x1 path) for the plan's mask
     int16_t* d_f4n = nullptr;  // ... with every column live (noisy forward)
     float* d_rcp = nullptr;    // [RCP_N] 1/(i+1)
     int device = 0;
@@ -558,7 +558,7 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     p.spc = pick_spc(g, p.csz);
     p.row_id0 = p.draw_id0 / g->nchunks;
     p.xcd_order = (g->nchunks > 1 || (double)g->B * g->T * F * sizeof(float) > 256.0 * 1024 * 1024) ? 1 : 0;
-    p.tab_f2 = pl->d_f2; p.tab_f4 = noisy ? pl->d_f4n : pl->d_f4; p.rcp_tab = pl->d_rcp;
+    p.tab_f2 = pl->d_f2; p.tab_wr = noisy ? pl->d_f4n : pl->d_f4; p.rcp_tab = pl->d_rcp;
     p.zero_mask = pl->arch.zero_mask;
     p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);
     const int64_t nsub = (p.csz + p.spc - 1) / p.spc;

@@ -4,8 +4,11 @@
 // Included by the bnn_fwd_*.hip translation units, each of which instantiates a few of the template's forms.
 //
 // lane = row, so there is no padding anywhere: 310 + 400 + 200 = 910 MFMAs of 8 cycles per 64 rows (113.75 pipe cycles per
-// row against 148 for a 16x16x4 tiling).  Weights stream from an LDS image with broadcast ds_read_b128 (one read feeds four
-// MFMAs), activations never leave registers: a layer's accumulator registers are the next layer's B operands as they stand.
+// row against 148 for a 16x16x4 tiling).  The weights are REGISTER-RESIDENT: with CBSZ = 4 the MFMA broadcasts the A operand of
+// block ABID to all 16 blocks, so one VGPR carries the A operands of 16 different MFMAs (lanes 4a..4a+3 = the four neurons of
+// MFMA 16R + a) and the whole of feature_nn is 58 VGPRs (WR<KIN>), loaded once per workgroup; the tile loop reads no weights
+// from anywhere (round 2 streamed them from LDS images: 253 ds_read_b128 + 212 s_waitcnt per 910-MFMA tile, LDS 45 % busy).
+// Activations never leave registers: a layer's accumulator registers are the next layer's B operands as they stand.
 // A wave owns 16 systems at a time: lane l = system l>>2, timestep phase l&3; tile `it` = timesteps 4it..4it+3.
 // Accumulation order per output = bias, then inputs in ascending order: the oracle's natural order.
 // KIN = 31: the v50 column mask (31 live columns); KIN = 41: any mask (whole rows, zero weights on masked columns).
@@ -13,10 +16,22 @@
 // co-issues with it, from either wave of the SIMD, so the kernel's time is the SUM of its matrix and vector instructions and the
 // loop below is written to need as few vector instructions as the arithmetic allows.
 #pragma once
+#include <utility>
+
 #include "bnn_common.hip.h"
 #include "bnn_stats.hip.h"
 
 namespace bnn {
+
+// v_mfma_f32_4x4x1_16b_f32 with CBSZ = 4: the A operand (4 neurons x 1 input) of block ABID serves all 16 blocks
+// (scripts/probes/cbsz_probe.hip confirms the semantics on gfx950).  cbsz / abid are immediates: compile-time loop below.
+template <int ABID>
+DEVINL f32x4 mfma4b(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0); }
+
+template <class Fn, int... I>
+DEVINL void static_for_impl(Fn&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class Fn>
+DEVINL void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int KIN>
 DEVINL void load_row(const float* __restrict__ rp, float (&xv)[KIN]) {
@@ -43,18 +58,18 @@ constexpr int NSC4 = 96 + 2 * 56;  // LDS floats of the noisy forward: exp(logva
                                    // per 6-column noise block, padded to 8: the input scales [7][8] and the column keep-masks [7][8]
 
 template <int KIN>
-constexpr size_t fwd_lds_bytes() { return sizeof(float) * (FLAT_LDS + MAXK + W4<KIN>::PAD + 4 * SCR4 + NSC4); }
+constexpr size_t fwd_lds_bytes() { return sizeof(float) * (FLAT_LDS + MAXK + BIAS_PAD + 4 * SCR4 + NSC4); }
 
 template <int KIN, bool FUSED, bool NOISY, bool STATS>
 __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) {
-    using LY = W4<KIN>;
+    using WRL = WR<KIN>;
     static_assert(!NOISY || (KIN == F && !FUSED && !STATS), "the noisy forward multiplies all 41 columns and takes materialised weights");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot, later ...
     float* f2frag = lds;               // ... [NF2][64] regress_nn operands in fragment order
     float* zsh = lds + FLAT_LDS;       // [MAXK]
-    float* wl = zsh + MAXK;            // [LY::PAD] feature_nn images for the 4x4x1 operands
-    float* scr = wl + LY::PAD;         // [4][SCR4]
+    float* wl = zsh + MAXK;            // [BIAS_PAD] feature_nn biases [b1 | b2 | b3], 16-byte aligned rows of 4
+    float* scr = wl + BIAS_PAD;        // [4][SCR4]
     float* nsc = scr + 4 * SCR4;       // [NSC4] (NOISY only)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -97,7 +112,12 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     }
     if (tid == 0) flat[ZERO_IDX] = 0.0f;
     __syncthreads();
-    for (int i = tid; i < LY::PAD; i += 256) wl[i] = flat[p.tab_f4[i]];
+    // feature_nn weights -> registers (every wave holds the same 58): register R, lane 4a+i = W[neuron 4n+i][input k] of the
+    // layer's MFMA number m = 16R + a = k * groups + n (bnn_layout.h, WR<KIN>); biases -> a small LDS image
+    float wr[WRL::NR];
+#pragma unroll
+    for (int R = 0; R < WRL::NR; ++R) wr[R] = flat[p.tab_wr[R * 64 + lane]];
+    if (tid < 2 * H + L) wl[tid] = flat[tid < H ? OFF_B1 + tid : tid < 2 * H ? OFF_B2 + (tid - H) : OFF_B3 + (tid - 2 * H)];
     if constexpr (NOISY) {  // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
         if (tid < F + S2) nsc[tid] = expf(flat[OFF_INLV + tid] / 2.0f);
         if (tid < 56) {     // the same input scales per noise block, and all-ones / zero bit masks for kept / zeroed columns
@@ -132,15 +152,9 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     const float nm1 = (float)(T - 1), nT = (float)T;
     const float half_n0 = (float)ntiles * 0.5f;
     const int64_t rowstride = (int64_t)T * F;
-    const f32x4* wqA1 = reinterpret_cast<const f32x4*>(wl + LY::L1A) + ph0;
-    const f32x4* wqB1 = reinterpret_cast<const f32x4*>(wl + LY::L1B) + ph0;
-    const f32x4* wqA2 = reinterpret_cast<const f32x4*>(wl + LY::L2A) + ph0;
-    const f32x4* wqB2 = reinterpret_cast<const f32x4*>(wl + LY::L2B) + ph0;
-    const f32x4* wqA3 = reinterpret_cast<const f32x4*>(wl + LY::L3A) + ph0;
-    const f32x4* wqB3 = reinterpret_cast<const f32x4*>(wl + LY::L3B) + ph0;
-    const f32x4* bq1 = reinterpret_cast<const f32x4*>(wl + LY::B1);
-    const f32x4* bq2 = reinterpret_cast<const f32x4*>(wl + LY::B2);
-    const f32x4* bq3 = reinterpret_cast<const f32x4*>(wl + LY::B3);
+    const f32x4* bq1 = reinterpret_cast<const f32x4*>(wl);
+    const f32x4* bq2 = reinterpret_cast<const f32x4*>(wl + H);
+    const f32x4* bq3 = reinterpret_cast<const f32x4*>(wl + 2 * H);
     float* epsscr = scr + wave * SCR4;
     float* sumscr = epsscr + 16 * S2;
 
@@ -158,25 +172,15 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         load_row<KIN>(rowp, xv);
         asm volatile("" ::: "memory");
         for (int it = 0; it < ntiles; ++it) {
-            // A operands are read one group of 20 MFMAs ahead of their use and the order is pinned with
-            // sched_group_barrier (5 LDS reads, then 20 MFMAs): left alone, the scheduler issues each read one or two
-            // MFMAs before its use and the LDS latency lands on the matrix pipe.
-            // feature_nn.0 + ReLU: pairs of input columns (k0, k1): reads A(k0,m0) A(k0,m1) A(k1,m0) A(k1,m1) B(pair)
+            // feature_nn.0 + ReLU: MFMA m = k * 10 + n multiplies input column k into neuron group n (bias first, then the inputs in
+            // ascending order: the oracle's natural order); its A operand is lanes 4(m&15).. of weight register m >> 4.
             f32x4 h[10];
             {
-                constexpr int NP = LY::NP1;  // column pairs; the last one holds a single column (KIN is odd)
-                f32x4 q[NP][5];
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h[n] = bq1[n];
-                auto rd = [&](int kp) {
-                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
-                    q[kp][0] = wqA1[(k0 * 2 + 0) * 4]; q[kp][1] = wqA1[(k0 * 2 + 1) * 4];
-                    if (k1 < KIN) { q[kp][2] = wqA1[(k1 * 2 + 0) * 4]; q[kp][3] = wqA1[(k1 * 2 + 1) * 4]; }
-                    q[kp][4] = wqB1[kp * 4];
-                };
                 // masks, then add_input_noise (:486-504): masked columns become pure noise.  This lane's row is timestep
                 // 4*it + ph0 of system sysc0; its 41 normals are the 7 Philox blocks t*7 + 0..6, six normals each (or the explicit
-                // tensor's row).  A block is generated right in front of the three column pairs that consume it, so that its
+                // tensor's row).  A block is generated right in front of the six columns that consume it, so that its
                 // registers are short-lived (the whole row's noise up front cost 13 spilled VGPRs).
                 const float* er = nullptr;
                 int tblk = 0;
@@ -206,32 +210,15 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                         }
                     }
                 };
-                rd(0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
-#pragma unroll
-                for (int kp = 0; kp < NP; ++kp) {
-                    if constexpr (NOISY) {
-                        if (kp % 3 == 0) {  // a scheduling region of its own: neither the reads nor the MFMAs around it move across
-                            __builtin_amdgcn_sched_barrier(0);
-                            noise6(kp / 3);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                static_for<KIN * 10>([&](auto M) {
+                    constexpr int m = M, k = m / 10, n = m % 10;
+                    if constexpr (NOISY && n == 0 && k % 6 == 0) {  // a scheduling region of its own: the MFMAs around it do not move across
+                        __builtin_amdgcn_sched_barrier(0);
+                        noise6(k / 6);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (kp + 1 < NP) rd(kp + 1);
-                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
-                    const float b0 = xv[k0];
-                    h[0] = mfma4(q[kp][0].x, b0, h[0]); h[1] = mfma4(q[kp][0].y, b0, h[1]); h[2] = mfma4(q[kp][0].z, b0, h[2]); h[3] = mfma4(q[kp][0].w, b0, h[3]);
-                    h[4] = mfma4(q[kp][1].x, b0, h[4]); h[5] = mfma4(q[kp][1].y, b0, h[5]); h[6] = mfma4(q[kp][1].z, b0, h[6]); h[7] = mfma4(q[kp][1].w, b0, h[7]);
-                    h[8] = mfma4(q[kp][4].x, b0, h[8]); h[9] = mfma4(q[kp][4].y, b0, h[9]);
-                    if (k1 < KIN) {
-                        const float b1v = xv[k1];
-                        h[0] = mfma4(q[kp][2].x, b1v, h[0]); h[1] = mfma4(q[kp][2].y, b1v, h[1]); h[2] = mfma4(q[kp][2].z, b1v, h[2]); h[3] = mfma4(q[kp][2].w, b1v, h[3]);
-                        h[4] = mfma4(q[kp][3].x, b1v, h[4]); h[5] = mfma4(q[kp][3].y, b1v, h[5]); h[6] = mfma4(q[kp][3].z, b1v, h[6]); h[7] = mfma4(q[kp][3].w, b1v, h[7]);
-                        h[8] = mfma4(q[kp][4].z, b1v, h[8]); h[9] = mfma4(q[kp][4].w, b1v, h[9]);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
-                }
+                    h[n] = mfma4b<(m & 15)>(wr[m >> 4], xv[k], h[n]);
+                });
             }
 #pragma unroll
             for (int n = 0; n < 10; ++n) h[n] = relu4(h[n]);
@@ -241,65 +228,27 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                 load_row<KIN>(rowp + (int64_t)itn * 4 * F, xv);
                 asm volatile("" ::: "memory");
             }
-            // feature_nn.2 + ReLU
+            // feature_nn.2 + ReLU: MFMA m = k * 10 + n
             f32x4 h2[10];
             {
-                constexpr int NP = H / 2;
-                f32x4 q[NP][5];
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h2[n] = bq2[n];
-                auto rd = [&](int kp) {
-                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
-                    q[kp][0] = wqA2[(k0 * 2 + 0) * 4]; q[kp][1] = wqA2[(k0 * 2 + 1) * 4];
-                    q[kp][2] = wqA2[(k1 * 2 + 0) * 4]; q[kp][3] = wqA2[(k1 * 2 + 1) * 4];
-                    q[kp][4] = wqB2[kp * 4];
-                };
-                rd(0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 10 + 5, 0);
-#pragma unroll
-                for (int kp = 0; kp < NP; ++kp) {
-                    if (kp + 1 < NP) rd(kp + 1);
-                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
-                    const float b0 = h[k0 >> 2][k0 & 3], b1v = h[k1 >> 2][k1 & 3];
-                    h2[0] = mfma4(q[kp][0].x, b0, h2[0]); h2[1] = mfma4(q[kp][0].y, b0, h2[1]); h2[2] = mfma4(q[kp][0].z, b0, h2[2]); h2[3] = mfma4(q[kp][0].w, b0, h2[3]);
-                    h2[4] = mfma4(q[kp][1].x, b0, h2[4]); h2[5] = mfma4(q[kp][1].y, b0, h2[5]); h2[6] = mfma4(q[kp][1].z, b0, h2[6]); h2[7] = mfma4(q[kp][1].w, b0, h2[7]);
-                    h2[8] = mfma4(q[kp][4].x, b0, h2[8]); h2[9] = mfma4(q[kp][4].y, b0, h2[9]);
-                    h2[0] = mfma4(q[kp][2].x, b1v, h2[0]); h2[1] = mfma4(q[kp][2].y, b1v, h2[1]); h2[2] = mfma4(q[kp][2].z, b1v, h2[2]); h2[3] = mfma4(q[kp][2].w, b1v, h2[3]);
-                    h2[4] = mfma4(q[kp][3].x, b1v, h2[4]); h2[5] = mfma4(q[kp][3].y, b1v, h2[5]); h2[6] = mfma4(q[kp][3].z, b1v, h2[6]); h2[7] = mfma4(q[kp][3].w, b1v, h2[7]);
-                    h2[8] = mfma4(q[kp][4].z, b1v, h2[8]); h2[9] = mfma4(q[kp][4].w, b1v, h2[9]);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
-                }
+                static_for<H * 10>([&](auto M) {
+                    constexpr int m = M, k = m / 10, n = m % 10;
+                    h2[n] = mfma4b<(m & 15)>(wr[WRL::R1 + (m >> 4)], h[k >> 2][k & 3], h2[n]);
+                });
             }
 #pragma unroll
             for (int n = 0; n < 10; ++n) h2[n] = relu4(h2[n]);
-            // feature_nn.4: quads of inputs: reads A(k..k+3) + B(quad)
+            // feature_nn.4: MFMA m = k * 5 + n
             f32x4 y[5];
             {
-                constexpr int NQ = H / 4;
-                f32x4 q[NQ][5];
 #pragma unroll
                 for (int n = 0; n < 5; ++n) y[n] = bq3[n];
-                auto rd = [&](int kq) {
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) q[kq][cc] = wqA3[(4 * kq + cc) * 4];
-                    q[kq][4] = wqB3[kq * 4];
-                };
-                rd(0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 5 + 5, 0);
-#pragma unroll
-                for (int kq = 0; kq < NQ; ++kq) {
-                    if (kq + 1 < NQ) rd(kq + 1);
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const int k = 4 * kq + cc;
-                        const float b = h2[k >> 2][k & 3];
-                        y[0] = mfma4(q[kq][cc].x, b, y[0]); y[1] = mfma4(q[kq][cc].y, b, y[1]); y[2] = mfma4(q[kq][cc].z, b, y[2]); y[3] = mfma4(q[kq][cc].w, b, y[3]);
-                        y[4] = mfma4(q[kq][4][cc], b, y[4]);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
-                }
+                static_for<H * 5>([&](auto M) {
+                    constexpr int m = M, k = m / 5, n = m % 5;
+                    y[n] = mfma4b<(m & 15)>(wr[WRL::R1 + WRL::R2 + (m >> 4)], h2[k >> 2][k & 3], y[n]);
+                });
             }
             // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
             const float rcn = p.rcp_tab[it];

@@ -50,7 +50,7 @@ struct FwdParams {
     float* pre_clamp;
     float* summary;
     const int16_t* tab_f2;
-    const int16_t* tab_f4;  // 4x4x1 image gather table
+    const int16_t* tab_wr;  // feature_nn weight-register gather table [WR<KIN>::NR][64] (bnn_layout.h)
     const float* rcp_tab;   // [i] = 1/(i+1), correctly rounded
     uint64_t zero_mask;
     float std_lo, std_span;

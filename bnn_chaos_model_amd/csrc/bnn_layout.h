@@ -76,31 +76,25 @@ BNN_HD inline int kmap_summary(int ks, int g) {
     return kind * L + n;
 }
 // ---- second operand layout: v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 neurons x 4 rows, K = 1) -----------------
-// lane l = row (B operand), register r of neuron group n = neuron 4n + r (A operand: lane l supplies W[4n + (l&3)][k]).
-// No padding inside a layer: 40 outputs = 10 groups, 20 outputs = 5 groups.  The A operands stream from LDS images,
-// one broadcast ds_read_b128 per four MFMAs with every float of every read used:
-//   image A of a layer: [k][m][i][j]  -> W[neuron 4*(4m+j) + i][col(k)]   (groups 0..7 of a 40-wide layer, 0..3 of the latent)
-//   image B of a 40-wide layer: [k/2][i][2*(k&1) + j] -> groups 8, 9 (j = 0, 1) for two consecutive k
-//   image B of the latent layer: [k/4][i][k&3]         -> group 4 for four consecutive k
-// biases sit behind them as [n][r] and enter as the C operand of the first MFMA of a chain.
+// lane l = row (B operand), register r of neuron group n = neuron 4n + r.  The MFMA is issued with CBSZ = 4, ABID = a: the A
+// operand (4 neurons x 1 input) held by lanes 4a .. 4a+3 is broadcast to all 16 blocks.  So ONE weight register carries the A
+// operands of 16 MFMAs and all of feature_nn lives in registers for the workgroup's lifetime:
+//   layer with G neuron groups and K inputs: MFMA number m = k * G + n  (input k, group n; per output: bias, then k ascending)
+//   weight register R = m >> 4 of the layer, lane 4a + i (a = m & 15)  ->  W[neuron 4n + i][col(k)]
+// No padding inside a layer: 40 outputs = 10 groups, 20 outputs = 5 groups; only the last register of a layer may have unused
+// lanes (they read the zero slot).  Biases sit in a small LDS image [b1 | b2 | b3] and enter as the C operand of the first MFMA
+// of a chain.
 // KIN = number of layer-1 inputs the kernel multiplies: 31 for the v50 mask (live columns 0, 8..37, ascending), else all 41
-// columns (weights of masked columns are zero in the image).
+// columns (weights of masked columns are zero in the registers).
 BNN_HD inline int col4(int kin, int k) { return kin == F ? k : (k == 0 ? 0 : 7 + k); }
 template <int KIN>
-struct W4 {
-    static constexpr int NP1 = (KIN + 1) / 2;        // layer-1 column pairs (the last may hold one column)
-    static constexpr int L1A = 0;                    // [KIN][2][4][4]
-    static constexpr int L1B = L1A + KIN * 32;       // [NP1][4][4]
-    static constexpr int L2A = L1B + NP1 * 16;       // [40][2][4][4]
-    static constexpr int L2B = L2A + H * 32;         // [20][4][4]
-    static constexpr int L3A = L2B + 20 * 16;        // [40][4][4]
-    static constexpr int L3B = L3A + H * 16;         // [10][4][4]
-    static constexpr int B1 = L3B + 10 * 16;         // [10][4]
-    static constexpr int B2 = B1 + H;                // [10][4]
-    static constexpr int B3 = B2 + H;                // [5][4]
-    static constexpr int N = B3 + L;
-    static constexpr int PAD = (N + 15) / 16 * 16;   // 3760 (KIN = 31) / 4160 (KIN = 41)
+struct WR {
+    static constexpr int G1 = H / 4, G2 = H / 4, G3 = L / 4;   // neuron groups per layer
+    static constexpr int M1 = KIN * G1, M2 = H * G2, M3 = H * G3;  // MFMAs per 64-row tile: 310 (410) + 400 + 200
+    static constexpr int R1 = (M1 + 15) / 16, R2 = (M2 + 15) / 16, R3 = (M3 + 15) / 16;
+    static constexpr int NR = R1 + R2 + R3;                    // 58 (KIN = 31) / 64 (KIN = 41) weight registers
 };
+constexpr int BIAS_PAD = 112;  // LDS floats of the bias image (2 * H + L = 100, padded)
 
 // regress_nn fragment count (see bnn_tables.cpp)
 constexpr int NF2 = 30 + 30 + 10 + 12 + 12 + 4;

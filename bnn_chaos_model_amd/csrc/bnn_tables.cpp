@@ -1,6 +1,6 @@
 // bnn_tables.cpp -- builds the gather tables that turn the reference's flat parameter vector (spock_reg_model.py:734-761
-// order) into MFMA operands: the packed LDS images of feature_nn (v_mfma_f32_4x4x1) and the per-lane fragments + C-init
-// biases of regress_nn (v_mfma_f32_16x16x4).
+// order) into MFMA operands: the register-resident A operands of feature_nn (v_mfma_f32_4x4x1 with CBSZ broadcast) and the per-lane
+// fragments + C-init biases of regress_nn (v_mfma_f32_16x16x4).
 #include "bnn_tables.h"
 
 namespace bnn {
@@ -65,42 +65,31 @@ Tables build_tables(uint64_t zero_mask, bool all_columns) {
             return n < 0 ? ZERO_IDX : OFF_B6 + n;
         });
 
-    // 4x4x1 images: 31 live columns for the v50 mask, else all 41 with zero weights on the masked ones
+    // 4x4x1 weight registers (bnn_layout.h, WR<KIN>): 31 live columns for the v50 mask, else all 41 with zero weights on the
+    // masked ones.  Entry [R * 64 + lane]: lane 4a + i of register R holds W[neuron 4n + i][col(k)] of MFMA m = 16 R' + a = k * G + n
+    // (R' = register index within the layer).
     T.kin4 = v50 ? 31 : F;
     {
         auto build4 = [&](auto lay) {
             using LY = decltype(lay);
             const int kin = T.kin4;
-            T.f4.assign(LY::PAD, (int16_t)ZERO_IDX);
-            auto w = [&](int off_w, int ld, int n_out, int neuron, int col, bool input) {
-                if (neuron >= n_out || (input && dropped(col))) return (int16_t)ZERO_IDX;
-                return (int16_t)(off_w + neuron * ld + col);
+            T.f4.assign((size_t)LY::NR * 64, (int16_t)ZERO_IDX);
+            auto layer = [&](int reg0, int nregs, int K, int G, int off_w, int ld, bool input) {
+                for (int R = 0; R < nregs; ++R)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = 16 * R + (lane >> 2), i = lane & 3;
+                        if (m >= K * G) continue;
+                        const int k = m / G, n = m % G;
+                        const int col = input ? col4(kin, k) : k;
+                        if (input && dropped(col)) continue;
+                        T.f4[(size_t)(reg0 + R) * 64 + lane] = (int16_t)(off_w + (4 * n + i) * ld + col);
+                    }
             };
-            auto imgA = [&](int base, int K, int M, int off_w, int ld, int n_out, bool input) {
-                for (int k = 0; k < K; ++k)
-                    for (int m = 0; m < M; ++m)
-                        for (int i = 0; i < 4; ++i)
-                            for (int j = 0; j < 4; ++j)
-                                T.f4[base + ((k * M + m) * 4 + i) * 4 + j] = w(off_w, ld, n_out, 4 * (4 * m + j) + i, input ? col4(kin, k) : k, input);
-            };
-            auto imgB40 = [&](int base, int K, int off_w, int ld, bool input) {  // groups 8, 9, two k per read
-                for (int k = 0; k < K; ++k)
-                    for (int i = 0; i < 4; ++i)
-                        for (int j = 0; j < 2; ++j)
-                            T.f4[base + ((k >> 1) * 4 + i) * 4 + 2 * (k & 1) + j] = w(off_w, ld, H, 4 * (8 + j) + i, input ? col4(kin, k) : k, input);
-            };
-            imgA(LY::L1A, kin, 2, OFF_W1, F, H, true);
-            imgB40(LY::L1B, kin, OFF_W1, F, true);
-            imgA(LY::L2A, H, 2, OFF_W2, H, H, false);
-            imgB40(LY::L2B, H, OFF_W2, H, false);
-            imgA(LY::L3A, H, 1, OFF_W3, H, L, false);
-            for (int k = 0; k < H; ++k)  // group 4 of the latent layer, four k per read
-                for (int i = 0; i < 4; ++i) T.f4[LY::L3B + ((k >> 2) * 4 + i) * 4 + (k & 3)] = w(OFF_W3, H, L, 16 + i, k, false);
-            for (int n = 0; n < H; ++n) T.f4[LY::B1 + n] = (int16_t)(OFF_B1 + n);
-            for (int n = 0; n < H; ++n) T.f4[LY::B2 + n] = (int16_t)(OFF_B2 + n);
-            for (int n = 0; n < L; ++n) T.f4[LY::B3 + n] = (int16_t)(OFF_B3 + n);
+            layer(0, LY::R1, kin, LY::G1, OFF_W1, F, true);
+            layer(LY::R1, LY::R2, H, LY::G2, OFF_W2, H, false);
+            layer(LY::R1 + LY::R2, LY::R3, H, LY::G3, OFF_W3, H, false);
         };
-        if (v50) build4(W4<31>{}); else build4(W4<F>{});
+        if (v50) build4(WR<31>{}); else build4(WR<F>{});
     }
 
     // accumulation order.  feature_nn (4x4x1, K = 1 per instruction): the accumulator starts at the bias, then the live inputs in

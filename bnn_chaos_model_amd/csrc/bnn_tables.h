@@ -12,7 +12,7 @@ namespace bnn {
 struct Tables {
     std::vector<int16_t> f2;   // NF2 * 64: regress_nn fragments + C-init biases
     int kin4;                  // layer-1 inputs of the 4x4x1 kernel: 31 (v50 mask) or 41
-    std::vector<int16_t> f4;   // W4<kin4>::PAD: feature_nn images for the 4x4x1 kernel
+    std::vector<int16_t> f4;   // WR<kin4>::NR * 64: feature_nn weight registers of the 4x4x1 kernel (entry [R * 64 + lane])
     std::vector<int32_t> order[6];  // accumulation order per Linear layer (input index or -1 = bias)
 };
 

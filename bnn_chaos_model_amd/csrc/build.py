@@ -40,11 +40,13 @@ def source_hash(extra=()):
     return h.hexdigest()
 
 
-def stale():
-    """True when the library is missing or was built from other sources than the ones next to it."""
+def stale(so=None):
+    """True when the library is missing or was built from other sources (or other flags) than the default build of the ones next
+    to it."""
+    so = so or SO
     try:
-        with open(SO + ".srchash") as f:
-            return not os.path.exists(SO) or f.read().strip() != source_hash()
+        with open(so + ".srchash") as f:
+            return not os.path.exists(so) or f.read().strip() != source_hash()
     except OSError:
         return True
 
@@ -58,6 +60,18 @@ def build(force=False, verbose=False, extra=(), out=None):
     objdir = OBJDIR if out is None else os.path.join(HERE, "build_" + os.path.splitext(out)[0])
     os.makedirs(objdir, exist_ok=True)
     hdr_t = max(_mtime(h) for h in HEADERS)
+    # objects are reusable only under the flags they were compiled with: the object directory carries a stamp of CFLAGS + extra
+    flags_stamp = " ".join(CFLAGS + list(extra))
+    stamp_file = os.path.join(objdir, "FLAGS")
+    try:
+        with open(stamp_file) as f:
+            same_flags = f.read() == flags_stamp
+    except OSError:
+        same_flags = False
+    if not same_flags:
+        force = True
+        with open(stamp_file, "w") as f:
+            f.write(flags_stamp)
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")

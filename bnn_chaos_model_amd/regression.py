@@ -86,7 +86,14 @@ class FeatureRegressor(object):
         return out[..., 0], out[..., 1]
 
     def predict(self, sim, indices=None, samples=1000):
-        raise NotImplementedError("needs REBOUND feature generation (get_extended_tseries), upstream of the accelerated path")
+        raise NotImplementedError("needs REBOUND feature generation (get_extended_tseries), upstream of the accelerated path; "
+                                  "give its output to predict_tseries()")
+
+    def predict_tseries(self, tseries, mass_arrays, samples=1000, rng="torch", philox_seed=0):
+        """FeatureRegressor.predict (regression.py:94-108) downstream of the N-body integration: the reference returns
+        `np.median(self.sample(...))`, i.e. the median over the stacked (mu, std) arrays that `sample` returns (:107-108, :179) --
+        reproduced as it stands."""
+        return np.median(self.sample_tseries(tseries, mass_arrays, samples=samples, rng=rng, philox_seed=philox_seed))
 
     # ---- batched driver ----------------------------------------------------------------------------------------
     def ensemble_state(self, device=None):

@@ -59,14 +59,10 @@ def _(x, w_avg, w2_avg, pre_D, seed_idx, z1, z2, eps, nchunks, scale, philox_see
 def multiswag_moments(x: torch.Tensor, w_avg: torch.Tensor, w2_avg: torch.Tensor, pre_D: torch.Tensor, seed_idx: torch.Tensor,
                       scale: float, philox_seed: int, draw_id0: int, system_id0: int, draws_per_launch: int) -> torch.Tensor:
     """Predictive moments of the dense (systems x draws) grid -> float64 [B, 4] (sum mu, sum mu^2, sum std, sum std^2), the draws
-    evaluated in slabs of `draws_per_launch` so that [J,B,2] is never materialised (the multi-GPU gather payload)."""
-    mom = None
-    J = seed_idx.numel()
-    for j0 in range(0, J, max(int(draws_per_launch), 1)):
-        s = ops.multiswag(x, w_avg, w2_avg, pre_D, seed_idx[j0:j0 + draws_per_launch], scale=scale, philox_seed=philox_seed,
-                          draw_id0=draw_id0 + j0, system_id0=system_id0)
-        mom = ops.moments(s, mom)
-    return mom if mom is not None else x.new_zeros((x.shape[0], 4), dtype=torch.float64)
+    evaluated in slabs of `draws_per_launch` so that [J,B,2] is never materialised (the multi-GPU gather payload):
+    the native slab driver bnn_multiswag_moments_f64, one C-ABI call."""
+    return ops.multiswag_moments(x, w_avg, w2_avg, pre_D, seed_idx, scale=scale, philox_seed=philox_seed, draw_id0=draw_id0,
+                                 system_id0=system_id0, draws_per_launch=draws_per_launch)
 
 
 @multiswag_moments.register_fake

@@ -69,8 +69,9 @@ int bnn_plan_layer_order(const bnn_plan* plan, int layer, int noisy, int32_t* ho
 /* Host-only views of the operand layout (no device needed; used by the CPU test-suite):
  * bnn_layer_order = bnn_plan_layer_order without a plan;
  * bnn_fragment_table: which = 2: regress_nn gather table, entry [f*64 + lane] = index into the flat parameter vector (or
- * d = 7583 for "zero") that lane `lane` loads into v_mfma_f32_16x16x4 operand register f; which = 1: the feature_nn LDS image
- * of the v_mfma_f32_4x4x1 path, entry [i] = index of the parameter stored at float i of the image (layout: bnn_layout.h, W4<KIN>).
+ * d = 7583 for "zero") that lane `lane` loads into v_mfma_f32_16x16x4 operand register f; which = 1: the feature_nn weight
+ * registers of the v_mfma_f32_4x4x1 path (CBSZ broadcast), entry [R*64 + lane] = index of the parameter lane `lane` holds in weight
+ * register R (layout: bnn_layout.h, WR<KIN>).
  * Both return the number of entries (the required capacity) or a negative bnn_status. */
 int bnn_layer_order(const bnn_arch* arch, int layer, int noisy, int32_t* host_order, int cap);
 int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host_table, int cap);

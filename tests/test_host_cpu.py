@@ -69,20 +69,10 @@ def _image(N, mask, noisy):
     return t.astype(np.int64)
 
 
-def _w4(kin):
-    """Offsets of the feature_nn LDS image (bnn_layout.h, W4<KIN>)."""
-    np1 = (kin + 1) // 2
-    o = dict(L1A=0)
-    o["L1B"] = o["L1A"] + kin * 32
-    o["L2A"] = o["L1B"] + np1 * 16
-    o["L2B"] = o["L2A"] + 40 * 32
-    o["L3A"] = o["L2B"] + 20 * 16
-    o["L3B"] = o["L3A"] + 40 * 16
-    o["B1"] = o["L3B"] + 10 * 16
-    o["B2"] = o["B1"] + 40
-    o["B3"] = o["B2"] + 40
-    o["N"] = o["B3"] + 20
-    return o
+def _wr(kin):
+    """Weight-register counts of the feature_nn 4x4x1 path (bnn_layout.h, WR<KIN>): MFMAs per layer / 16, rounded up."""
+    r1, r2, r3 = (kin * 10 + 15) // 16, (40 * 10 + 15) // 16, (40 * 5 + 15) // 16
+    return dict(R1=r1, R2=r2, R3=r3, NR=r1 + r2 + r3)
 
 
 OFF = dict(W1=81, B1=1721, W2=1761, B2=3361, W3=3401, B3=4201, W4=4221, B4=5821, W5=5861, B5=7461, W6=7501, B6=7581, D=7583)
@@ -96,68 +86,62 @@ def test_accumulation_orders_are_permutations(N, mask, noisy, kin):
         assert _order(N, mask, layer, noisy).tolist() == list(range(40))
     for layer in (3, 4, 5):
         assert sorted(_order(N, mask, layer, noisy).tolist()) == list(range(40))
-    assert _image(N, mask, noisy).size == (_w4(kin)["N"] + 15) // 16 * 16
+    assert _image(N, mask, noisy).size == _wr(kin)["NR"] * 64
 
 
 def test_operand_tables_use_every_parameter_exactly_once(N):
-    """Each weight and bias of feature_nn (LDS images of the 4x4x1 path) / regress_nn (16x16x4 fragments) sits in exactly one slot."""
+    """Each weight of feature_nn (register-resident A operands of the 4x4x1 path) / each weight and bias of regress_nn (16x16x4
+    fragments) sits in exactly one slot; unused lanes read the zero slot."""
     img = _image(N, V50_MASK, 0)
-    o = _w4(31)
-    body = img[:o["N"]]
-    body = body[body != OFF["D"]]
+    o = _wr(31)
+    assert img.size == o["NR"] * 64 == 58 * 64
+    body = img[img != OFF["D"]]
     live = [0] + list(range(8, 38))
-    want = {OFF["W1"] + n * 41 + c for n in range(40) for c in live} | set(range(OFF["B1"], OFF["B1"] + 40)) | \
-        set(range(OFF["W2"], OFF["B2"] + 40)) | set(range(OFF["W3"], OFF["B3"] + 20))
+    want = {OFF["W1"] + n * 41 + c for n in range(40) for c in live} | set(range(OFF["W2"], OFF["B2"])) | set(range(OFF["W3"], OFF["B3"]))
     assert len(body) == len(want) and set(body.tolist()) == want
-    assert (img[o["N"]:] == OFF["D"]).all()                      # tail padding reads the zero slot
+    # only the last register of a layer has unused lanes: 310, 400, 200 MFMAs x 4 lanes
+    per_reg = (img.reshape(-1, 64) != OFF["D"]).sum(1)
+    assert per_reg[:o["R1"]].sum() == 1240 and per_reg[o["R1"]:o["R1"] + o["R2"]].sum() == 1600 and per_reg[o["R1"] + o["R2"]:].sum() == 800
+    assert (per_reg[:o["R1"] - 1] == 64).all() and (per_reg[o["R1"]:o["R1"] + o["R2"]] == 64).all()
     f2 = _table(N, V50_MASK, 0, 2)
     a2 = f2[:70].ravel()
     a2 = a2[a2 != OFF["D"]]
     want2 = set(range(OFF["W4"], OFF["B4"])) | set(range(OFF["W5"], OFF["B5"])) | set(range(OFF["W6"], OFF["B6"]))
     assert len(a2) == len(want2) and set(a2.tolist()) == want2
-    # any other mask: all 41 columns are in the image, the masked ones read the zero slot
+    # any other mask: all 41 columns are multiplied, the masked ones read the zero slot
     g = _image(N, 1 << 7, 0)
-    og = _w4(41)
-    l1 = g[:og["L2A"]]
+    og = _wr(41)
+    assert g.size == og["NR"] * 64 == 64 * 64
+    l1 = g[:og["R1"] * 64]
     assert set(l1[l1 != OFF["D"]].tolist()) == {OFF["W1"] + n * 41 + c for n in range(40) for c in range(41) if c != 7}
-    n1 = _image(N, V50_MASK, 1)[:og["L2A"]]                      # noisy forward: every column live (masked ones carry noise)
+    n1 = _image(N, V50_MASK, 1)[:og["R1"] * 64]                  # noisy forward: every column live (masked ones carry noise)
     assert set(n1[n1 != OFF["D"]].tolist()) == set(range(OFF["W1"], OFF["B1"]))
 
 
-def test_image_dataflow_emulation_matches_oracle(N, inputs):
-    """Evaluate feature_nn for a few rows in numpy exactly the way the kernel reads its LDS images (v_mfma_f32_4x4x1: lane = row,
-    register r of neuron group n = neuron 4n + r, one input per instruction, four groups per broadcast ds_read_b128) and compare
-    with the oracle's latents."""
+def test_register_dataflow_emulation_matches_oracle(N, inputs):
+    """Evaluate feature_nn for a few rows in numpy exactly the way the kernel issues it (v_mfma_f32_4x4x1 with CBSZ = 4: lane = row,
+    MFMA m = k * G + n of a layer takes its A operand -- neurons 4n..4n+3 against input k -- from lanes 4(m & 15).. of weight
+    register m >> 4, accumulator register i of group n = neuron 4n + i; bias first, then the inputs in ascending order) and
+    compare with the oracle's latents."""
     from oracle import oracle as orc
     z = load_golden("case_swagfast_v50_0_slow.npz")
     w = np.concatenate([z["w"], [0.0]]).astype(np.float64)
-    img = w[_image(N, V50_MASK, 0)]
-    o = _w4(31)
+    regs = w[_image(N, V50_MASK, 0)].reshape(-1, 64)
+    o = _wr(31)
     live = [0] + list(range(8, 38))
     x = inputs["slow"][0][:8].astype(np.float64)[:, live]     # 8 rows x 31 live columns
 
-    def layer(xin, A, Bimg, bias, n_groups, per_read):
-        """A: image [k][m][i][j] -> neuron 4*(4m+j)+i ; Bimg: leftover groups, `per_read` consecutive k per 16-float read."""
-        K = xin.shape[1]
-        M = (n_groups // 4)
-        out = np.tile(img[bias:bias + 4 * n_groups], (xin.shape[0], 1))
-        for k in range(K):
-            for m in range(M):
-                for i in range(4):
-                    for j in range(4):
-                        out[:, 4 * (4 * m + j) + i] += img[A + ((k * M + m) * 4 + i) * 4 + j] * xin[:, k]
-            if per_read == 2:      # groups 8, 9 of a 40-wide layer: [k/2][i][2*(k&1) + j]
-                for i in range(4):
-                    for j in range(2):
-                        out[:, 4 * (8 + j) + i] += img[Bimg + ((k >> 1) * 4 + i) * 4 + 2 * (k & 1) + j] * xin[:, k]
-            else:                  # group 4 of the latent layer: [k/4][i][k&3]
-                for i in range(4):
-                    out[:, 16 + i] += img[Bimg + ((k >> 2) * 4 + i) * 4 + (k & 3)] * xin[:, k]
+    def layer(xin, reg0, G, bias_off):
+        out = np.tile(w[bias_off:bias_off + 4 * G], (xin.shape[0], 1))
+        for m in range(xin.shape[1] * G):
+            k, n, a = m // G, m % G, m & 15
+            for i in range(4):
+                out[:, 4 * n + i] += regs[reg0 + (m >> 4), 4 * a + i] * xin[:, k]
         return out
 
-    h = np.maximum(layer(x, o["L1A"], o["L1B"], o["B1"], 10, 2), 0)
-    h2 = np.maximum(layer(h, o["L2A"], o["L2B"], o["B2"], 10, 2), 0)
-    lat = layer(h2, o["L3A"], o["L3B"], o["B3"], 5, 4)
+    h = np.maximum(layer(x, 0, 10, OFF["B1"]), 0)
+    h2 = np.maximum(layer(h, o["R1"], 10, OFF["B2"]), 0)
+    lat = layer(h2, o["R1"] + o["R2"], 5, OFF["B3"])
     tp1, tp2 = z["tape_002"], z["tape_003"]
     _, ex = orc.forward(inputs["slow"][:1], z["w"], tp1[:1], tp2[:1], extras=True)
     assert np.abs(lat - ex["latents"][0, :8]).max() < 5e-5
