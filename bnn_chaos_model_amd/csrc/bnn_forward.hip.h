@@ -21,6 +21,17 @@
 #include "bnn_common.hip.h"
 #include "bnn_stats.hip.h"
 
+// Build-time switches of the tile loop (A/B'd on one box, scripts/ab_variants.py; both on: -4.6 % at configs[2]):
+// BNN_RELU_BATCH: the 40 ReLUs of a layer in one run behind a scheduling barrier (interleaved with the next layer's MFMAs each one
+// costs an s_nop for the VALU-write -> MFMA-read hazard); BNN_BIAS_PREFETCH: accumulators are initialised with their biases a layer
+// ahead (feature_nn.2's during feature_nn.0, the next tile's feature_nn.0's before feature_nn.4), so no MFMA waits on an LDS read.
+#ifndef BNN_BIAS_PREFETCH
+#define BNN_BIAS_PREFETCH 1
+#endif
+#ifndef BNN_RELU_BATCH
+#define BNN_RELU_BATCH 1
+#endif
+
 namespace bnn {
 
 // v_mfma_f32_4x4x1_16b_f32 with CBSZ = 4: the A operand (4 neurons x 1 input) of block ABID serves all 16 blocks
@@ -63,6 +74,8 @@ constexpr size_t fwd_lds_bytes() { return sizeof(float) * (FLAT_LDS + MAXK + BIA
 template <int KIN, bool FUSED, bool NOISY, bool STATS>
 __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) {
     using WRL = WR<KIN>;
+    constexpr bool PREF = BNN_BIAS_PREFETCH && KIN == 31;   // the 41-column forms have no registers to spare for it
+    constexpr bool RBATCH = BNN_RELU_BATCH != 0;
     static_assert(!NOISY || (KIN == F && !FUSED && !STATS), "the noisy forward multiplies all 41 columns and takes materialised weights");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot, later ...
@@ -171,13 +184,23 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         float xv[KIN];
         load_row<KIN>(rowp, xv);
         asm volatile("" ::: "memory");
+        f32x4 h[10], h2[10], y[5];
+            if constexpr (PREF) {
+#pragma unroll
+        for (int n = 0; n < 10; ++n) h[n] = bq1[n];
+            }
         for (int it = 0; it < ntiles; ++it) {
             // feature_nn.0 + ReLU: MFMA m = k * 10 + n multiplies input column k into neuron group n (bias first, then the inputs in
             // ascending order: the oracle's natural order); its A operand is lanes 4(m&15).. of weight register m >> 4.
-            f32x4 h[10];
             {
+            if constexpr (PREF) {
+#pragma unroll
+                for (int n = 0; n < 10; ++n) h2[n] = bq2[n];   // next layer's accumulators start at its biases: read a layer ahead
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h[n] = bq1[n];
+            }
                 // masks, then add_input_noise (:486-504): masked columns become pure noise.  This lane's row is timestep
                 // 4*it + ph0 of system sysc0; its 41 normals are the 7 Philox blocks t*7 + 0..6, six normals each (or the explicit
                 // tensor's row).  A block is generated right in front of the six columns that consume it, so that its
@@ -200,13 +223,25 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                     }
                     const f32x4* nb = reinterpret_cast<const f32x4*>(nsc + 96 + 8 * blk);
                     const f32x4 s0 = nb[0], s1 = nb[1], k0 = nb[14], k1 = nb[15];  // scales, keep-masks (56 floats further on)
+                    float scs[6], kpf[6];
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
+                    for (int j = 0; j < 6; ++j) { scs[j] = j < 4 ? s0[j] : s1[j - 4]; kpf[j] = j < 4 ? k0[j] : k1[j - 4]; }
+#pragma unroll
+                    for (int j = 0; j < 6; j += 2) {   // column pairs: two v_and, then ONE v_pk_mul_f32 and ONE v_pk_add_f32
                         const int col = 6 * blk + j;
-                        if (col < KIN) {
-                            const float sc = j < 4 ? s0[j] : s1[j - 4], kp_ = j < 4 ? k0[j] : k1[j - 4];
-                            const float xm = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, xv[col]) & __builtin_bit_cast(uint32_t, kp_));
-                            xv[col] = xm + n6[j] * sc;   // x_masked + randn * exp(logvar / 2): a multiply, then an add (:445)
+                        if (col + 1 < KIN) {
+                            f32x2 xm;
+                            xm.x = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, xv[col]) & __builtin_bit_cast(uint32_t, kpf[j]));
+                            xm.y = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, xv[col + 1]) & __builtin_bit_cast(uint32_t, kpf[j + 1]));
+                            f32x2 nz = {n6[j], n6[j + 1]};
+                            const f32x2 sc = {scs[j], scs[j + 1]};
+                            nz = nz * sc;                 // randn * exp(logvar / 2): a multiply ...
+                            const f32x2 xs = xm + nz;     // ... then an add (:445)
+                            xv[col] = xs.x;
+                            xv[col + 1] = xs.y;
+                        } else if (col < KIN) {           // the last column stands alone (KIN is odd)
+                            const float xm = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, xv[col]) & __builtin_bit_cast(uint32_t, kpf[j]));
+                            xv[col] = xm + n6[j] * scs[j];
                         }
                     }
                 };
@@ -220,8 +255,14 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                     h[n] = mfma4b<(m & 15)>(wr[m >> 4], xv[k], h[n]);
                 });
             }
+            if constexpr (RBATCH) {
+            __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int n = 0; n < 10; ++n) h[n] = relu4(h[n]);
+            if constexpr (RBATCH) {
+            __builtin_amdgcn_sched_barrier(0);
+            }
             // x of this tile is dead: fetch the next tile's rows into the same registers (one tile of work to land)
             {
                 const int itn = (it + 1 < ntiles) ? it + 1 : it;
@@ -229,22 +270,39 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                 asm volatile("" ::: "memory");
             }
             // feature_nn.2 + ReLU: MFMA m = k * 10 + n
-            f32x4 h2[10];
             {
+            if constexpr (!PREF) {
 #pragma unroll
                 for (int n = 0; n < 10; ++n) h2[n] = bq2[n];
+            }
                 static_for<H * 10>([&](auto M) {
                     constexpr int m = M, k = m / 10, n = m % 10;
                     h2[n] = mfma4b<(m & 15)>(wr[WRL::R1 + (m >> 4)], h[k >> 2][k & 3], h2[n]);
                 });
             }
+            if constexpr (RBATCH) {
+            __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (PREF) {  // the reads land while the ReLUs below issue
+#pragma unroll
+            for (int n = 0; n < 5; ++n) y[n] = bq3[n];
+            __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int n = 0; n < 10; ++n) h2[n] = relu4(h2[n]);
+            if constexpr (RBATCH) {
+            __builtin_amdgcn_sched_barrier(0);
+            }
             // feature_nn.4: MFMA m = k * 5 + n
-            f32x4 y[5];
             {
+            if constexpr (PREF) {
+#pragma unroll
+                for (int n = 0; n < 10; ++n) h[n] = bq1[n];    // the NEXT tile's layer-1 accumulators (h is dead from here on)
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
 #pragma unroll
                 for (int n = 0; n < 5; ++n) y[n] = bq3[n];
+            }
                 static_for<H * 5>([&](auto M) {
                     constexpr int m = M, k = m / 5, n = m % 5;
                     y[n] = mfma4b<(m & 15)>(wr[WRL::R1 + WRL::R2 + (m >> 4)], h2[k >> 2][k & 3], y[n]);

@@ -188,6 +188,32 @@ def test_noisy_forward_in_kernel_noise_equals_explicit(ops, swag_states):
     assert not torch.equal(a, quiet)
 
 
+def test_input_noise_stream_statistics(ops):
+    """The input-noise stream (TAG_IN) runs Philox4x32 with 7 rounds and cuts each block into six 21-bit uniforms: 3.3e6 of its
+    normals pass a Kolmogorov-Smirnov test against N(0,1), have the right moments, and show no correlation between neighbouring
+    columns (same block), neighbouring timesteps / systems / draws (neighbouring counters)."""
+    from scipy import stats
+    R, B, T = 4, 200, 100
+    e = ops.philox_normal(3, 2024, 17, R, width=T, B=B, system_id0=5_000_000).double().cpu().numpy()   # [R,B,T,41]
+    n = e.ravel()
+    assert n.size == R * B * T * 41
+    ks = stats.kstest(n[::7], "norm")                        # a 4.7e5-sample thinning keeps the test's own resolution sensible
+    assert ks.pvalue > 1e-3, ks
+    assert abs(n.mean()) < 3e-3 and abs(n.std() - 1) < 3e-3
+    assert abs(stats.skew(n)) < 6e-3 and abs(stats.kurtosis(n)) < 1.2e-2   # 4 sigma of sqrt(6/N), sqrt(24/N)
+    assert np.abs(n).max() < 5.5 and np.abs(n).max() > 4.2   # 21-bit radius levels: reaches 5.4 sigma, no further
+
+    def corr(a, b):
+        return abs(np.corrcoef(a.ravel(), b.ravel())[0, 1])
+    bound = 4.0 / np.sqrt(n.size / 2)
+    assert corr(e[..., 0:40:2], e[..., 1:41:2]) < bound      # cos / sin partners and block neighbours
+    assert corr(e[..., :-1], e[..., 1:]) < bound
+    assert corr(e[:, :, :-1], e[:, :, 1:]) < bound           # consecutive timesteps
+    assert corr(e[:, :-1], e[:, 1:]) < bound                 # consecutive systems
+    assert corr(e[:-1], e[1:]) < bound                       # consecutive output rows
+    assert corr(e ** 2, np.roll(e, 1, axis=-1) ** 2) < bound  # no dependence in the magnitudes either
+
+
 def test_sample_with_philox_rng(swag_states, tmp_path):
     """VarModel.sample with rng='philox': same estimator, in-kernel noise; agrees statistically with the torch-rng path."""
     import json
