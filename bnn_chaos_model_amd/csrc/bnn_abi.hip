@@ -330,7 +330,10 @@ __global__ void bnn_stats_draw_kernel(const float* __restrict__ musd, int64_t R,
 // ---- streaming quantile sketch ----------------------------------------------------------------------------------
 // Per simulation (= `group` consecutive systems; min over the group first, figures/multiswag_5_planet.py:428) a histogram over
 // piecewise-uniform bins plus float64 sum / sum of squares.  hist is bin-major [nbins][n_sims] so that the threads of a wave (one
-// simulation each) touch neighbouring words.  Bin 0 collects everything below the first segment.
+// simulation each) touch neighbouring words.  Bin 0 collects everything below the first segment (reported as the segment's lower
+// edge: only there is the error unbounded; with the scripts' truncation at 4 such a value needs 40 rejected candidates in a row);
+// the LAST bin counts NaN draws (a bad seed index poisons its draws): a simulation with any NaN draw gets NaN percentiles, as
+// np.percentile would give.
 struct SketchSpec {
     int32_t nseg, nbins;
     float lo[4], hi[4], inv_w[4];
@@ -338,6 +341,7 @@ struct SketchSpec {
 };
 
 DEVINL int sketch_bin(const SketchSpec& sk, float t) {
+    if (t != t) return sk.nbins - 1;
     if (!(t >= sk.lo[0])) return 0;
     int s = 0;
     while (s + 1 < sk.nseg && t >= sk.hi[s]) ++s;
@@ -376,8 +380,9 @@ __global__ void bnn_sketch_quantiles_kernel(const uint32_t* __restrict__ hist, i
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_sims) return;
     uint64_t total = 0;
-    for (int b = 0; b < sk.nbins; ++b) total += hist[(int64_t)b * n_sims + i];
-    if (total == 0) {
+    const int nb = sk.nbins - 1;  // value bins; bin nb counts the NaN draws
+    for (int b = 0; b < nb; ++b) total += hist[(int64_t)b * n_sims + i];
+    if (total == 0 || hist[(int64_t)nb * n_sims + i] != 0) {
         for (int k = 0; k < qp.nq; ++k) out[i * qp.nq + k] = __builtin_nanf("");
         return;
     }
@@ -393,7 +398,7 @@ __global__ void bnn_sketch_quantiles_kernel(const uint32_t* __restrict__ hist, i
     }
     uint64_t c = 0;
     int seg = 0, kin = 0;  // position of bin b inside its segment
-    for (int b = 0; b < sk.nbins; ++b) {
+    for (int b = 0; b < nb; ++b) {
         const uint32_t n = hist[(int64_t)b * n_sims + i];
         double edge, width;
         if (b == 0) { edge = sk.lo[0]; width = 0.0; }
@@ -859,7 +864,7 @@ static int sketch_spec(const bnn_sketch* sk, SketchSpec* out) {
         s.inv_w[i] = (float)((double)sk->n[i] / ((double)sk->hi[i] - (double)sk->lo[i]));
         base += sk->n[i];
     }
-    s.nbins = base;
+    s.nbins = base + 1;  // + the NaN counter
     *out = s;
     return 0;
 }

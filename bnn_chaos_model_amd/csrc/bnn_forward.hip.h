@@ -25,6 +25,12 @@
 // BNN_RELU_BATCH: the 40 ReLUs of a layer in one run behind a scheduling barrier (interleaved with the next layer's MFMAs each one
 // costs an s_nop for the VALU-write -> MFMA-read hazard); BNN_BIAS_PREFETCH: accumulators are initialised with their biases a layer
 // ahead (feature_nn.2's during feature_nn.0, the next tile's feature_nn.0's before feature_nn.4), so no MFMA waits on an LDS read.
+// BNN_ABLATE (profiling builds ONLY, results are wrong by construction; scripts/ablate_r03.sh): bit 0 drops the ReLUs, bit 1 the
+// Welford pool, bit 2 the per-tile x loads (tile 0's rows are reused), bit 3 everything after the tile loop (merge, sampled
+// moments, regress_nn, soft_clamp).  The time each removal saves is that part's cost in the real kernel (profiles/r03_ablation_c3.txt).
+#ifndef BNN_ABLATE
+#define BNN_ABLATE 0
+#endif
 #ifndef BNN_BIAS_PREFETCH
 #define BNN_BIAS_PREFETCH 1
 #endif
@@ -258,17 +264,21 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
             if constexpr (RBATCH) {
             __builtin_amdgcn_sched_barrier(0);
             }
+#if !(BNN_ABLATE & 1)
 #pragma unroll
             for (int n = 0; n < 10; ++n) h[n] = relu4(h[n]);
+#endif
             if constexpr (RBATCH) {
             __builtin_amdgcn_sched_barrier(0);
             }
             // x of this tile is dead: fetch the next tile's rows into the same registers (one tile of work to land)
+#if !(BNN_ABLATE & 4)
             {
                 const int itn = (it + 1 < ntiles) ? it + 1 : it;
                 load_row<KIN>(rowp + (int64_t)itn * 4 * F, xv);
                 asm volatile("" ::: "memory");
             }
+#endif
             // feature_nn.2 + ReLU: MFMA m = k * 10 + n
             {
             if constexpr (!PREF) {
@@ -288,8 +298,10 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
             for (int n = 0; n < 5; ++n) y[n] = bq3[n];
             __builtin_amdgcn_sched_barrier(0);
             }
+#if !(BNN_ABLATE & 1)
 #pragma unroll
             for (int n = 0; n < 10; ++n) h2[n] = relu4(h2[n]);
+#endif
             if constexpr (RBATCH) {
             __builtin_amdgcn_sched_barrier(0);
             }
@@ -309,6 +321,10 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                 });
             }
             // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
+#if BNN_ABLATE & 2
+#pragma unroll
+            for (int n = 0; n < 5; ++n) asm volatile("" : : "v"(y[n]));   // the latents stay computed, nothing consumes them
+#else
             const float rcn = p.rcp_tab[it];
 #pragma unroll
             for (int n = 0; n < 5; ++n)
@@ -319,7 +335,16 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                     m2[n][i] = fmaf(dl, y[n][i] - mn, m2[n][i]);
                     mean[n][i] = mn;
                 }
+#endif
         }
+#if BNN_ABLATE & 8
+        {
+#pragma unroll
+            for (int n = 0; n < 5; ++n) { asm volatile("" : : "v"(mean[n])); asm volatile("" : : "v"(m2[n])); }
+            if (valid0 && ph0 == 0) p.out[(r * p.B + sys0) * 2] = mean[0][0];
+            continue;
+        }
+#endif
 
         // Everything below the tile loop works from coordinates RE-derived here from a laundered copy of the lane id, so that
         // none of them (system ids, validity, pointers) is kept in a register -- or spilled -- across the loop.

@@ -165,10 +165,12 @@ DEVINL void lowp_next_operand(const f32x4 (&acc)[3], Frag<NS>& b0, Frag<NS>& b1)
     for (int p = 0; p < NS; ++p) b1.part[p][1] = pk[p];
 }
 
-// per wave: [XST] x-tile staging buffer (4 systems x 4 rows x 41 floats = 656; doubles as the Philox scratch of the finish)
-// + [16 * S2] summaries of the wave-batch
-constexpr int XST = 4 * 4 * F;                     // 656 floats, a multiple of 4
-constexpr int SCRL = XST + 16 * S2 + 4;            // + one float that holds the constant 1.0 of the bias slot (padded to 16 B)
+// per wave: [XST] x-tile staging buffer (8 chunks x 16 rows x 16 B = 512 floats; doubles as the Philox scratch of the finish, which
+// needs 16 * S2 = 640) + [16 * S2] summaries of the wave-batch
+constexpr int XST = 16 * S2;                       // 640 floats
+constexpr int SCRL = XST + 16 * S2;
+// staged tile, chunk-major with an XOR swizzle: 16-byte slot of (chunk k, row r) = 16 k + (r ^ (k & 3))
+DEVINL int xslot(int k, int r) { return 16 * k + (r ^ (k & 3)); }
 constexpr size_t lowp_lds_bytes() { return sizeof(float) * (FLAT_LDS + 4 * SCRL); }
 
 template <int NS, bool H>
@@ -245,24 +247,24 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
     float* epsscr = scr + wave * SCRL;  // Philox normals of the finish; the x-tile staging buffer during the tile loop
     float* sumscr = epsscr + XST;
     float* xst = epsscr;
-    float* one_slot = sumscr + 16 * S2;
-    if (lane == 0) one_slot[0] = 1.0f;
-    static_assert(XST >= 16 * S2 && XST % 4 == 0, "staging buffer covers the Philox scratch and stays 16-byte aligned");
+    static_assert(XST >= 8 * 16 * 4 && XST >= 16 * S2 && XST % 4 == 0, "staging buffer covers the tile and the Philox scratch, 16-byte aligned");
     // x tile staging (global -> registers -> LDS -> fragment registers).  A lane's fragment is 8 floats of ONE row, and lanes
     // that are neighbours in the wave hold DIFFERENT rows (164 B apart), so loading fragments straight from global memory makes
     // every lane touch its own cache line: 64 lines per wave-instruction, and the kernel ran at exactly one tile per ~190 cycles
-    // per CU -- the L1's rate for that pattern, not the matrix or vector pipes'.  The four systems' 4-row spans of a tile are each
-    // 656 contiguous, 16-byte-aligned bytes: 164 chunks of 16 B, fetched by consecutive lanes (3 loads per lane, the last one
-    // partly idle), written to LDS as they are, and read back per fragment.
-    int stq[3];  // chunk id -> (span = system of the tile, offset within the span) for the three rounds; -1 = no chunk
-    int sto[3];
-#pragma unroll
-    for (int rnd = 0; rnd < 3; ++rnd) {
-        const int q = lane + 64 * rnd;
-        stq[rnd] = q < 4 * F ? q / F : -1;
-        sto[rnd] = 4 * (q % F);
-    }
-
+    // per CU -- the L1's rate for that pattern, not the matrix or vector pipes'.  So a tile is fetched by ROW CHUNKS: the 16 rows
+    // (4 systems x 4 timesteps) x 8 chunks of 16 B = columns 8..11, ..., 32..35 and [36, 37, column 0, 1.0] -- exactly the four
+    // k-groups' fragments (chunks 2g, 2g + 1), group 3's "column 0" and "constant 1.0 of the bias slot" taking the places of the
+    // dead columns 38, 39 -- two chunks per lane: round 0 chunks 0..3, round 1 chunks 4..7; four consecutive lanes read 64
+    // consecutive bytes of a row.
+    // LDS layout and banks (MI355X_MICROARCH.md, LDS): ds_read_b128 is served in four 16-lane groups over 64 banks (16 slots of
+    // 16 B), each group holding every row c exactly once (with two different k-groups g); ds_write_b128 in eight groups of 8
+    // contiguous lanes over 32 banks (8 slots).  Slot of (chunk k, row r) = 16 k + (r ^ (k & 3)):
+    //   reads:  slot mod 16 = c ^ (k & 3): the XOR permutes rows inside aligned blocks of 4, so the 16 rows of a group stay
+    //           16 different slots whatever chunks its lanes read -> conflict-free;
+    //   writes: an 8-lane group stores rows {ra, ra + 4} x chunks {kb .. kb + 3}: slot mod 8 = ((ra & 3) ^ q) | 4 h, all different
+    //           -> conflict-free.   (Round 2 staged rows verbatim at their 41-float stride: 27 % of the LDS cycles were conflicts.)
+    const int sq4 = lane & 3, sh = (lane >> 2) & 1, su = lane >> 3;
+    const int srow = (su & 3) + 8 * (su >> 2) + 4 * sh;   // this lane's staging row; its chunks: sq4 (round 0) and 4 + sq4 (round 1)
     for (int64_t wb0 = b0 + (int64_t)wave * 16; wb0 < b1; wb0 += 64) {
         for (int sb = 0; sb < 4; ++sb) {  // four tiles' worth of systems: wb0 + 4 sb + sq
             if (wb0 + 4 * sb >= b1) break;  // wave-uniform
@@ -272,35 +274,39 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
             // staging chunk addresses = wave-uniform base of the tile (scalar registers, advanced on the scalar unit) + a per-lane
             // 32-bit offset that does not change over the tiles: no vector address arithmetic in the loop
             const float* tbase = p.x + (wb0 + 4 * sb) * rowstride;
-            uint32_t soff[3];
-#pragma unroll
-            for (int rnd = 0; rnd < 3; ++rnd) {
-                int64_t ss = wb0 + 4 * sb + (stq[rnd] < 0 ? 0 : stq[rnd]);
-                ss = ss < b1 ? ss : b1 - 1;  // >= wb0 + 4 sb: the offset is not negative
-                soff[rnd] = (uint32_t)((ss - (wb0 + 4 * sb)) * rowstride + sto[rnd]);
+            uint32_t soff, soff0;   // offset of this lane's chunk 0 of the row (column 8 + 4 sq4), offset of the row's column 0
+            {
+                int64_t ss = wb0 + 4 * sb + (srow >> 2);           // row = 4 * (system of the tile) + timestep phase
+                ss = ss < b1 ? ss : b1 - 1;                         // >= wb0 + 4 sb: the offset is not negative
+                soff0 = (uint32_t)((ss - (wb0 + 4 * sb)) * rowstride + (srow & 3) * F);
+                soff = soff0 + 8 + 4 * sq4;
             }
-            // this lane's fragment in the staging buffer: 6 floats at column 8 + 8g of its row, then (groups 0-2) the next two
-            // or (group 3) column 0 and the constant 1.0 -- per-lane addresses instead of selects on the loaded values
-            const float* fr = xst + sq * (4 * F) + tph * F;
-            const float* fr6 = g == 3 ? fr : fr + 8 + 8 * g + 6;
-            const float* fr7 = g == 3 ? one_slot : fr + 8 + 8 * g + 7;
+            // this lane's fragment in the staging buffer: chunks 2g and 2g + 1 of its row c
+            const f32x4* fr0 = reinterpret_cast<const f32x4*>(xst) + xslot(2 * g, c);
+            const f32x4* fr1 = reinterpret_cast<const f32x4*>(xst) + xslot(2 * g + 1, c);
+            f32x4* const st0 = reinterpret_cast<f32x4*>(xst) + xslot(sq4, srow);
+            f32x4* const st1 = reinterpret_cast<f32x4*>(xst) + xslot(4 + sq4, srow);
 
             f32x4 mean0 = {0, 0, 0, 0}, m20 = {0, 0, 0, 0}, mean1 = {0, 0, 0, 0}, m21 = {0, 0, 0, 0};
             // Three tiles are kept in flight per wave (one tile = 2.6 KB; with ONE in flight the kernel ran at exactly
             // tile bytes / loaded memory latency (~2 200 cycles) per wave, whatever the arithmetic): three register slots P, Q, R
             // rotate by unrolling the tile loop three times.
             constexpr int DEPTH = NS == 3 ? 1 : 3;  // the six-product form has no registers to spare (and is bound by its arithmetic)
-            f32x4 s0[3], s1[3], s2[3];
-            auto fetch = [&](int it, f32x4 (&slot)[3]) {
+            struct Slot { f32x4 v[2]; float c0; };
+            Slot s0, s1, s2;
+            auto fetch = [&](int it, Slot& slot) {
                 const int itc = it < ntiles ? it : ntiles - 1;
-#pragma unroll
-                for (int rnd = 0; rnd < 3; ++rnd)
-                    if (stq[rnd] >= 0) slot[rnd] = *reinterpret_cast<const f32x4*>(tbase + (int64_t)itc * 4 * F + soff[rnd]);
+                const float* tb = tbase + (int64_t)itc * 4 * F;
+                slot.v[0] = *reinterpret_cast<const f32x4u*>(tb + soff);        // columns 8 + 4 sq4 ..
+                slot.v[1] = *reinterpret_cast<const f32x4u*>(tb + soff + 16);   // columns 24 + 4 sq4 .. (sq4 = 3: 36..39)
+                slot.c0 = tb[soff0];
             };
-            auto stage = [&](const f32x4 (&slot)[3]) {
-#pragma unroll
-                for (int rnd = 0; rnd < 3; ++rnd)
-                    if (stq[rnd] >= 0) *reinterpret_cast<f32x4*>(xst + 4 * (lane + 64 * rnd)) = slot[rnd];
+            auto stage = [&](const Slot& slot) {
+                f32x4 v = slot.v[1];
+                v.z = sq4 == 3 ? slot.c0 : v.z;   // chunk 7 = [36, 37, column 0, 1.0]
+                v.w = sq4 == 3 ? 1.0f : v.w;
+                *st0 = slot.v[0];
+                *st1 = v;
             };
             fetch(0, s0);
             if constexpr (DEPTH == 3) {
@@ -315,16 +321,15 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
                 Bs1.part[q][3] = 0u;
             }
             // one tile: LDS holds tile `it`; P holds tile it+1, R is free (gets tile it+3); at the end P goes to LDS
-            auto tile = [&](int it, const f32x4 (&P)[3], f32x4 (&R)[3]) {
+            auto tile = [&](int it, const Slot& P, Slot& R) {
 
                 // layer-1 B operand from the staged tile: 8 floats of this lane's row at column 8 + 8g (group 3: 32..37, then
-                // column 0 and the constant 1.0 of the bias slot)
+                // column 0 and the constant 1.0 of the bias slot, put there by stage())
                 Frag<NS> B1;
                 {
-                    float v[6];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) v[j] = fr[8 + 8 * g + j];
-                    const float v6 = *fr6, v7 = *fr7;
+                    const f32x4 va = *fr0, vb = *fr1;     // two conflict-free ds_read_b128
+                    const float v[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
+                    const float v6 = vb.z, v7 = vb.w;
                     uint32_t pk[NS];
                     split_pair<NS, H>(v[0], v[1], pk);
 #pragma unroll

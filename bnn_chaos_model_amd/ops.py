@@ -91,6 +91,17 @@ def swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, scale=0.5, philo
 
 
 PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16": 4, "f16x3": 5}
+HALF_FORMS = ("f16", "f16x3")
+HALF_MAX = 65504.0
+
+
+def half_range_exceeded(x, zero_mask=V50_ZERO_MASK):
+    """Rows of x [B,T,41] that the IEEE-half forms ("f16", "f16x3") cannot represent: a live column holds |v| >= 65 504.  Those
+    forms SATURATE such values (MODE.FP16_OVFL), so the affected systems get finite but wrong outputs -- e.g. the 5-planet script's
+    constant-4 fill of unstable systems standardises the mass columns to 1.9e5 (figures/multiswag_5_planet.py:215).  Returns a bool
+    tensor [B] on x's device (no host sync; `.any().item()` is the caller's).  The bfloat16 forms have fp32's range."""
+    live = [c for c in range(41) if not (int(zero_mask) >> c) & 1]
+    return (x[..., live].abs() >= HALF_MAX).flatten(1).any(1)
 
 
 @_on_device_of(0)
@@ -102,7 +113,9 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     eps_in [R,B,T,41] + eps_sum [R,B,40] switch on noisy_val=True (:444-450); noisy=True with no noise tensors at all
     is noisy_val=True with every normal generated in-kernel (Philox).
     precision: "f32" (default: the parity path) or the OPT-IN reduced-precision forms "bf16" / "bf16x3" / "bf16x6" / "f16" /
-    "f16x3" (feature_nn on the bf16 / half matrix pipe; BASELINE configs[4] sweep; v50 mask, quiet forward only)."""
+    "f16x3" (feature_nn on the bf16 / half matrix pipe; BASELINE configs[4] sweep; v50 mask, quiet forward only).
+    PRECONDITION of "f16" / "f16x3": |x| < 65 504 in the live columns (half_range_exceeded(x) names the rows that violate it;
+    their outputs are finite but wrong).  This op never synchronises, so it does not check; the FeatureRegressor surface does."""
     plan = plan or get_plan()
     x, W = _f32(x, "x"), _f32(W, "W")
     if x.dim() != 3 or x.shape[2] != 41:

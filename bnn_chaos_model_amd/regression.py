@@ -115,7 +115,10 @@ class FeatureRegressor(object):
         (one randint + randn((1,d)) + randn((K,1)) + 2 randn_like([Bc,20]) per chunk per sample);
         rng="philox" draws the seed picks from numpy and everything else in-kernel.
         precision: "f32" (the parity path) or an OPT-IN reduced-precision form of ops.forward ("f16x3": fp32-level error at ~1.9x
-        the throughput; "bf16", "f16", ...: approximate) -- DESIGN.md section 4.6."""
+        the throughput; "bf16", "f16", ...: approximate) -- DESIGN.md section 4.6.  The IEEE-half forms ("f16", "f16x3") require
+        |X| < 65 504 in the live columns: rows beyond that (e.g. the script's constant-4 fill of unstable systems,
+        figures/multiswag_5_planet.py:215) get finite but WRONG outputs; this method checks and warns (RuntimeWarning, with the
+        number of rows); use a bfloat16 form ("bf16x6": fp32 range and fp32-level error) or "f32" for such inputs."""
         if X.dim() != 3 or X.shape[-1] != 41:
             raise NotImplementedError("X must be [B, T, 41]")
         g = _gpu()
@@ -133,6 +136,12 @@ class FeatureRegressor(object):
             raise NotImplementedError("unexpected torch.chunk partition")
         J = samples * nch
         xg = X.detach().to(g, torch.float32).contiguous()
+        if precision in ops.HALF_FORMS:
+            nbad = int(ops.half_range_exceeded(xg, m0.zero_mask()).sum())
+            if nbad:
+                import warnings
+                warnings.warn(f"precision={precision!r}: {nbad} of {B} rows hold |x| >= 65504 in a live column; IEEE half saturates there and "
+                              "the outputs of those rows are wrong (finite); use 'bf16x6' or 'f32' for them", RuntimeWarning, stacklevel=2)
         noise_dev = g if self.cuda else torch.device("cpu")
         seed_idx = np.empty(J, np.int32)
         if rng == "torch":

@@ -231,18 +231,20 @@ int bnn_multiswag_stats_f32(const bnn_plan* plan, const bnn_grid* grid, const fl
                             float* W_workspace, const bnn_stats* st, float* t_out, void* stream);
 
 /* Streaming per-simulation quantile sketch: min over `group` consecutive systems (min over trios, :428), then a histogram over
- * 1..4 contiguous uniform segments (bin 0 = below lo[0]; values at or above the last hi fall in the last bin) and float64
+ * 1..4 contiguous uniform segments (bin 0 = below lo[0], reported as lo[0] -- the one place where the error is not bounded by a
+ * bin width; values at or above the last hi fall in the last value bin; the very last bin counts NaN draws) and float64
  * sum / sum of squares.  hist [nbins, n_sims] uint32 (bin-major), mom [n_sims, 2] float64, both zeroed by the caller and
  * accumulated over any number of slabs t [R,B].  Memory is O(n_sims * nbins) whatever the number of draws.
  * bnn_sketch_quantiles_f32: numpy 'linear' percentiles (np.median / np.percentile of :484-489, main_figures.py:277-278)
- * read off the histogram; every estimate lies within one bin width of the exact order statistic.  out [n_sims, nq]. */
+ * read off the histogram; every estimate lies within one bin width of the exact order statistic (draws below lo[0] excepted);
+ * a simulation with any NaN draw gets NaN percentiles, like np.percentile.  out [n_sims, nq]. */
 typedef struct bnn_sketch {
     int32_t nseg;
     int32_t reserved;
     float lo[4], hi[4];
     int32_t n[4];
 } bnn_sketch;
-int bnn_sketch_bins(const bnn_sketch* sk); /* total bins (1 + sum n), or negative */
+int bnn_sketch_bins(const bnn_sketch* sk); /* total bins (1 + sum n + 1: underflow, values, NaN counter), or negative */
 int bnn_sketch_update_u32(const float* t, int64_t R, int64_t B, int32_t group, const bnn_sketch* sk, uint32_t* hist, double* mom,
                           void* stream);
 int bnn_sketch_quantiles_f32(const uint32_t* hist, int64_t n_sims, const bnn_sketch* sk, const double* host_q, int32_t nq,

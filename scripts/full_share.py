@@ -59,7 +59,7 @@ elif which == "c4q":
     assert bands.shape == (B, 6) and torch.isfinite(bands).all()
     print(f"c4q share: {B} systems x {J} draws = {B * J:.3g} evals -> bands [B,5] + mean in {dt:.2f} s = {B * J / dt:.4g} evals/s; "
           f"peak GPU memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB (x = {x.numel() * 4 / 2**30:.1f} GiB, sketch = "
-          f"{945 * 4 * B / 2**30:.1f} GiB)", flush=True)
+          f"{946 * 4 * B / 2**30:.1f} GiB)", flush=True)
 elif which == "c5q":
     import numpy as np
     B, chunks, samples, trios = 375_000, 10, 100, 3

@@ -150,3 +150,25 @@ def test_half_forms_saturate_out_of_range_inputs(ops, inputs):
         assert torch.isfinite(o).all()
     o = ops.forward(dev(x), dev(z["w"][None]), eps=dev(eps), precision="bf16x6").cpu().numpy()[0]
     assert (np.abs(o - z["out"]) <= 1e-5 * np.abs(z["out"])).all()
+    # the precondition is checkable: half_range_exceeded names the rows, the 'slow' inputs have none
+    bad = ops.half_range_exceeded(dev(x))
+    assert bad.shape == (x.shape[0],) and bool(bad.all())
+    assert not bool(ops.half_range_exceeded(dev(inputs["slow"])).any())
+
+
+def test_surface_warns_when_half_cannot_hold_the_inputs(swag_states, tmp_path, inputs):
+    import json
+    import warnings
+    from bnn_chaos_model_amd import checkpoint
+    from bnn_chaos_model_amd.regression import FeatureRegressor
+    z = load_golden("swag_v50_0.npz")
+    checkpoint.write_swag_file(str(tmp_path / "s_v50_00_output.pkl"), json.loads(str(z["hparams_json"])), json.loads(str(z["swa_params_json"])),
+                               torch.tensor(z["w_avg"]), torch.tensor(z["w2_avg"]), torch.tensor(z["pre_D"]))
+    fr = FeatureRegressor(cuda=False, filebase=str(tmp_path / "*v50*output.pkl"), sort=True)
+    x = torch.tensor(np.concatenate([inputs["slow"][:4], inputs["const4"][:2]]))
+    with pytest.warns(RuntimeWarning, match="2 of 6 rows"):
+        fr.sample_full_swag_many(x, samples=2, rng="philox", precision="f16x3")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        fr.sample_full_swag_many(x, samples=2, rng="philox", precision="bf16x6")   # fp32 range: nothing to warn about
+        fr.sample_full_swag_many(x[:4], samples=2, rng="philox", precision="f16x3")

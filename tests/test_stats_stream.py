@@ -114,6 +114,15 @@ def test_sketch_against_exact_percentiles_small(ops):
     sk2.update(torch.tensor([[3.0, 4.5, 4.5, 4.5], [3.5, 4.5, 4.5, 4.5], [5.0, 4.5, 4.5, 4.5]]).cuda())
     got2 = sk2.percentiles((0.0, 50.0, 100.0)).cpu().numpy()
     assert got2[0, 0] == 4.0 and got2[0, 1] == 4.0 and abs(got2[0, 2] - 5.0) < 1 / 128 and abs(got2[1, 1] - 4.5) < 1 / 128
+    # a NaN draw (a bad seed index poisons its draws) makes THAT simulation's percentiles and mean NaN, as np.percentile would;
+    # the other simulations are untouched
+    sk3 = ops.QuantileSketch(6, group=3)
+    t3 = torch.tensor([[5.0, 6.0, 7.0, 5.5, 6.5, 7.5], [5.0, float("nan"), 7.0, 5.5, 6.5, 7.5], [5.0, 6.0, 7.0, 5.5, 6.5, 7.5]]).cuda()
+    sk3.update(t3)
+    got3 = sk3.percentiles((16.0, 50.0, 84.0)).cpu().numpy()
+    assert np.isnan(got3[0]).all() and np.isnan(sk3.mean().cpu().numpy()[0])
+    assert np.abs(got3[1] - 5.5).max() < 1 / 128 and abs(sk3.mean().cpu().numpy()[1] - 5.5) < 1e-12
+    assert int(sk3.hist[-1].sum()) == 1 and int(sk3.hist.sum()) == 6     # the last bin is the NaN counter
 
 
 def test_streaming_bands_at_configs1_size(ops, ens):
@@ -192,3 +201,60 @@ def test_native_slab_drivers(ops, ens):
     assert z.shape == (B, 4) and (z == 0).all()
     with pytest.raises(ValueError):
         ops.multiswag_bands(x, wa, w2, pd, idx, ops.QuantileSketch(B - 3, group=3))
+
+
+def test_streamed_bands_agree_with_the_reference_replay_statistically(ops, ens):
+    """The link between the STREAMED epilogue (Philox candidates, exact erfc survival table, quantile sketch) and the reference's
+    own arithmetic (the numpy-replay kernels of bnn_chaos_model_amd/stats.py, bit-identical to the reference's source fragments,
+    figures/multiswag_5_planet.py:388-428, 484-489): on the SAME [R, B, 2] (mu, std) samples, R = 4000 draws of 100 simulations x 3
+    trios, the two pipelines are independent Monte-Carlo estimates of the same per-simulation distribution, so every band must
+    agree within   sketch bin width  +  z = 5 sigma of the order-statistic sampling error of the DIFFERENCE of two estimates.
+    The sampling error is taken distribution-free from the replay sample itself: the q-quantile of R draws lies between the
+    order statistics of ranks R q -+ z sqrt(2 R q (1 - q)) (binomial), so the bound is that rank interval's width."""
+    from scipy import stats as sst
+    from bnn_chaos_model_amd import stats
+    wa, w2, pd = ens
+    R, sims, trios = 4000, 100, 3
+    B = sims * trios
+    x = synth(B, 2718)
+    idx = torch.as_tensor((np.arange(R) % 2).astype(np.int32)).cuda()
+    musd = ops.multiswag(x, wa, w2, pd, idx, philox_seed=31)                       # [R, B, 2]
+    q = (2.5, 16.0, 50.0, 84.0, 97.5)
+    # (a) the reference's pipeline, numpy generator consumed exactly as the script does
+    np.random.seed(12345)
+    samps = stats.fast_truncnorm(musd, left=4, nsamp=40, d=10000)                  # :388-392
+    samps = stats.resample_prior(samps)                                            # :396-422
+    outs = stats.min_over_trios(samps.reshape(R, sims, trios))                     # :428 -> [sims, R]
+    ref = stats.percentiles(outs, q).double().cpu().numpy()                        # :484-489
+    ref_mean = outs.double().mean(1).cpu().numpy()
+    # (b) the streamed pipeline
+    t = ops.stats_draw(musd, philox_seed=77)
+    sk = ops.QuantileSketch(B, group=trios)
+    for r0 in range(0, R, 500):
+        sk.update(t[r0:r0 + 500].contiguous())
+    got = sk.percentiles(q).double().cpu().numpy()
+    got_mean = sk.mean().cpu().numpy()
+    # bound per (simulation, band)
+    z = 5.0
+    srt = np.sort(outs.double().cpu().numpy(), axis=1)                             # [sims, R]
+    worst = 0.0
+    for k, qq in enumerate(q):
+        p = qq / 100.0
+        half = z * np.sqrt(2.0 * R * p * (1 - p))
+        lo = np.clip(np.floor(R * p - half).astype(int), 0, R - 1)
+        hi = np.clip(np.ceil(R * p + half).astype(int), 0, R - 1)
+        bound = (srt[:, hi] - srt[:, lo]) + np.vectorize(sk.resolution)(ref[:, k])
+        err = np.abs(got[:, k] - ref[:, k])
+        worst = max(worst, (err / bound).max())
+        assert (err <= bound).all(), (qq, err.max(), bound[err.argmax()])
+    sd = srt.std(1)
+    assert (np.abs(got_mean - ref_mean) <= z * np.sqrt(2.0) * sd / np.sqrt(R)).all()
+    # and element-wise: the two samples of post-epilogue times have the same distribution on both legs (two-sample K-S, alpha = 1e-3)
+    a = samps.cpu().numpy().ravel()[::3]       # the same (draw, system) elements in both: each pair of entries is two independent
+    b = t.cpu().numpy().ravel()[::3]           # draws from the same conditional distribution, so the pooled samples match in law
+    for leg in (lambda v: v[v < 9], lambda v: v[v >= 9]):
+        va, vb = leg(a), leg(b)
+        assert min(va.size, vb.size) > 10_000
+        ks = sst.ks_2samp(va, vb)
+        assert ks.statistic < 1.95 * np.sqrt((va.size + vb.size) / (va.size * vb.size)), ks
+    assert abs((a >= 9).mean() - (b >= 9).mean()) < 5 * np.sqrt(0.5 / a.size)       # the same share of draws reaches the prior
