@@ -22,9 +22,8 @@
 #include "bnn_stats.hip.h"
 
 // Build-time switches of the tile loop (A/B'd on one box, scripts/ab_variants.py; both on: -4.6 % at configs[2]):
-// BNN_RELU_BATCH: the 40 ReLUs of a layer in one run behind a scheduling barrier (interleaved with the next layer's MFMAs each one
-// costs an s_nop for the VALU-write -> MFMA-read hazard); BNN_BIAS_PREFETCH: accumulators are initialised with their biases a layer
-// ahead (feature_nn.2's during feature_nn.0, the next tile's feature_nn.0's before feature_nn.4), so no MFMA waits on an LDS read.
+// BNN_RELU_BATCH: the 40 ReLUs of a layer in one run behind a scheduling barrier; BNN_BIAS_PREFETCH: accumulators are initialised
+// with their biases a layer ahead (31-column forms only: the 41-column forms have no registers to spare).
 // BNN_ABLATE (profiling builds ONLY, results are wrong by construction; scripts/ablate_r03.sh): bit 0 drops the ReLUs, bit 1 the
 // Welford pool, bit 2 the per-tile x loads (tile 0's rows are reused), bit 3 everything after the tile loop (merge, sampled
 // moments, regress_nn, soft_clamp).  The time each removal saves is that part's cost in the real kernel (profiles/r03_ablation_c3.txt).
@@ -190,23 +189,39 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         float xv[KIN];
         load_row<KIN>(rowp, xv);
         asm volatile("" ::: "memory");
+        // Accumulators of the three layers.  An accumulator chain starts at its bias (C operand of its first MFMA), read from the LDS
+        // bias image.  With PREF the reads run a layer ahead of their first use: feature_nn.2's biases are fetched at the top of
+        // feature_nn.0, feature_nn.4's behind feature_nn.2's last MFMA (they land while its ReLUs issue), the NEXT tile's
+        // feature_nn.0 biases at the top of feature_nn.4 -- no MFMA ever waits on an LDS read.  sched_barrier(0) pins each group of
+        // reads (and each batch of ReLUs) where it is written; the scheduler otherwise sinks them to just in front of their use.
         f32x4 h[10], h2[10], y[5];
-            if constexpr (PREF) {
+        auto bias10 = [&](f32x4 (&acc)[10], const f32x4* bq) {
 #pragma unroll
-        for (int n = 0; n < 10; ++n) h[n] = bq1[n];
-            }
+            for (int n = 0; n < 10; ++n) acc[n] = bq[n];
+        };
+        auto bias5 = [&](f32x4 (&acc)[5], const f32x4* bq) {
+#pragma unroll
+            for (int n = 0; n < 5; ++n) acc[n] = bq[n];
+        };
+        auto relu10 = [&](f32x4 (&acc)[10]) {   // the 40 ReLUs of a layer in one run (RBATCH): interleaved with the next layer's MFMAs,
+            if constexpr (RBATCH) __builtin_amdgcn_sched_barrier(0);   // each would cost an s_nop for the VALU-write -> MFMA-read hazard
+#if !(BNN_ABLATE & 1)
+#pragma unroll
+            for (int n = 0; n < 10; ++n) acc[n] = relu4(acc[n]);
+#endif
+            if constexpr (RBATCH) __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (PREF) bias10(h, bq1);
         for (int it = 0; it < ntiles; ++it) {
             // feature_nn.0 + ReLU: MFMA m = k * 10 + n multiplies input column k into neuron group n (bias first, then the inputs in
             // ascending order: the oracle's natural order); its A operand is lanes 4(m&15).. of weight register m >> 4.
             {
-            if constexpr (PREF) {
-#pragma unroll
-                for (int n = 0; n < 10; ++n) h2[n] = bq2[n];   // next layer's accumulators start at its biases: read a layer ahead
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-#pragma unroll
-                for (int n = 0; n < 10; ++n) h[n] = bq1[n];
-            }
+                if constexpr (PREF) {
+                    bias10(h2, bq2);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    bias10(h, bq1);
+                }
                 // masks, then add_input_noise (:486-504): masked columns become pure noise.  This lane's row is timestep
                 // 4*it + ph0 of system sysc0; its 41 normals are the 7 Philox blocks t*7 + 0..6, six normals each (or the explicit
                 // tensor's row).  A block is generated right in front of the six columns that consume it, so that its
@@ -229,6 +244,8 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                     }
                     const f32x4* nb = reinterpret_cast<const f32x4*>(nsc + 96 + 8 * blk);
                     const f32x4 s0 = nb[0], s1 = nb[1], k0 = nb[14], k1 = nb[15];  // scales, keep-masks (56 floats further on)
+                    // (indexed access only: __builtin_bit_cast of a swizzle member such as k0.y was miscompiled by hipcc 7.2 -- every
+                    // column got k0.x's mask)
                     float scs[6], kpf[6];
 #pragma unroll
                     for (int j = 0; j < 6; ++j) { scs[j] = j < 4 ? s0[j] : s1[j - 4]; kpf[j] = j < 4 ? k0[j] : k1[j - 4]; }
@@ -261,65 +278,36 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                     h[n] = mfma4b<(m & 15)>(wr[m >> 4], xv[k], h[n]);
                 });
             }
-            if constexpr (RBATCH) {
-            __builtin_amdgcn_sched_barrier(0);
-            }
-#if !(BNN_ABLATE & 1)
-#pragma unroll
-            for (int n = 0; n < 10; ++n) h[n] = relu4(h[n]);
-#endif
-            if constexpr (RBATCH) {
-            __builtin_amdgcn_sched_barrier(0);
-            }
-            // x of this tile is dead: fetch the next tile's rows into the same registers (one tile of work to land)
+            relu10(h);
 #if !(BNN_ABLATE & 4)
-            {
-                const int itn = (it + 1 < ntiles) ? it + 1 : it;
-                load_row<KIN>(rowp + (int64_t)itn * 4 * F, xv);
-                asm volatile("" ::: "memory");
-            }
+            // x of this tile is dead: fetch the next tile's rows into the same registers, one tile of work to land.  All nine loads in
+            // ONE burst: spread over the MFMAs of feature_nn.2 (one per 20 or 36) the kernel measured 14-20 % SLOWER
+            // (profiles/r03_ab_variants.txt).
+            load_row<KIN>(rowp + (int64_t)((it + 1 < ntiles) ? it + 1 : it) * 4 * F, xv);
+            asm volatile("" ::: "memory");
 #endif
             // feature_nn.2 + ReLU: MFMA m = k * 10 + n
-            {
-            if constexpr (!PREF) {
-#pragma unroll
-                for (int n = 0; n < 10; ++n) h2[n] = bq2[n];
-            }
-                static_for<H * 10>([&](auto M) {
-                    constexpr int m = M, k = m / 10, n = m % 10;
-                    h2[n] = mfma4b<(m & 15)>(wr[WRL::R1 + (m >> 4)], h[k >> 2][k & 3], h2[n]);
-                });
-            }
-            if constexpr (RBATCH) {
-            __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (PREF) {  // the reads land while the ReLUs below issue
-#pragma unroll
-            for (int n = 0; n < 5; ++n) y[n] = bq3[n];
-            __builtin_amdgcn_sched_barrier(0);
-            }
-#if !(BNN_ABLATE & 1)
-#pragma unroll
-            for (int n = 0; n < 10; ++n) h2[n] = relu4(h2[n]);
-#endif
-            if constexpr (RBATCH) {
-            __builtin_amdgcn_sched_barrier(0);
-            }
-            // feature_nn.4: MFMA m = k * 5 + n
-            {
+            if constexpr (!PREF) bias10(h2, bq2);
+            static_for<H * 10>([&](auto M) {
+                constexpr int m = M, k = m / 10, n = m % 10;
+                h2[n] = mfma4b<(m & 15)>(wr[WRL::R1 + (m >> 4)], h[k >> 2][k & 3], h2[n]);
+            });
             if constexpr (PREF) {
-#pragma unroll
-                for (int n = 0; n < 10; ++n) h[n] = bq1[n];    // the NEXT tile's layer-1 accumulators (h is dead from here on)
+                __builtin_amdgcn_sched_barrier(0);
+                bias5(y, bq3);   // lands while the ReLUs below issue
+            }
+            relu10(h2);
+            // feature_nn.4: MFMA m = k * 5 + n
+            if constexpr (PREF) {
+                bias10(h, bq1);  // the NEXT tile's feature_nn.0 accumulators (h is dead from here on)
                 __builtin_amdgcn_sched_barrier(0);
             } else {
-#pragma unroll
-                for (int n = 0; n < 5; ++n) y[n] = bq3[n];
+                bias5(y, bq3);
             }
-                static_for<H * 5>([&](auto M) {
-                    constexpr int m = M, k = m / 5, n = m % 5;
-                    y[n] = mfma4b<(m & 15)>(wr[WRL::R1 + WRL::R2 + (m >> 4)], h2[k >> 2][k & 3], y[n]);
-                });
-            }
+            static_for<H * 5>([&](auto M) {
+                constexpr int m = M, k = m / 5, n = m % 5;
+                y[n] = mfma4b<(m & 15)>(wr[WRL::R1 + WRL::R2 + (m >> 4)], h2[k >> 2][k & 3], y[n]);
+            });
             // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
 #if BNN_ABLATE & 2
 #pragma unroll
