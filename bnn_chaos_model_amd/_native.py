@@ -17,7 +17,7 @@ ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_RANGE = -1, -2, -3, -4
 
 
 class BnnArch(C.Structure):
-    _fields_ = [("n_features", C.c_int32), ("hidden", C.c_int32), ("latent", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("n_features", C.c_int32), ("hidden", C.c_int32), ("latent", C.c_int32), ("fix_megno", C.c_int32),
                 ("zero_mask", C.c_uint64), ("lowest_std", C.c_float), ("pad", C.c_float)]
 
 
@@ -144,9 +144,11 @@ def stream_ptr():
 class Plan:
     """Owns a bnn_plan (device operand tables) for one architecture / column mask."""
 
-    def __init__(self, zero_mask, lowest_std=0.5, n_features=41, hidden=40, latent=20):
-        self.arch = BnnArch(n_features, hidden, latent, 0, zero_mask, lowest_std, 0.0)
+    def __init__(self, zero_mask, lowest_std=0.5, n_features=41, hidden=40, latent=20, fix_megno=False):
+        self.arch = BnnArch(n_features, hidden, latent, int(bool(fix_megno)), zero_mask, lowest_std, 0.0)
         self.d = check(lib().bnn_param_count(C.byref(self.arch)))
+        self.fix_megno = bool(fix_megno)
+        self.summary_width = 2 * latent + (2 if fix_megno else 0)   # [mu_sample | std_sample | megno mean, megno std]
         h = _vp()
         check(lib().bnn_plan_create(C.byref(self.arch), C.byref(h)))
         self.handle = h

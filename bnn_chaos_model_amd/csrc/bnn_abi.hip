@@ -56,46 +56,48 @@ __global__ __launch_bounds__(1024) void bnn_moments_kernel(const float* __restri
 // draw's regress_nn parameters in LDS, each neuron a bias-initialised fmaf chain in the fused kernel's accumulation order, so
 // the result is bit-identical to the tail of bnn_forward_f32 on the same summary.
 struct RegressParams {
-    const float* summary;  // [J,B,40]
+    const float* summary;  // [J,B,SM]  (SM = 40, or 42 with fix_megno)
     const float* W;        // [J,d]
     float* out;            // [J,B,2]
     float* pre;            // [J,B,2] or null
     int64_t B;
     float std_lo, std_span;
-    int8_t ord[3][H];
+    int8_t ord[3][H + 4];
 };
 
-constexpr int REG_NW = D - OFF_W4;  // 3362 floats
-constexpr int REG_LD = H + 1;
+constexpr int REG_LD = H + 5;  // odd: conflict-free per-thread rows; holds the 42-wide summary of fix_megno
 
+template <bool MEGNO>
 __global__ __launch_bounds__(128) void bnn_regress_kernel(RegressParams p) {
-    __shared__ float w[REG_NW];
+    using Y = Lay<MEGNO>;
+    constexpr int NW = Y::D - Y::W4, SM = Y::SM;  // 3362 (3446) floats
+    __shared__ float w[NW];
     __shared__ float a[128 * REG_LD];
     __shared__ float h[128 * REG_LD];
     const int tid = threadIdx.x, j = blockIdx.y;
-    const float* wj = p.W + (int64_t)j * D + OFF_W4;
-    for (int i = tid; i < REG_NW; i += 128) w[i] = wj[i];
+    const float* wj = p.W + (int64_t)j * Y::D + Y::W4;
+    for (int i = tid; i < NW; i += 128) w[i] = wj[i];
     const int64_t b = (int64_t)blockIdx.x * 128 + tid;
     const bool live = b < p.B;
     const int64_t o = (int64_t)j * p.B + b;
-    for (int k = 0; k < S2; ++k) a[tid * REG_LD + k] = live ? p.summary[o * S2 + k] : 0.0f;
+    for (int k = 0; k < SM; ++k) a[tid * REG_LD + k] = live ? p.summary[o * SM + k] : 0.0f;
     __syncthreads();
     float* av = a + tid * REG_LD;
     float* hv = h + tid * REG_LD;
     for (int n = 0; n < H; ++n) {
-        float acc = w[OFF_B4 - OFF_W4 + n];
-        for (int i = 0; i < S2; ++i) { int k = p.ord[0][i]; acc = fmaf(w[n * S2 + k], av[k], acc); }
+        float acc = w[Y::B4 - Y::W4 + n];
+        for (int i = 0; i < SM; ++i) { int k = p.ord[0][i]; acc = fmaf(w[n * SM + k], av[k], acc); }
         hv[n] = fmaxf(acc, 0.0f);
     }
     for (int n = 0; n < H; ++n) {
-        float acc = w[OFF_B5 - OFF_W4 + n];
-        for (int i = 0; i < H; ++i) { int k = p.ord[1][i]; acc = fmaf(w[OFF_W5 - OFF_W4 + n * H + k], hv[k], acc); }
+        float acc = w[Y::B5 - Y::W4 + n];
+        for (int i = 0; i < H; ++i) { int k = p.ord[1][i]; acc = fmaf(w[Y::W5 - Y::W4 + n * H + k], hv[k], acc); }
         av[n] = fmaxf(acc, 0.0f);
     }
     float r[2];
     for (int n = 0; n < 2; ++n) {
-        float acc = w[OFF_B6 - OFF_W4 + n];
-        for (int i = 0; i < H; ++i) { int k = p.ord[2][i]; acc = fmaf(w[OFF_W6 - OFF_W4 + n * H + k], av[k], acc); }
+        float acc = w[Y::B6 - Y::W4 + n];
+        for (int i = 0; i < H; ++i) { int k = p.ord[2][i]; acc = fmaf(w[Y::W6 - Y::W4 + n * H + k], av[k], acc); }
         r[n] = acc;
     }
     if (!live) return;
@@ -247,11 +249,12 @@ __global__ void bnn_philox_fill_kernel(int kind, uint64_t seed, int64_t id0, int
         int64_t row = i / width;
         int el = (int)(i % width);
         out[i] = philox_z(kind == 0 ? TAG_Z1 : TAG_Z2, id0 + row, el, seed);
-    } else if (kind == 2 || kind == 4) {
-        int64_t total = n_rows * B * S2;
+    } else if (kind == 2 || kind == 4) {   // eps [n_rows,B,2,20]; eps_sum [n_rows,B,SM] with SM = width (40, or 42 with fix_megno)
+        const int SM = kind == 4 && width > 0 ? width : S2;
+        int64_t total = n_rows * B * SM;
         if (i >= total) return;
-        int el = (int)(i % S2);
-        int64_t sys = (i / S2) % B, row = i / (S2 * B);
+        int el = (int)(i % SM);
+        int64_t sys = (i / SM) % B, row = i / ((int64_t)SM * B);
         out[i] = philox_sys4(kind == 2 ? TAG_EPS : TAG_SUM, id0 + row, sys0 + sys, el >> 2, seed)[el & 3];
     } else if (kind == 5) {  // candidates of the truncated-normal draw [n_rows, B, nsamp = width] (bnn_stats.hip.h)
         int64_t total = n_rows * B * width;
@@ -287,15 +290,16 @@ __global__ void bnn_philox_raw_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uin
 }
 
 // SWAGModel.sample_weights for J draws: grid.x = (draw, 256-row slice of the parameter vector), so J is bounded only by 2^31 / 30.
-constexpr int DRAW_SLICES = (D + 255) / 256;
+// D = length of the flat parameter vector (7583; 7665 with fix_megno).
 __global__ __launch_bounds__(256) void bnn_swag_draw_kernel(const float* __restrict__ w_avg, const float* __restrict__ w2_avg,
-                                                            const float* __restrict__ pre_D, int S, int K,
+                                                            const float* __restrict__ pre_D, int D, int S, int K,
                                                             const int32_t* __restrict__ seed_idx, const float* __restrict__ z1,
                                                             const float* __restrict__ z2, float c1, float c2, float scale,
                                                             uint64_t seed, int64_t draw_id0, float* __restrict__ W_out) {
     __shared__ float slabs[4 * SLAB];
     __shared__ float zsh[MAXK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int DRAW_SLICES = (D + 255) / 256;
     const int64_t e = blockIdx.x / DRAW_SLICES;
     const int slice = blockIdx.x % DRAW_SLICES;
     int s = seed_idx[e];
@@ -305,14 +309,14 @@ __global__ __launch_bounds__(256) void bnn_swag_draw_kernel(const float* __restr
         zsh[threadIdx.x] = z2 ? z2[e * K + threadIdx.x] : philox_z(TAG_Z2, draw_id0 + e, threadIdx.x, seed);
     const int i0 = (slice * 4 + wave) * 64;
     const float* pd = pre_D + (int64_t)s * D * K;
-    if (i0 < D) draw_stage(pd, i0, K, lane, slabs + wave * SLAB);
+    if (i0 < D) draw_stage(pd, i0, D, K, lane, slabs + wave * SLAB);
     __syncthreads();
     const int i = i0 + lane;
     if (i < D) {
-        float z1v = z1 ? z1[e * D + i] : philox_z(TAG_Z1, draw_id0 + e, i, seed);
+        float z1v = z1 ? z1[e * (int64_t)D + i] : philox_z(TAG_Z1, draw_id0 + e, i, seed);
         float w = draw_row(w_avg + (int64_t)s * D, w2_avg + (int64_t)s * D, i, K, lane, slabs + wave * SLAB, zsh, z1v, c1, c2,
                            scale);
-        W_out[e * D + i] = bad ? __builtin_nanf("") : w;
+        W_out[e * (int64_t)D + i] = bad ? __builtin_nanf("") : w;
     }
 }
 
@@ -436,6 +440,8 @@ static int fail(int code, const std::string& msg) {
 
 struct bnn_plan {
     bnn_arch arch;
+    bool megno = false;  // arch.fix_megno
+    int d = D;           // length of the flat parameter vector
     Tables tab[2];  // [0] = arch mask, [1] = all 41 columns (noisy forward)
     int16_t* d_f2 = nullptr;   // regress_nn fragment gather table
     int16_t* d_f4 = nullptr;   // feature_nn weight-register table (4x4x1 path) for the plan's mask
@@ -449,6 +455,7 @@ static int check_arch(const bnn_arch* a) {
     if (a->n_features != F || a->hidden != H || a->latent != L)
         return fail(BNN_ERR_UNSUPPORTED, "only the 41->40->40->20 / 40->40->40->2 network of the pretrained ensemble is built");
     if (a->zero_mask >> F) return fail(BNN_ERR_INVALID, "zero_mask has bits beyond column 40");
+    if (a->fix_megno != 0 && a->fix_megno != 1) return fail(BNN_ERR_INVALID, "fix_megno must be 0 or 1");
     return 0;
 }
 
@@ -466,7 +473,7 @@ int bnn_device_count(void) {
 
 int bnn_param_count(const bnn_arch* arch) {
     int rc = check_arch(arch);
-    return rc ? rc : D;
+    return rc ? rc : layout_of(arch->fix_megno != 0).D;
 }
 
 static bool upload(const void* host, size_t bytes, void** dev) {
@@ -479,8 +486,10 @@ int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
     if (!out) return fail(BNN_ERR_INVALID, "out is NULL");
     bnn_plan* pl = new bnn_plan();
     pl->arch = *arch;
-    pl->tab[0] = build_tables(arch->zero_mask, false);
-    pl->tab[1] = build_tables(arch->zero_mask, true);
+    pl->megno = arch->fix_megno != 0;
+    pl->d = layout_of(pl->megno).D;
+    pl->tab[0] = build_tables(arch->zero_mask, false, pl->megno);
+    pl->tab[1] = build_tables(arch->zero_mask, true, pl->megno);
     if (hipGetDevice(&pl->device) != hipSuccess) {
         delete pl;
         return fail(BNN_ERR_NO_DEVICE, "no HIP device");
@@ -520,7 +529,7 @@ int bnn_layer_order(const bnn_arch* arch, int layer, int noisy, int32_t* host_or
     int rc = check_arch(arch);
     if (rc) return rc;
     if (layer < 0 || layer > 5) return fail(BNN_ERR_INVALID, "layer must be 0..5");
-    Tables t = build_tables(arch->zero_mask, noisy != 0);
+    Tables t = build_tables(arch->zero_mask, noisy != 0, arch->fix_megno != 0);
     const std::vector<int32_t>& o = t.order[layer];
     if (host_order)
         for (int i = 0; i < (int)o.size() && i < cap; ++i) host_order[i] = o[i];
@@ -531,7 +540,7 @@ int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host
     int rc = check_arch(arch);
     if (rc) return rc;
     if (which != 1 && which != 2) return fail(BNN_ERR_INVALID, "which must be 1 (feature_nn images) or 2 (regress_nn fragments)");
-    Tables t = build_tables(arch->zero_mask, noisy != 0);
+    Tables t = build_tables(arch->zero_mask, noisy != 0, arch->fix_megno != 0);
     const std::vector<int16_t>& v = which == 1 ? t.f4 : t.f2;
     if (host_table)
         for (int i = 0; i < (int)v.size() && i < cap; ++i) host_table[i] = v[i];
@@ -569,11 +578,13 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     const int64_t nsub = (p.csz + p.spc - 1) / p.spc;
     const int64_t nblk = nsub * g->J;
     if (nblk > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "grid too large; split the draws");
-    static_assert(NF2 * 64 <= FLAT_LDS, "regress_nn fragments overwrite the flat vector in place");
+    static_assert(Lay<true>::NF2 * 64 <= FLAT_LDS, "regress_nn fragments overwrite the flat vector in place");
     hipStream_t st = (hipStream_t)stream;
     const bool k31 = pl->tab[0].kin4 == 31;
     hipError_t e;
-    if (lowp) e = launch_fwd_lowp(lowp, (unsigned)nblk, st, p);
+    if (pl->megno && (lowp || p.sink)) return fail(BNN_ERR_UNSUPPORTED, "fix_megno: the reduced-precision and fused-statistics forms are not built");
+    if (pl->megno) e = launch_fwd_megno(k31, fused, noisy, (unsigned)nblk, st, p);
+    else if (lowp) e = launch_fwd_lowp(lowp, (unsigned)nblk, st, p);
     else if (p.sink) e = launch_fwd_stats(k31, (unsigned)nblk, st, p);
     else if (noisy) e = launch_fwd_noisy((unsigned)nblk, st, p);
     else if (k31) e = launch_fwd_k31(fused, (unsigned)nblk, st, p);
@@ -600,9 +611,10 @@ int bnn_swag_draw_f32(const bnn_plan* plan, const float* w_avg, const float* w2_
     int rc = draw_consts(K, scale, &c1, &c2);
     if (rc) return rc;
     if (J == 0) return 0;
-    if ((int64_t)J * DRAW_SLICES > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many draws for one launch");
-    dim3 grid((unsigned)((int64_t)J * DRAW_SLICES)), block(256);
-    hipLaunchKernelGGL(bnn_swag_draw_kernel, grid, block, 0, (hipStream_t)stream, w_avg, w2_avg, pre_D, S, K, seed_idx, z1, z2, c1,
+    const int d = plan->d, slices = (d + 255) / 256;
+    if ((int64_t)J * slices > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many draws for one launch");
+    dim3 grid((unsigned)((int64_t)J * slices)), block(256);
+    hipLaunchKernelGGL(bnn_swag_draw_kernel, grid, block, 0, (hipStream_t)stream, w_avg, w2_avg, pre_D, d, S, K, seed_idx, z1, z2, c1,
                        c2, scale, philox_seed, draw_id0, W_out);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -697,18 +709,20 @@ int bnn_regress_f32(const bnn_plan* pl, const float* summary, const float* W, in
     RegressParams p;
     p.summary = summary; p.W = W; p.out = out; p.pre = pre_clamp; p.B = B;
     p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);
+    const int SM = layout_of(pl->megno).SM;
     for (int l = 0; l < 3; ++l) {
         const std::vector<int32_t>& o = pl->tab[0].order[3 + l];
-        if ((int)o.size() != H) return fail(BNN_ERR_INVALID, "internal: regress_nn order table");
-        for (int i = 0; i < H; ++i) p.ord[l][i] = (int8_t)o[i];
+        if ((int)o.size() != (l == 0 ? SM : H)) return fail(BNN_ERR_INVALID, "internal: regress_nn order table");
+        for (int i = 0; i < (int)o.size(); ++i) p.ord[l][i] = (int8_t)o[i];
     }
     if ((B + 127) / 128 > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many systems for one launch");
     for (int64_t j0 = 0; j0 < J; j0 += 65535) {  // grid.y limit
         const int64_t nj = J - j0 < 65535 ? J - j0 : 65535;
         RegressParams q = p;
-        q.summary = summary + j0 * B * S2; q.W = W + j0 * D; q.out = out + j0 * B * 2;
+        q.summary = summary + j0 * B * SM; q.W = W + j0 * pl->d; q.out = out + j0 * B * 2;
         q.pre = pre_clamp ? pre_clamp + j0 * B * 2 : nullptr;
-        hipLaunchKernelGGL(bnn_regress_kernel, dim3((unsigned)((B + 127) / 128), (unsigned)nj), dim3(128), 0, (hipStream_t)stream, q);
+        if (pl->megno) hipLaunchKernelGGL(bnn_regress_kernel<true>, dim3((unsigned)((B + 127) / 128), (unsigned)nj), dim3(128), 0, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL(bnn_regress_kernel<false>, dim3((unsigned)((B + 127) / 128), (unsigned)nj), dim3(128), 0, (hipStream_t)stream, q);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -776,7 +790,8 @@ int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments,
 int bnn_philox_normal_f32(int32_t kind, uint64_t philox_seed, int64_t id0, int64_t n_rows, int64_t B, int64_t system_id0, int32_t width,
                           float* out, void* stream) {
     if (!out || kind < 0 || kind > 6 || n_rows < 0) return fail(BNN_ERR_INVALID, "bad argument");
-    int64_t total = (kind == 2 || kind == 4) ? n_rows * B * S2 : kind == 3 ? n_rows * B * (int64_t)width * F : kind == 5 ? n_rows * B * (int64_t)width
+    if (kind == 4 && width != 0 && width != S2 && width != S2 + 2) return fail(BNN_ERR_INVALID, "eps_sum is 40 wide (42 with fix_megno)");
+    int64_t total = kind == 2 ? n_rows * B * S2 : kind == 4 ? n_rows * B * (int64_t)(width > 0 ? width : S2) : kind == 3 ? n_rows * B * (int64_t)width * F : kind == 5 ? n_rows * B * (int64_t)width
                     : kind == 6 ? n_rows * B : n_rows * (int64_t)width;
     if (total == 0) return 0;
     hipLaunchKernelGGL(bnn_philox_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind, philox_seed,

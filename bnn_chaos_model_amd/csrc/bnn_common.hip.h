@@ -182,8 +182,8 @@ DEVINL f32x2 soft_clamp2(float r0, float r1, float std_lo, float std_span) {
 // 64*K-float run; lane l then owns row i0+l and accumulates its K-term dot product in k order.
 // Callers bracket the two phases with workgroup barriers (stage -> barrier -> compute -> barrier).
 // ------------------------------------------------------------------------------------------------
-DEVINL void draw_stage(const float* __restrict__ pre_D_s, int i0, int K, int lane, float* slab) {
-    const int64_t base = (int64_t)i0 * K, lim = (int64_t)D * K;
+DEVINL void draw_stage(const float* __restrict__ pre_D_s, int i0, int d, int K, int lane, float* slab) {
+    const int64_t base = (int64_t)i0 * K, lim = (int64_t)d * K;
     for (int n = 0; n < K; ++n) {
         int idx = n * 64 + lane;
         if (base + idx < lim) slab[idx] = pre_D_s[base + idx];

@@ -70,16 +70,23 @@ DEVINL void load_row(const float* __restrict__ rp, float (&xv)[KIN]) {
     }
 }
 
+constexpr int MEGSCR = 32;         // LDS floats per wave: [16 systems][megno mean, megno std] (fix_megno forms)
 constexpr int NSC4 = 96 + 2 * 56;  // LDS floats of the noisy forward: exp(logvar/2) for 41 inputs + 40 summaries (padded to 96), then
                                    // per 6-column noise block, padded to 8: the input scales [7][8] and the column keep-masks [7][8]
 
 template <int KIN>
-constexpr size_t fwd_lds_bytes() { return sizeof(float) * (FLAT_LDS + MAXK + BIAS_PAD + 4 * SCR4 + NSC4); }
+constexpr size_t fwd_lds_bytes() { return sizeof(float) * (FLAT_LDS + MAXK + BIAS_PAD + 4 * SCR4 + NSC4 + 4 * MEGSCR); }
 
-template <int KIN, bool FUSED, bool NOISY, bool STATS>
+// MEGNO: hparams['fix_megno'] (spock_reg_model.py:360-362, 480-491, 509-510): the summary gains the time mean and unbiased std of
+// the RAW MEGNO column (read before the masks and before any noise), pooled with the same per-lane Welford + quad merge as the
+// latents; regress_nn.0 takes 42 inputs (an 11th k-step), the flat vector is Lay<true> (d = 7665).
+template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false>
 __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) {
     using WRL = WR<KIN>;
-    constexpr bool PREF = BNN_BIAS_PREFETCH && KIN == 31;   // the 41-column forms have no registers to spare for it
+    using Y = Lay<MEGNO>;
+    constexpr int D = Y::D;                                  // shadows the fix_megno = False constant
+    static_assert(!MEGNO || !STATS, "the fused statistics tail is not built for fix_megno");
+    constexpr bool PREF = BNN_BIAS_PREFETCH && KIN == 31 && !MEGNO;   // the other forms have no registers to spare for it
     constexpr bool RBATCH = BNN_RELU_BATCH != 0;
     static_assert(!NOISY || (KIN == F && !FUSED && !STATS), "the noisy forward multiplies all 41 columns and takes materialised weights");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -89,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     float* wl = zsh + MAXK;            // [BIAS_PAD] feature_nn biases [b1 | b2 | b3], 16-byte aligned rows of 4
     float* scr = wl + BIAS_PAD;        // [4][SCR4]
     float* nsc = scr + 4 * SCR4;       // [NSC4] (NOISY only)
+    float* megscr = nsc + NSC4;        // [4][MEGSCR] (MEGNO only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,25 +136,26 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         const float* We = p.W + (int64_t)e * D;
         for (int i = tid; i < D; i += 256) flat[i] = We[i];
     }
-    if (tid == 0) flat[ZERO_IDX] = 0.0f;
+    if (tid == 0) flat[Y::ZERO] = 0.0f;
     __syncthreads();
     // feature_nn weights -> registers (every wave holds the same 58): register R, lane 4a+i = W[neuron 4n+i][input k] of the
     // layer's MFMA number m = 16R + a = k * groups + n (bnn_layout.h, WR<KIN>); biases -> a small LDS image
     float wr[WRL::NR];
 #pragma unroll
     for (int R = 0; R < WRL::NR; ++R) wr[R] = flat[p.tab_wr[R * 64 + lane]];
-    if (tid < 2 * H + L) wl[tid] = flat[tid < H ? OFF_B1 + tid : tid < 2 * H ? OFF_B2 + (tid - H) : OFF_B3 + (tid - 2 * H)];
+    if (tid < 2 * H + L) wl[tid] = flat[tid < H ? Y::B1 + tid : tid < 2 * H ? Y::B2 + (tid - H) : Y::B3 + (tid - 2 * H)];
     if constexpr (NOISY) {  // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
-        if (tid < F + S2) nsc[tid] = expf(flat[OFF_INLV + tid] / 2.0f);
+        if (tid < F + Y::SM) nsc[tid] = expf(flat[Y::INLV + tid] / 2.0f);
         if (tid < 56) {     // the same input scales per noise block, and all-ones / zero bit masks for kept / zeroed columns
             const int col = NIN_PER_BLOCK * (tid >> 3) + (tid & 7);
             const bool live = (tid & 7) < NIN_PER_BLOCK && col < F;
-            nsc[96 + tid] = live ? expf(flat[OFF_INLV + col] / 2.0f) : 0.0f;
+            nsc[96 + tid] = live ? expf(flat[Y::INLV + col] / 2.0f) : 0.0f;
             nsc[96 + 56 + tid] = __builtin_bit_cast(float, (live && !((p.zero_mask >> col) & 1ull)) ? 0xFFFFFFFFu : 0u);
         }
     }
     {   // regress_nn operands replace the flat vector in place: gather to registers, barrier, write.  All table entries are
         // fetched first (branch-free, clamped), so the 25 global loads are in flight together.
+        constexpr int NF2 = Y::NF2;
         constexpr int PER = (NF2 + 3) / 4;
         int idx[PER];
         float tmp[PER];
@@ -188,6 +197,8 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
 
         float xv[KIN];
         load_row<KIN>(rowp, xv);
+        float xmeg = 0.0f, gmean = 0.0f, gm2 = 0.0f;   // MEGNO: the raw column 7 of this lane's row, its running mean and M2
+        if constexpr (MEGNO) xmeg = rowp[MEGNO_COL];
         asm volatile("" ::: "memory");
         // Accumulators of the three layers.  An accumulator chain starts at its bias (C operand of its first MFMA), read from the LDS
         // bias image.  With PREF the reads run a layer ahead of their first use: feature_nn.2's biases are fetched at the top of
@@ -213,6 +224,13 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         };
         if constexpr (PREF) bias10(h, bq1);
         for (int it = 0; it < ntiles; ++it) {
+            if constexpr (MEGNO) {   // summarize_megno (:480-484): Welford over the lane's timesteps, like the latents below
+                const float rcm = p.rcp_tab[it];
+                const float dl = xmeg - gmean;
+                const float mn = fmaf(dl, rcm, gmean);
+                gm2 = fmaf(dl, xmeg - mn, gm2);
+                gmean = mn;
+            }
             // feature_nn.0 + ReLU: MFMA m = k * 10 + n multiplies input column k into neuron group n (bias first, then the inputs in
             // ascending order: the oracle's natural order); its A operand is lanes 4(m&15).. of weight register m >> 4.
             {
@@ -284,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
             // ONE burst: spread over the MFMAs of feature_nn.2 (one per 20 or 36) the kernel measured 14-20 % SLOWER
             // (profiles/r03_ab_variants.txt).
             load_row<KIN>(rowp + (int64_t)((it + 1 < ntiles) ? it + 1 : it) * 4 * F, xv);
+            if constexpr (MEGNO) xmeg = rowp[(int64_t)((it + 1 < ntiles) ? it + 1 : it) * 4 * F + MEGNO_COL];
             asm volatile("" ::: "memory");
 #endif
             // feature_nn.2 + ReLU: MFMA m = k * 10 + n
@@ -369,6 +388,35 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                     mean[n][i] = mm;
                 }
         }
+        if constexpr (MEGNO) {   // the same two merge steps for the MEGNO column; then mean and torch.std (unbiased) -> LDS, summary
+            float half_n = half_n0;
+            {
+                float om = quad_perm<0xB1>(gmean), o2 = quad_perm<0xB1>(gm2);
+                float dl = om - gmean;
+                float mm = (gmean + om) * 0.5f;
+                gm2 = (gm2 + o2) + (dl * dl) * half_n;
+                gmean = mm;
+            }
+            half_n = half_n * 2.0f;
+            {
+                float om = quad_perm<0x4E>(gmean), o2 = quad_perm<0x4E>(gm2);
+                float dl = om - gmean;
+                float mm = (gmean + om) * 0.5f;
+                gm2 = (gm2 + o2) + (dl * dl) * half_n;
+                gmean = mm;
+            }
+            const float gstd = sqrtf(gm2 / nm1);
+            if (ph == 0) {
+                float* mg = megscr + wave * MEGSCR + sl * 2;
+                mg[0] = gmean;
+                mg[1] = gstd;
+                if (p.summary && valid) {
+                    float* sp = p.summary + (r * p.B + sys) * Y::SM + S2;
+                    sp[0] = gmean;
+                    sp[1] = gstd;
+                }
+            }
+        }
         // The quad now holds four copies of the 20 pooled (mean, M2) pairs of its system: lane `ph` finishes
         // neurons 5ph..5ph+4 (compute_summary_stats :420-431), so the sqrt/divide sequences run once, not four times.
         float mymean[5], mym2[5];
@@ -411,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
             sumscr[sl * S2 + 5 * ph + j] = mu_s;
             sumscr[sl * S2 + L + 5 * ph + j] = sd_s;
             if (p.summary && valid) {
-                float* sp = p.summary + (r * p.B + sys) * S2 + 5 * ph + j;
+                float* sp = p.summary + (r * p.B + sys) * Y::SM + 5 * ph + j;
                 sp[0] = mu_s;
                 sp[L] = sd_s;
             }
@@ -421,15 +469,18 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         // ---- regress_nn on the 16 systems of this wave-batch (16x16x4 path): column c <-> system wb0 + c
         const int64_t sysb = wb0 + c;
         const bool validb = sysb < b1;
-        float skeep[10];
+        float skeep[Y::NK4];
 #pragma unroll
         for (int ks = 0; ks < 10; ++ks) skeep[ks] = sumscr[c * S2 + kmap_summary(ks, g)];
+        if constexpr (MEGNO) skeep[10] = g < 2 ? megscr[wave * MEGSCR + c * 2 + g] : 0.0f;   // torch.cat([summary_stats, megno_avg_std]) (:509-510)
         if constexpr (NOISY) {  // add_summary_noise (:448-450)
             const int64_t sc = validb ? sysb : b1 - 1;
             if (p.eps_sum) {
-                const float* es = p.eps_sum + (r * p.B + sc) * S2;
+                const float* es = p.eps_sum + (r * p.B + sc) * Y::SM;
 #pragma unroll
                 for (int ks = 0; ks < 10; ++ks) skeep[ks] = skeep[ks] + es[kmap_summary(ks, g)] * nsc[F + kmap_summary(ks, g)];
+                if constexpr (MEGNO)
+                    if (g < 2) skeep[10] = skeep[10] + es[S2 + g] * nsc[F + S2 + g];
             } else {
                 const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + sc;
 #pragma unroll
@@ -441,28 +492,35 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                         skeep[kind * 5 + rr] = skeep[kind * 5 + rr] + a4n[rr] * nsc[F + kmap_summary(kind * 5 + rr, g)];
                     skeep[kind * 5 + 4] = skeep[kind * 5 + 4] + bn * nsc[F + kmap_summary(kind * 5 + 4, g)];
                 }
+                if constexpr (MEGNO) {   // eps_sum[40 + g] = element g of quad 10
+                    const f32x4 mn4 = philox_sys4(TAG_SUM, grow, gsys, 10, p.seed);
+                    const float mnz = g == 0 ? mn4[0] : mn4[1];
+                    if (g < 2) skeep[10] = skeep[10] + mnz * nsc[F + S2 + g];
+                }
             }
         }
         const float* f2l = f2frag + lane;
         auto W2f = [&](int f) { return f2l[f * 64]; };
         f32x4 a4[3], a5[3], a6;
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) a4[mt] = (f32x4){W2f(70 + mt * 4), W2f(71 + mt * 4), W2f(72 + mt * 4), W2f(73 + mt * 4)};
+        for (int mt = 0; mt < 3; ++mt)
+            a4[mt] = (f32x4){W2f(Y::F_B4 + mt * 4), W2f(Y::F_B4 + 1 + mt * 4), W2f(Y::F_B4 + 2 + mt * 4), W2f(Y::F_B4 + 3 + mt * 4)};
 #pragma unroll
-        for (int ks = 0; ks < 10; ++ks)
+        for (int ks = 0; ks < Y::NK4; ++ks)
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(ks * 3 + mt), skeep[ks], a4[mt]);
+            for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(Y::F_L4 + ks * 3 + mt), skeep[ks], a4[mt]);
         a4[0] = relu4(a4[0]); a4[1] = relu4(a4[1]); a4[2] = relu4<2>(a4[2]);
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) a5[mt] = (f32x4){W2f(82 + mt * 4), W2f(83 + mt * 4), W2f(84 + mt * 4), W2f(85 + mt * 4)};
+        for (int mt = 0; mt < 3; ++mt)
+            a5[mt] = (f32x4){W2f(Y::F_B5 + mt * 4), W2f(Y::F_B5 + 1 + mt * 4), W2f(Y::F_B5 + 2 + mt * 4), W2f(Y::F_B5 + 3 + mt * 4)};
 #pragma unroll
         for (int ks = 0; ks < NKH; ++ks)
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(30 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
+            for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(Y::F_L5 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
         a5[0] = relu4(a5[0]); a5[1] = relu4(a5[1]); a5[2] = relu4<2>(a5[2]);
-        a6 = (f32x4){W2f(94), W2f(95), W2f(96), W2f(97)};
+        a6 = (f32x4){W2f(Y::F_B6), W2f(Y::F_B6 + 1), W2f(Y::F_B6 + 2), W2f(Y::F_B6 + 3)};
 #pragma unroll
-        for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(60 + ks), a5[ks >> 2][ks & 3], a6);
+        for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(Y::F_L6 + ks), a5[ks >> 2][ks & 3], a6);
         if (g == 0 && validb) {
             // predict_instability + soft_clamp (:295-296, :437-442)
             const float r0 = a6[0], r1 = a6[1];
@@ -480,16 +538,16 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     }
 }
 
-template <int KIN, bool FUSED, bool NOISY, bool STATS>
+template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false>
 inline hipError_t launch_forward_form(unsigned nblk, hipStream_t st, const FwdParams& p) {
     static bool attr_set[MAX_DEVICES];  // the attribute belongs to the (function, device) pair
     const int slot = current_device_slot();
     if (!attr_set[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_kernel<KIN, FUSED, NOISY, STATS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set[slot] = true;
     }
-    hipLaunchKernelGGL((bnn_forward_kernel<KIN, FUSED, NOISY, STATS>), dim3(nblk), dim3(256), fwd_lds_bytes<KIN>(), st, p);
+    hipLaunchKernelGGL((bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO>), dim3(nblk), dim3(256), fwd_lds_bytes<KIN>(), st, p);
     return hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 //   bnn_fwd_k31.hip     forward kernel, 31 live input columns (the v50 mask), quiet      (workspace + in-prologue draw)
 //   bnn_fwd_k41.hip     forward kernel, all 41 columns (any other mask), quiet           (workspace + in-prologue draw)
 //   bnn_fwd_noisy.hip   forward kernel, forward(noisy_val=True)
+//   bnn_fwd_megno.hip   forward kernel forms for hparams['fix_megno'] = True (42-wide summary, d = 7665)
 //   bnn_fwd_bf16.hip    reduced-precision forward kernels (bf16 matrix pipe; opt-in, configs[4])
 //   bnn_small.hip       SWAG draw, moments, regress_nn, statistics epilogue, feature packing, Philox fills
 //   bnn_abi.hip         extern "C" entry points of include/bnn_chaos_hip.h
@@ -68,6 +69,7 @@ hipError_t launch_fwd_k41(bool fused, unsigned nblk, hipStream_t st, const FwdPa
 hipError_t launch_fwd_noisy(unsigned nblk, hipStream_t st, const FwdParams& p);
 hipError_t launch_fwd_stats(bool k31, unsigned nblk, hipStream_t st, const FwdParams& p);  // quiet forward + fused statistics tail
 hipError_t launch_fwd_lowp(int precision, unsigned nblk, hipStream_t st, const FwdParams& p);  // bf16 / half matrix pipe (bnn_precision)
+hipError_t launch_fwd_megno(bool k31, bool fused, bool noisy, unsigned nblk, hipStream_t st, const FwdParams& p);  // hparams['fix_megno'] layout
 
 constexpr int MAX_DEVICES = 64;
 inline int current_device_slot() {

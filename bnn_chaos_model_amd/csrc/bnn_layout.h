@@ -45,7 +45,36 @@ constexpr int OFF_W6 = OFF_B5 + H;            // 7501
 constexpr int OFF_B6 = OFF_W6 + 2 * H;        // 7581
 constexpr int D = OFF_B6 + 2;                 // 7583
 constexpr int ZERO_IDX = D;                   // LDS slot that always holds 0.0f
-constexpr int FLAT_LDS = 7616;                // floats reserved for the flat vector (+zero slot, 16B multiple)
+constexpr int FLAT_LDS = 7680;                // floats reserved for the flat vector (+zero slot, 16B multiple; fix_megno: 7665 + 1)
+
+// The same layout for either value of hparams['fix_megno'] (spock_reg_model.py:360-362): with it the summary is SM = 42 wide
+// ([mu_sample(20) | std_sample(20) | megno mean, megno std]), so summary_noise_logvar has 42 entries and regress_nn.0 is 40 x 42;
+// everything behind summary_noise_logvar moves by 2, everything behind regress_nn.0.weight by 82 (d = 7665).
+template <bool MEGNO>
+struct Lay {
+    static constexpr int SM = S2 + (MEGNO ? 2 : 0);
+    static constexpr int INLV = 0, SUMLV = F;
+    static constexpr int W1 = SUMLV + SM, B1 = W1 + H * F, W2 = B1 + H, B2 = W2 + H * H, W3 = B2 + H, B3 = W3 + L * H;
+    static constexpr int W4 = B3 + L, B4 = W4 + H * SM, W5 = B4 + H, B5 = W5 + H * H, W6 = B5 + H, B6 = W6 + 2 * H;
+    static constexpr int D = B6 + 2, ZERO = D;
+    // regress_nn fragments (bnn_tables.cpp): k-steps of regress_nn.0 (the 11th carries the two MEGNO statistics in lane groups 0, 1)
+    static constexpr int NK4 = MEGNO ? 11 : 10;
+    static constexpr int F_L4 = 0, F_L5 = 3 * NK4, F_L6 = F_L5 + 30, F_B4 = F_L6 + 10, F_B5 = F_B4 + 12, F_B6 = F_B5 + 12, NF2 = F_B6 + 4;
+};
+static_assert(Lay<false>::D == D && Lay<false>::W4 == OFF_W4 && Lay<false>::B6 == OFF_B6, "the fixed constants above are Lay<false>");
+static_assert(Lay<true>::D == 7665 && Lay<true>::D < FLAT_LDS && Lay<true>::NF2 * 64 <= FLAT_LDS, "fix_megno layout fits the LDS budget");
+constexpr int MEGNO_COL = 7;                  // self.megno_location (:371)
+
+// runtime mirror for the host-side table builder
+struct LayoutRT {
+    int SM, W1, B1, W2, B2, W3, B3, W4, B4, W5, B5, W6, B6, D, NK4, NF2;
+};
+template <bool MEGNO>
+constexpr LayoutRT layout_rt() {
+    using Y = Lay<MEGNO>;
+    return LayoutRT{Y::SM, Y::W1, Y::B1, Y::W2, Y::B2, Y::W3, Y::B3, Y::W4, Y::B4, Y::W5, Y::B5, Y::W6, Y::B6, Y::D, Y::NK4, Y::NF2};
+}
+inline LayoutRT layout_of(bool megno) { return megno ? layout_rt<true>() : layout_rt<false>(); }
 
 constexpr int MAXK = 32;  // SWAG rank supported (reference uses K = 30, run_swag.py:37)
 
@@ -71,6 +100,7 @@ BNN_HD inline int kmap_hidden(int ks, int g) {
 // k-steps over the 40-wide summary [mu_sample(20) | std_sample(20)]: ks = kind*5 + r; lane group g carries neuron
 // 4g + r for r < 4 and neuron 16 + g for r = 4 of that kind.
 BNN_HD inline int kmap_summary(int ks, int g) {
+    if (ks >= 10) return g < 2 ? S2 + g : -1;   // fix_megno: 11th k-step = [megno mean, megno std, 0, 0]
     int kind = ks / 5, r = ks % 5;
     int n = r < 4 ? 4 * g + r : 16 + g;
     return kind * L + n;
@@ -96,7 +126,8 @@ struct WR {
 };
 constexpr int BIAS_PAD = 112;  // LDS floats of the bias image (2 * H + L = 100, padded)
 
-// regress_nn fragment count (see bnn_tables.cpp)
+// regress_nn fragment count (see bnn_tables.cpp) for fix_megno = False (Lay<MEGNO>::NF2 in general)
 constexpr int NF2 = 30 + 30 + 10 + 12 + 12 + 4;
+static_assert(NF2 == Lay<false>::NF2, "");
 
 }  // namespace bnn

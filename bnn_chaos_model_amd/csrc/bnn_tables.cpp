@@ -20,19 +20,25 @@ struct Builder {
 
 }  // namespace
 
-Tables build_tables(uint64_t zero_mask, bool all_columns) {
+Tables build_tables(uint64_t zero_mask, bool all_columns, bool megno) {
     Tables T;
+    const LayoutRT Y = layout_of(megno);
+    // the names below shadow the fix_megno = False constants of bnn_layout.h on purpose: every index in this function is layout-relative
+    const int OFF_W1 = Y.W1, OFF_B1 = Y.B1, OFF_W2 = Y.W2, OFF_B2 = Y.B2, OFF_W3 = Y.W3, OFF_B3 = Y.B3, OFF_W4 = Y.W4, OFF_B4 = Y.B4,
+              OFF_W5 = Y.W5, OFF_B5 = Y.B5, OFF_W6 = Y.W6, OFF_B6 = Y.B6, ZERO_IDX = Y.D;
+    (void)OFF_B1; (void)OFF_B2; (void)OFF_B3;
+    // the v50 column mask (31 live columns) whichever of fix_megno / fix_megno2 zeroes column 7
     const bool v50 = !all_columns && zero_mask == V50_ZERO_MASK;
     auto dropped = [&](int col) { return !all_columns && ((zero_mask >> col) & 1ull); };
 
-    T.f2.assign((size_t)NF2 * 64, (int16_t)ZERO_IDX);
+    T.f2.assign((size_t)Y.NF2 * 64, (int16_t)ZERO_IDX);
     Builder b2(T.f2);
-    // layer 4 (regress_nn.0): k over the summary vector
-    for (int ks = 0; ks < 10; ++ks)
+    // layer 4 (regress_nn.0): k over the summary vector (fix_megno: an 11th k-step with the two MEGNO statistics)
+    for (int ks = 0; ks < Y.NK4; ++ks)
         for (int mt = 0; mt < 3; ++mt)
             b2.frag([&](int g, int m) {
                 int n = nmap_hidden(mt, m), k = kmap_summary(ks, g);
-                return n < 0 ? ZERO_IDX : OFF_W4 + n * S2 + k;
+                return (n < 0 || k < 0) ? ZERO_IDX : OFF_W4 + n * Y.SM + k;
             });
     // layer 5 (regress_nn.2)
     for (int ks = 0; ks < NKH; ++ks)
@@ -104,8 +110,9 @@ Tables build_tables(uint64_t zero_mask, bool all_columns) {
             T.order[4].push_back(k);
             T.order[5].push_back(k);
         }
-    for (int ks = 0; ks < 10; ++ks)
-        for (int g = 0; g < 4; ++g) T.order[3].push_back(kmap_summary(ks, g));
+    for (int ks = 0; ks < Y.NK4; ++ks)
+        for (int g = 0; g < 4; ++g)
+            if (kmap_summary(ks, g) >= 0) T.order[3].push_back(kmap_summary(ks, g));
     return T;
 }
 

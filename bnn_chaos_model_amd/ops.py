@@ -48,12 +48,13 @@ def zero_mask_from_flags(fix_megno=False, fix_megno2=True, include_mmr=False, in
     return sum(1 << c for c in set(cols))
 
 
-def get_plan(zero_mask=V50_ZERO_MASK, lowest_std=0.5, device=None):
+def get_plan(zero_mask=V50_ZERO_MASK, lowest_std=0.5, device=None, fix_megno=False):
+    """fix_megno: hparams['fix_megno'] (spock_reg_model.py:360-362): 42-wide summary, d = 7665; the mask must zero column 7."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    key = (dev, int(zero_mask), float(lowest_std))
+    key = (dev, int(zero_mask), float(lowest_std), bool(fix_megno))
     if key not in _plans:
         with torch.cuda.device(dev):
-            _plans[key] = N.Plan(int(zero_mask), float(lowest_std))
+            _plans[key] = N.Plan(int(zero_mask), float(lowest_std), fix_megno=fix_megno)
     return _plans[key]
 
 
@@ -132,11 +133,12 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
         raise ValueError(f"eps must be [{R},{B},2,{LATENT}]")
     if (eps_in is None) != (eps_sum is None):
         raise ValueError("eps_in and eps_sum must both be given or both be None")
-    if eps_in is not None and (tuple(eps_in.shape) != (R, B, T, 41) or tuple(eps_sum.shape) != (R, B, 2 * LATENT)):
-        raise ValueError(f"eps_in must be [{R},{B},{T},41] and eps_sum [{R},{B},{2 * LATENT}]")
+    SM = plan.summary_width
+    if eps_in is not None and (tuple(eps_in.shape) != (R, B, T, 41) or tuple(eps_sum.shape) != (R, B, SM)):
+        raise ValueError(f"eps_in must be [{R},{B},{T},41] and eps_sum [{R},{B},{SM}]")
     out = torch.empty((R, B, 2), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(out) if debug else None
-    summ = torch.empty((R, B, 2 * LATENT), dtype=torch.float32, device=x.device) if debug else None
+    summ = torch.empty((R, B, SM), dtype=torch.float32, device=x.device) if debug else None
     g = _grid(B, T, J, nchunks, systems_per_block, noisy)
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
@@ -221,7 +223,7 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
     elif tuple(out.shape) != (R, B, 2) or out.dtype != torch.float32 or not out.is_contiguous():
         raise ValueError("out has the wrong shape/dtype")
     pre = torch.empty_like(out) if debug else None
-    summ = torch.empty((R, B, 2 * LATENT), dtype=torch.float32, device=x.device) if debug else None
+    summ = torch.empty((R, B, plan.summary_width), dtype=torch.float32, device=x.device) if debug else None
     g = _grid(B, T, J, nchunks, systems_per_block)
     if single_launch is None:
         single_launch = -(-B // max(nchunks, 1)) <= 256
@@ -285,8 +287,8 @@ def regress(summary, W, plan=None, debug=False):
     W = _f32(W, "W")
     J, B, S = summary.shape
     plan = plan or get_plan()
-    if S != 2 * LATENT or W.shape != (J, plan.d):
-        raise ValueError("regress needs summary [J,B,40] and W [J,d]")
+    if S != plan.summary_width or W.shape != (J, plan.d):
+        raise ValueError(f"regress needs summary [J,B,{plan.summary_width}] and W [J,{plan.d}]")
     out = torch.empty((J, B, 2), dtype=torch.float32, device=summary.device)
     pre = torch.empty_like(out) if debug else None
     N.check(N.lib().bnn_regress_f32(plan.handle, N.ptr(summary), N.ptr(W), J, B, N.ptr(out), N.ptr(pre) if debug else None,
@@ -296,9 +298,9 @@ def regress(summary, W, plan=None, debug=False):
 
 def philox_normal(kind, philox_seed, id0, n_rows, width=0, B=0, system_id0=0, device="cuda"):
     """The normals the kernels generate in-kernel: kind 0 -> z1[n_rows,width], 1 -> z2[n_rows,width], 2 -> eps[n_rows,B,2,20],
-    3 -> eps_in[n_rows,B,T=width,41], 4 -> eps_sum[n_rows,B,40]; statistics epilogue: 5 -> truncated-normal candidates
+    3 -> eps_in[n_rows,B,T=width,41], 4 -> eps_sum[n_rows,B,40] (width=42 with fix_megno); statistics epilogue: 5 -> truncated-normal candidates
     [n_rows,B,nsamp=width], 6 -> survival level of the prior draw [n_rows,B]."""
-    shape = {2: (n_rows, B, 2, LATENT), 3: (n_rows, B, width, 41), 4: (n_rows, B, 2 * LATENT), 5: (n_rows, B, width),
+    shape = {2: (n_rows, B, 2, LATENT), 3: (n_rows, B, width, 41), 4: (n_rows, B, width or 2 * LATENT), 5: (n_rows, B, width),
              6: (n_rows, B)}.get(kind, (n_rows, width))
     out = torch.empty(shape, dtype=torch.float32, device=device)
     N.check(N.lib().bnn_philox_normal_f32(kind, int(philox_seed), int(id0), n_rows, B, int(system_id0), width, N.ptr(out),

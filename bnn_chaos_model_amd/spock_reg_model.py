@@ -84,13 +84,19 @@ def mlp(in_n, out_n, hidden, layers):
     return nn.Sequential(*result)
 
 
-_STATE_LAYOUT = (("input_noise_logvar", (41,)), ("summary_noise_logvar", (40,)),
-                 ("feature_nn.0.weight", (40, 41)), ("feature_nn.0.bias", (40,)),
-                 ("feature_nn.2.weight", (40, 40)), ("feature_nn.2.bias", (40,)),
-                 ("feature_nn.4.weight", (20, 40)), ("feature_nn.4.bias", (20,)),
-                 ("regress_nn.0.weight", (40, 40)), ("regress_nn.0.bias", (40,)),
-                 ("regress_nn.2.weight", (40, 40)), ("regress_nn.2.bias", (40,)),
-                 ("regress_nn.4.weight", (2, 40)), ("regress_nn.4.bias", (2,)))
+def _state_layout(fix_megno=False):
+    """state_dict order and shapes (reference :734-761); with fix_megno the summary is 42 wide (:360-362): d = 7665."""
+    sm = 42 if fix_megno else 40
+    return (("input_noise_logvar", (41,)), ("summary_noise_logvar", (sm,)),
+            ("feature_nn.0.weight", (40, 41)), ("feature_nn.0.bias", (40,)),
+            ("feature_nn.2.weight", (40, 40)), ("feature_nn.2.bias", (40,)),
+            ("feature_nn.4.weight", (20, 40)), ("feature_nn.4.bias", (20,)),
+            ("regress_nn.0.weight", (40, sm)), ("regress_nn.0.bias", (40,)),
+            ("regress_nn.2.weight", (40, 40)), ("regress_nn.2.bias", (40,)),
+            ("regress_nn.4.weight", (2, 40)), ("regress_nn.4.bias", (2,)))
+
+
+_STATE_LAYOUT = _state_layout(False)
 
 
 def _gpu():
@@ -119,22 +125,23 @@ class VarModel:
         self.fix_megno2 = hparams.get("fix_megno2", False)
         self.include_angles = hparams.get("include_angles", False)
         self.n_features = hparams["time_series_features"] * (1 + int(hparams["include_derivatives"]))
-        if (self.n_features, hparams["hidden"], hparams["latent"], hparams["in"], hparams["out"]) != (41, 40, 20, 1, 1) \
-                or self.fix_megno:
-            raise NotImplementedError("only the 41->40->40->20 / 40->40->40->2 network of the pretrained ensemble "
-                                      "(in=1, out=1, fix_megno=False) is built for gfx950")
+        if (self.n_features, hparams["hidden"], hparams["latent"], hparams["in"], hparams["out"]) != (41, 40, 20, 1, 1):
+            raise NotImplementedError("only the 41->40->40->20 / 40(42)->40->40->2 network of the pretrained ensemble "
+                                      "(in=1, out=1) is built for gfx950")
+        self.fix_megno = bool(self.fix_megno)
         # reference init order (:359-362): feature_nn, regress_nn, then the two noise parameters
         feature_nn = mlp(self.n_features, hparams["latent"], hparams["hidden"], hparams["in"])
-        regress_nn = mlp(hparams["latent"] * 2, 2, hparams["hidden"], hparams["out"])
+        regress_nn = mlp(hparams["latent"] * 2 + int(self.fix_megno) * 2, 2, hparams["hidden"], hparams["out"])
         self.lowest = 0.1 if hparams.get("lower_std", False) else 0.5
         sd = OrderedDict()
         sd["input_noise_logvar"] = torch.zeros(self.n_features) - 2
-        sd["summary_noise_logvar"] = torch.zeros(hparams["latent"] * 2) - 2
+        sd["summary_noise_logvar"] = torch.zeros(hparams["latent"] * 2 + int(self.fix_megno) * 2) - 2
         for k, v in feature_nn.state_dict().items():
             sd["feature_nn." + k] = v
         for k, v in regress_nn.state_dict().items():
             sd["regress_nn." + k] = v
-        assert tuple((k, tuple(v.shape)) for k, v in sd.items()) == _STATE_LAYOUT
+        self._layout = _state_layout(self.fix_megno)
+        assert tuple((k, tuple(v.shape)) for k, v in sd.items()) == self._layout
         self._pending_draw = None
         self._w = torch.cat([v.detach().reshape(-1) for v in sd.values()]).float().contiguous()  # flat vector [d]
 
@@ -206,14 +213,14 @@ class VarModel:
 
     def state_dict(self):
         out, i = OrderedDict(), 0
-        for k, shp in _STATE_LAYOUT:
+        for k, shp in self._layout:
             n = int(np.prod(shp))
             out[k] = self._w[i:i + n].reshape(shp)
             i += n
         return out
 
     def load_state_dict(self, sd):
-        self._w = torch.cat([sd[k].detach().reshape(-1).float() for k, _ in _STATE_LAYOUT]).to(self._device).contiguous()
+        self._w = torch.cat([sd[k].detach().reshape(-1).float() for k, _ in self._layout]).to(self._device).contiguous()
 
     def flatten(self):
         """Convert state dict into a vector (:734-746)."""
@@ -232,7 +239,11 @@ class VarModel:
                                         self.include_eplusminus)
 
     def _plan(self):
-        return ops.get_plan(self.zero_mask(), self.lowest)
+        return ops.get_plan(self.zero_mask(), self.lowest, fix_megno=self.fix_megno)
+
+    @property
+    def _summary_width(self):
+        return 42 if self.fix_megno else 40
 
     @staticmethod
     def _check_x(x):
@@ -264,9 +275,10 @@ class VarModel:
     def zero_eplusminus(self, x):
         x = x.clone(); x[..., self.eplusminus_location] = 0; return x
 
-    def _forward_gpu(self, x, W, noisy, want_debug=False):
+    def _forward_gpu(self, x, W, noisy, want_debug=False, plan=None):
         """x [B,T,41] on any device, W [1,d] -> (out[B,2] on x.device, pre, summ)."""
         self._check_x(x)
+        plan = plan or self._plan()
         dev_in = x.device
         g = _gpu()
         xg = x.detach().to(g, torch.float32).contiguous()
@@ -279,15 +291,15 @@ class VarModel:
             e1 = torch.randn(B, 20, device=dev_in)
             e2 = torch.randn(B, 20, device=dev_in)
             if noisy:
-                eps_sum = torch.randn(B, 40, device=dev_in)
+                eps_sum = torch.randn(B, self._summary_width, device=dev_in)
             eps = torch.stack([e1, e2], dim=1)[None].to(g).contiguous()
             if noisy:
                 eps_in = eps_in[None].to(g).contiguous()
                 eps_sum = eps_sum[None].to(g).contiguous()
-            res = ops.forward(xg, W.to(g), eps=eps, eps_in=eps_in, eps_sum=eps_sum, plan=self._plan(), debug=want_debug)
+            res = ops.forward(xg, W.to(g), eps=eps, eps_in=eps_in, eps_sum=eps_sum, plan=plan, debug=want_debug)
         else:
             res = ops.forward(xg, W.to(g), philox_seed=self.philox_seed, draw_id0=self._next_philox_id(),
-                              plan=self._plan(), debug=want_debug, noisy=noisy)
+                              plan=plan, debug=want_debug, noisy=noisy)
         if want_debug:
             return tuple(r[0].to(dev_in) for r in res)
         return res[0].to(dev_in)
@@ -295,13 +307,11 @@ class VarModel:
     # ---- reference API -----------------------------------------------------------------------------------------
     def compute_summary_stats(self, x):
         """feature_nn -> mean/std time pool with sampled moments (:416-435).  x is used as given (no masking)."""
-        saved = (self.fix_megno2, self.include_mmr, self.include_nan, self.include_eplusminus)
-        try:  # the reference applies the masks in forward(), not here: run the kernel with an empty mask
-            self.fix_megno2, self.include_mmr, self.include_nan, self.include_eplusminus = False, True, True, True
-            _, _, summ = self._forward_gpu(x, self._w[None], noisy=False, want_debug=True)
-        finally:
-            self.fix_megno2, self.include_mmr, self.include_nan, self.include_eplusminus = saved
-        return summ
+        # the reference applies the masks in forward(), not here: run the kernel with an empty mask; the MEGNO statistics of
+        # fix_megno are appended by forward() (:509-510), not by this method (:416-435)
+        plan = ops.get_plan(0, self.lowest, fix_megno=self.fix_megno)
+        _, _, summ = self._forward_gpu(x, self._w[None], noisy=False, want_debug=True, plan=plan)
+        return summ[:, :40]
 
     def predict_instability(self, summary_stats):
         """regress_nn + soft_clamp (:437-442) on an explicit summary -> (mu [B,1], std [B,1]) on its device."""
@@ -317,7 +327,7 @@ class VarModel:
 
     def add_summary_noise(self, summary_stats):
         """summary + randn_like(summary) * exp(summary_noise_logvar / 2) (:448-450); forward() fuses this step."""
-        lv = self._w[41:81].to(summary_stats.device)
+        lv = self._w[41:41 + self._summary_width].to(summary_stats.device)
         return summary_stats + torch.randn_like(summary_stats) * torch.exp(lv[None, :] / 2)
 
     def forward(self, x, noisy_val=True):

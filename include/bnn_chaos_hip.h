@@ -43,7 +43,10 @@ typedef struct bnn_arch {
     int32_t n_features; /* hparams['time_series_features'] = 41                                  */
     int32_t hidden;     /* hparams['hidden'] = 40                                                */
     int32_t latent;     /* hparams['latent'] = 20                                                */
-    int32_t reserved;
+    int32_t fix_megno;  /* hparams['fix_megno'] (spock_reg_model.py:360-362): 1 = the summary is 42 wide ([.. | mean_t, std_t of the
+                           raw MEGNO column 7], :480-491, :509-510), summary_noise_logvar [42], regress_nn.0 [40,42], d = 7665;
+                           the reference zeroes column 7 as well then (:488-491: set bit 7 of zero_mask); the statistics are taken
+                           from the raw column whatever the mask.  0 for every pretrained checkpoint.  (Was `reserved`.) */
     uint64_t zero_mask; /* bit f set: input column f is zeroed before feature_nn
                            (zero_megno/zero_mmr/zero_nan/zero_eplusminus, spock_reg_model.py:452-500) */
     float lowest_std;   /* soft_clamp floor of std: 0.5, or 0.1 with lower_std (:363-365)         */
@@ -55,7 +58,7 @@ typedef struct bnn_plan bnn_plan; /* opaque: device-resident operand tables for 
 int bnn_abi_version(void);
 const char* bnn_last_error(void);
 int bnn_device_count(void); /* number of visible HIP devices, or negative bnn_status */
-int bnn_param_count(const bnn_arch* arch); /* d (7583), or negative */
+int bnn_param_count(const bnn_arch* arch); /* d (7583; 7665 with fix_megno), or negative */
 
 /* Plans own a few KB of device memory; create/destroy allocate and synchronise, nothing else does. */
 int bnn_plan_create(const bnn_arch* arch, bnn_plan** out);

@@ -18,9 +18,10 @@
  *
  * Flat parameter vector layout (reference state_dict order, spock_reg_model.py:734-761;
  * own parameters precede submodules), F=n_features, H=hidden, L=latent:
- *   input_noise_logvar[F] | summary_noise_logvar[2L] |
+ *   input_noise_logvar[F] | summary_noise_logvar[S] |
  *   feature_nn.0.{weight[H,F],bias[H]} | feature_nn.2.{weight[H,H],bias[H]} | feature_nn.4.{weight[L,H],bias[L]} |
- *   regress_nn.0.{weight[H,2L],bias[H]} | regress_nn.2.{weight[H,H],bias[H]} | regress_nn.4.{weight[2,H],bias[2]}
+ *   regress_nn.0.{weight[H,S],bias[H]} | regress_nn.2.{weight[H,H],bias[H]} | regress_nn.4.{weight[2,H],bias[2]}
+ * with S = 2L summary entries, or 2L + 2 with fix_megno (:360-362).
  */
 #include <math.h>
 #include <stdint.h>
@@ -49,7 +50,11 @@ typedef struct {
     int32_t T;          /* timesteps per system (100)                    */
     uint64_t zero_mask; /* bit f set => column f zeroed (spock_reg_model.py:452-478, applied :884-897) */
     double lowest;      /* soft_clamp floor for std: 0.5, or 0.1 with lower_std (:363-365)            */
+    int32_t fix_megno;  /* hparams['fix_megno'] (:360-362): the summary gains [mean_t, std_t] of the RAW MEGNO column (7),
+                           regress_nn.0 and summary_noise_logvar are 2 wider (:488-491, :509-510, summarize_megno :480-484) */
+    int32_t reserved;
 } orc_arch;
+#define MEGNO_COL 7 /* self.megno_location (:371) */
 
 /* Optional accumulation schedule.  The reference's summation order inside nn.Linear /
  * torch.std is whatever MKL and ATen do; the algorithm does not define one.  With sched==NULL the
@@ -67,8 +72,8 @@ typedef struct {
 } orc_schedule;
 
 int FN(param_count)(const orc_arch* a) {
-    int F = a->n_features, H = a->hidden, L = a->latent;
-    return F + 2 * L + (H * F + H) + (H * H + H) + (L * H + L) + (H * 2 * L + H) + (H * H + H) + (2 * H + 2);
+    int F = a->n_features, H = a->hidden, L = a->latent, S = 2 * L + (a->fix_megno ? 2 : 0);
+    return F + S + (H * F + H) + (H * H + H) + (L * H + L) + (H * S + H) + (H * H + H) + (2 * H + 2);
 }
 
 /* ---- SWAG weight draw: SWAGModel.sample_weights (spock_reg_model.py:815-838) ------------------
@@ -134,7 +139,8 @@ static inline REAL soft_clamp(REAL x, double lo, double hi) {
  *   x[B,T,F]; w = flat parameter vector; eps1, eps2 [B,L] = the two randn_like draws of
  *   compute_summary_stats (:426-427, ALWAYS consumed); eps_in [B,T,F] (:445) and eps_sum [B,2L] (:449)
  *   are consumed only by forward(noisy_val=True) -- pass NULL for forward_swag_fast / noisy_val=False.
- *   Optional outputs: pre_clamp[B,2] (regress_nn output), summary[B,2L] (before summary noise),
+ *   With fix_megno the summary is S = 2L + 2 wide (eps_sum [B,S], summary [B,S]).
+ *   Optional outputs: pre_clamp[B,2] (regress_nn output), summary[B,S] (before summary noise),
  *   latents[B,T,L] (feature_nn output). */
 int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, const REAL* eps_in, const REAL* eps1,
                 const REAL* eps2, const REAL* eps_sum, const orc_schedule* sched, REAL* out, REAL* pre_clamp,
@@ -145,16 +151,18 @@ int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, cons
     const int P = sched ? sched->pool_parts : 1;
     if (P != 1 && P != 4) return -3;
     if (P == 4 && T % 4) return -3;
+    const int FM = a->fix_megno ? 1 : 0, S = 2 * L + 2 * FM;
+    if (FM && F <= MEGNO_COL) return -2;
     const REAL* in_logvar = w;
     const REAL* sum_logvar = w + F;
-    const REAL* W1 = sum_logvar + 2 * L;
+    const REAL* W1 = sum_logvar + S;
     const REAL* b1 = W1 + H * F;
     const REAL* W2 = b1 + H;
     const REAL* b2 = W2 + H * H;
     const REAL* W3 = b2 + H;
     const REAL* b3 = W3 + L * H;
     const REAL* W4 = b3 + L;
-    const REAL* b4 = W4 + H * 2 * L;
+    const REAL* b4 = W4 + H * S;
     const REAL* W5 = b4 + H;
     const REAL* b5 = W5 + H * H;
     const REAL* W6 = b5 + H;
@@ -171,18 +179,29 @@ int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, cons
     int rc = 0;
 #pragma omp parallel
     {
-        REAL* xr = (REAL*)malloc(sizeof(REAL) * (size_t)(F + 3 * H + 2 * L + 2 * L * 4 + 8));
+        REAL* xr = (REAL*)malloc(sizeof(REAL) * (size_t)(F + 3 * H + 2 * L + 2 + 2 * L * 4 + 8));
         REAL* h1 = xr + F;
         REAL* h2 = h1 + H;
         REAL* y = h2 + H;        /* [L] */
-        REAL* s = y + L;         /* [2L] summary */
-        REAL* mean = s + 2 * L;  /* [4][L] partition means */
+        REAL* s = y + L;         /* [S] summary */
+        REAL* mean = s + 2 * L + 2; /* [4][L] partition means */
         REAL* m2 = mean + 4 * L; /* [4][L] partition M2    */
+        REAL gmean[4], gm2[4];   /* the same pool over the raw MEGNO column (fix_megno) */
 #pragma omp for schedule(static)
         for (int64_t b = 0; b < B; ++b) {
             for (int i = 0; i < 4 * L; ++i) { mean[i] = 0; m2[i] = 0; }
+            for (int i = 0; i < 4; ++i) { gmean[i] = 0; gm2[i] = 0; }
             for (int t = 0; t < T; ++t) {
                 const REAL* xi = x + ((size_t)b * T + t) * F;
+                if (FM) { /* summarize_megno (:480-484) sees x BEFORE zero_megno and before any noise (:488-491) */
+                    int p = (P == 4) ? (t & 3) : 0;
+                    int cnt = (P == 4) ? (t >> 2) + 1 : t + 1;
+                    REAL rc_n = (REAL)1 / (REAL)cnt;
+                    REAL delta = xi[MEGNO_COL] - gmean[p];
+                    REAL mnew = FMA(delta, rc_n, gmean[p]);
+                    gm2[p] = FMA(delta, xi[MEGNO_COL] - mnew, gm2[p]);
+                    gmean[p] = mnew;
+                }
                 for (int f = 0; f < F; ++f) {
                     /* zero_megno/mmr/nan/eplusminus: x - mask == 0 on masked columns (:452-478) */
                     REAL v = ((a->zero_mask >> f) & 1) ? (REAL)0 : xi[f];
@@ -218,6 +237,20 @@ int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, cons
                         }
                     half_n = half_n * (REAL)2;
                 }
+                if (FM) {
+                    REAL hn = (REAL)(T / 4) * (REAL)0.5;
+                    for (int stage = 0; stage < 2; ++stage) {
+                        int pa = 0, pb = stage == 0 ? 1 : 2;
+                        for (int rep = 0; rep < (stage == 0 ? 2 : 1); ++rep, pa += 2, pb += 2) {
+                            REAL dl = gmean[pb] - gmean[pa];
+                            REAL mm = (gmean[pa] + gmean[pb]) * (REAL)0.5;
+                            REAL q = (gm2[pa] + gm2[pb]) + (dl * dl) * hn;
+                            gmean[pa] = mm;
+                            gm2[pa] = q;
+                        }
+                        hn = hn * (REAL)2;
+                    }
+                }
             }
             for (int n = 0; n < L; ++n) { /* compute_summary_stats, :418-431 */
                 REAL sample_mu = mean[n];
@@ -230,11 +263,15 @@ int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, cons
                 s[n] = mu_s;
                 s[L + n] = SQRT(FABS(var_s) + (REAL)1e-5); /* EPSILON, :337 */
             }
-            if (summary) memcpy(summary + (size_t)b * 2 * L, s, sizeof(REAL) * 2 * L);
+            if (FM) { /* torch.cat([summary_stats, megno_avg_std], dim=1) (:509-510): mean, then torch.std (unbiased) */
+                s[2 * L] = gmean[0];
+                s[2 * L + 1] = SQRT(gm2[0] / (REAL)(T - 1));
+            }
+            if (summary) memcpy(summary + (size_t)b * S, s, sizeof(REAL) * S);
             if (eps_sum) /* add_summary_noise :448-450 */
-                for (int n = 0; n < 2 * L; ++n) s[n] = s[n] + eps_sum[(size_t)b * 2 * L + n] * EXP(sum_logvar[n] / (REAL)2);
+                for (int n = 0; n < S; ++n) s[n] = s[n] + eps_sum[(size_t)b * S + n] * EXP(sum_logvar[n] / (REAL)2);
             REAL r[2];
-            linear_row(W4, b4, H, 2 * L, s, h1, 1, ord[3], ordn[3]); /* regress_nn (:360, :438) */
+            linear_row(W4, b4, H, S, s, h1, 1, ord[3], ordn[3]); /* regress_nn (:360, :438) */
             linear_row(W5, b5, H, H, h1, h2, 1, ord[4], ordn[4]);
             linear_row(W6, b6, 2, H, h2, r, 0, ord[5], ordn[5]);
             if (pre_clamp) { pre_clamp[b * 2] = r[0]; pre_clamp[b * 2 + 1] = r[1]; }

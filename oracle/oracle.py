@@ -15,7 +15,7 @@ _BUILD = os.path.join(_HERE, "_build")
 
 class OrcArch(C.Structure):
     _fields_ = [("n_features", C.c_int32), ("hidden", C.c_int32), ("latent", C.c_int32), ("T", C.c_int32),
-                ("zero_mask", C.c_uint64), ("lowest", C.c_double)]
+                ("zero_mask", C.c_uint64), ("lowest", C.c_double), ("fix_megno", C.c_int32), ("reserved", C.c_int32)]
 
 
 class OrcSchedule(C.Structure):
@@ -87,10 +87,10 @@ def _arr(a, dt):
     return None if a is None else np.ascontiguousarray(a, dtype=dt)
 
 
-def make_arch(T=100, zero_mask=None, lowest=0.5, n_features=41, hidden=40, latent=20):
+def make_arch(T=100, zero_mask=None, lowest=0.5, n_features=41, hidden=40, latent=20, fix_megno=False):
     if zero_mask is None:
-        zero_mask = zero_mask_from_flags()
-    return OrcArch(n_features, hidden, latent, T, zero_mask, lowest)
+        zero_mask = zero_mask_from_flags(fix_megno=fix_megno)
+    return OrcArch(n_features, hidden, latent, T, zero_mask, lowest, int(bool(fix_megno)), 0)
 
 
 def make_schedule(orders=None, pool_parts=1):
@@ -143,7 +143,7 @@ def forward(x, w, eps1, eps2, eps_in=None, eps_sum=None, arch=None, sched=None, 
     assert eps1.shape == (B, L) and eps2.shape == (B, L)
     out = np.empty((B, 2), dt)
     pre = np.empty((B, 2), dt) if extras else None
-    summ = np.empty((B, 2 * L), dt) if extras else None
+    summ = np.empty((B, 2 * L + 2 * int(arch.fix_megno)), dt) if extras else None
     lat = np.empty((B, T, L), dt) if extras else None
     rc = getattr(lib(), pfx + "forward")(C.byref(arch), _p(x), C.c_int64(B), _p(w), _p(eps_in), _p(eps1), _p(eps2),
                                          _p(eps_sum), C.byref(sched) if sched is not None else None, _p(out), _p(pre),

@@ -147,6 +147,43 @@ def test_register_dataflow_emulation_matches_oracle(N, inputs):
     assert np.abs(lat - ex["latents"][0, :8]).max() < 5e-5
 
 
+def test_fix_megno_layout_tables(N):
+    """hparams['fix_megno'] (bnn_arch.fix_megno = 1): d = 7665, regress_nn.0 accumulates 42 inputs in 11 k-steps, every parameter of
+    the wider layer sits in exactly one fragment slot, feature_nn's registers hold the same weights two floats further on."""
+    L = N.lib()
+    a = N.BnnArch(41, 40, 20, 1, V50_MASK, 0.5, 0)
+    assert L.bnn_param_count(C.byref(a)) == 7665
+    bad = N.BnnArch(41, 40, 20, 2, V50_MASK, 0.5, 0)
+    assert L.bnn_param_count(C.byref(bad)) == N.ERR_INVALID
+
+    def order(layer):
+        buf = np.zeros(64, np.int32)
+        n = N.check(L.bnn_layer_order(C.byref(a), layer, 0, buf.ctypes.data, 64))
+        return buf[:n].tolist()
+
+    def table(which):
+        n = N.check(L.bnn_fragment_table(C.byref(a), 0, which, None, 0))
+        t = np.zeros(n, np.int16)
+        N.check(L.bnn_fragment_table(C.byref(a), 0, which, t.ctypes.data, n))
+        return t.astype(np.int64)
+
+    assert sorted(order(3)) == list(range(42)) and order(3)[-2:] == [40, 41]
+    assert sorted(order(4)) == list(range(40)) and order(0) == [0] + list(range(8, 38))
+    off_w4 = 41 + 42 + 1640 + 40 + 1600 + 40 + 800 + 20
+    f2 = table(2).reshape(-1, 64)
+    assert f2.shape[0] == 33 + 30 + 10 + 12 + 12 + 4
+    a2 = f2[:33 + 30 + 10].ravel()
+    a2 = a2[a2 != 7665]
+    want = set(range(off_w4, off_w4 + 40 * 42)) | set(range(off_w4 + 1680 + 40, off_w4 + 1680 + 40 + 1600)) | \
+        set(range(off_w4 + 1680 + 40 + 1640, off_w4 + 1680 + 40 + 1640 + 80))
+    assert len(a2) == len(want) and set(a2.tolist()) == want
+    w1 = table(1)
+    w1 = w1[w1 != 7665]
+    w1_plain = _image(N, V50_MASK, 0)
+    w1_plain = w1_plain[w1_plain != OFF["D"]]
+    assert np.array_equal(w1, w1_plain + 2)                      # everything behind summary_noise_logvar moves by two
+
+
 def test_checkpoint_roundtrip_and_reference_file(tmp_path):
     from bnn_chaos_model_amd import checkpoint, spock_reg_model as srm
     z = load_golden("swag_v50_0.npz")

@@ -245,3 +245,43 @@ def test_truncnorm_two_sided_and_right_sided_forms():
         got = stats.truncnorm_first_good(z["loc"], z["scale"], z[f"{name}_normals"], float(z[f"{name}_left"]), float(z[f"{name}_right"]))
         assert got.dtype == np.float32 and np.array_equal(got, z[f"{name}_out"]), name
     assert (z["two_sided_out"][0, :4] > 9).all()      # nothing inside (4, 9): the first candidate came back
+
+
+def _tp(z, pfx):
+    return [z[f"{pfx}_{i:03d}"] for i in range(int(z[pfx + "_n"]))]
+
+
+def test_fix_megno_branch_matches_reference():
+    """hparams['fix_megno'] = True (spock_reg_model.py:360-362, 480-491, 509-510): no pretrained checkpoint uses it, so the fixture
+    (tests/golden/make_golden_megno.py) runs the unmodified reference class with that flag on a synthetic SWAG state.  d = 7665, the
+    summary is 42 wide, its last two entries are the time mean / unbiased std of the RAW MEGNO column."""
+    z = load_golden("case_megno.npz")
+    arch = orc.make_arch(T=100, fix_megno=True)
+    assert z["w_avg"].shape == (7665,) and (arch.zero_mask >> 7) & 1
+    assert dict(zip(z["state_keys"].tolist(), z["state_sizes"].tolist()))["regress_nn.0.weight"] == 40 * 42
+    t = _tp(z, "swagfast_tape")
+    w = orc.swag_draw(z["w_avg"], z["w2_avg"], z["pre_D"], t[0], t[1])
+    assert np.abs(w - z["swagfast_w"]).max() <= 2e-6
+    nbad, mx = close_report(orc.forward(z["x"], w, t[2], t[3], arch=arch), z["swagfast_out"])
+    assert nbad == 0, (nbad, mx)
+    for noisy in (0, 1):
+        t = _tp(z, f"forward_noisy{noisy}_tape")
+        assert [a.shape for a in t] == ([(16, 100, 41)] if noisy else []) + [(16, 20), (16, 20)] + ([(16, 42)] if noisy else [])
+        kw = dict(eps_in=t[0], eps_sum=t[3]) if noisy else {}
+        e1, e2 = (t[1], t[2]) if noisy else (t[0], t[1])
+        out, ex = orc.forward(z["x"], z["swagfast_w"], e1, e2, arch=arch, extras=True, **kw)
+        nbad, mx = close_report(out, z[f"forward_noisy{noisy}_out"])
+        assert nbad == 0, (noisy, nbad, mx)
+        ref = z[f"forward_noisy{noisy}_summary"]
+        assert ex["summary"].shape == ref.shape == (16, 42)
+        assert np.abs(ex["summary"][:, 40:] - ref[:, 40:]).max() <= 1e-5 * np.abs(ref[:, 40:]).max()
+        if not noisy:   # the MEGNO statistics are those of the raw column, whatever the mask does to it afterwards
+            assert np.allclose(ref[:, 40], z["x"][:, :, 7].mean(1), rtol=1e-6) and np.allclose(ref[:, 41], z["x"][:, :, 7].std(1, ddof=1), rtol=1e-5)
+            nbad, mx = close_report(ex["summary"][:, :40], ref[:, :40], rtol=2e-5, atol=2e-5)
+            assert nbad == 0, (nbad, mx)
+    # the pool schedule of the GPU kernels (4 strided partitions, pairwise merge) changes rounding only
+    sch = orc.make_schedule(None, pool_parts=4)
+    t = _tp(z, "forward_noisy0_tape")
+    o4 = orc.forward(z["x"], z["swagfast_w"], t[0], t[1], arch=arch, sched=sch)
+    nbad, mx = close_report(o4, z["forward_noisy0_out"])
+    assert nbad == 0, (nbad, mx)
