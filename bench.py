@@ -238,6 +238,8 @@ def parse(argv=None):
     ap.add_argument("--allow-gloo", action="store_true", help="accept a gloo moments gather when RCCL cannot start (the line says degraded)")
     ap.add_argument("--launcher-selftest", action="store_true", help="ranks only rendezvous (gloo, CPU) and report; no GPU work")
     ap.add_argument("--rendezvous-timeout", type=float, default=120.0, help="seconds a rank waits for the others in init_process_group")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even at world size 1 (under a launcher): "
+                    "exercises the N > 1 code path -- init, collective, event timing -- on a one-GPU box")
     args = ap.parse_args(argv)
     wl = WORKLOADS[args.workload]
     if args.steps is None:
@@ -283,7 +285,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     degraded = False
     ranks_seen = 1
-    if world > 1:
+    use_dist = world > 1 or (args.force_dist and "WORLD_SIZE" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             dist.init_process_group("gloo", timeout=pg_timeout)
@@ -309,7 +312,7 @@ def main():
         ones = torch.ones(1, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
-    on_nccl = world > 1 and dist.get_backend() == "nccl"
+    on_nccl = use_dist and dist.get_backend() == "nccl"
 
     wl = dict(WORKLOADS[args.workload])
     if args.systems:
@@ -354,12 +357,12 @@ def main():
     def gather(local, n_total, i, timed):
         """The path's one exchange.  RCCL: HIP events on the current stream bracket it (the collective's stream is joined to the
         current stream on both sides); gloo (rehearsal / degraded): staged through the host, so a host clock around it."""
-        if world == 1:
+        if not use_dist:
             return local
         if on_nccl:
             if timed:
                 gv0[i].record()
-            res = all_gather_moments(local, n_total)
+            res = all_gather_moments(local, n_total, force=args.force_dist)
             if timed:
                 gv1[i].record()
             return res
@@ -397,7 +400,7 @@ def main():
         return gather(ops.moments(o), world * B, i, timed)  # [B,4] float64 per rank
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -410,7 +413,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
-    if world > 1:
+    if use_dist:
         gather_ms = (sum(a.elapsed_time(b) for a, b in zip(gv0, gv1)) if on_nccl else sum(gather_host_ms)) / args.steps
         cdev = dev if on_nccl else "cpu"
         t = torch.tensor([dt, gather_ms], dtype=torch.float64, device=cdev)
@@ -460,7 +463,7 @@ def main():
                        "features": 41, "noise": "in-kernel Philox4x32-10", "kernel": kernel,
                        "sharding": (f"whole simulations ({trios} trios each) over {world} rank(s), all-gather of {payload}" if trios > 1 else
                                     f"systems over {world} rank(s), all-gather of {payload}"),
-                       "collective": (dist.get_backend() if world > 1 else "none"), "degraded": degraded, "ranks_seen": ranks_seen,
+                       "collective": (dist.get_backend() if use_dist else "none"), "degraded": degraded, "ranks_seen": ranks_seen,
                        "gather_ms": gather_ms, "gather_bytes_per_rank": int(res_last.shape[0] // world * res_last.shape[1] * res_last.element_size()),
                        "kernel_ms_min": min(kern_ms_ranks), "kernel_ms_max": max(kern_ms_ranks),
                        "timing_note": "ms_per_step = wall clock of the whole step, max over ranks; kernel_ms_* = HIP events around the compute "
@@ -495,7 +498,7 @@ def main():
             except Exception as e:
                 res["cpu_baseline_torch"] = {"value": None, "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

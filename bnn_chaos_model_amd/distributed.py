@@ -27,10 +27,11 @@ def shard_bounds(B, world, group=1):
     return out
 
 
-def all_gather_moments(local, B, group=None):
-    """local [B_r, M] (this rank's slice, in shard_bounds order) -> [B, M] on every rank.  One collective."""
+def all_gather_moments(local, B, group=None, force=False):
+    """local [B_r, M] (this rank's slice, in shard_bounds order) -> [B, M] on every rank.  One collective.
+    force: issue the collective even at world size 1 (a self-gather; lets a one-GPU box exercise the RCCL call)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return local
     bounds = shard_bounds(B, world)
     nmax = max(hi - lo for lo, hi in bounds)

@@ -1,0 +1,41 @@
+"""RCCL on the one-GPU box: the calls the N > 1 bench makes (init with device_id, barrier, all_gather_into_tensor of the float64
+moments, all_reduce(MAX), per-rank all_gather, HIP-event timing of the gather) executed for real at world size 1, as a child process
+under torch.distributed.run exactly as the driver launches `bench.py --gpus N`.  Needs an MI355X."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_under_launcher(*bench_args):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--force-dist",
+           "--rendezvous-timeout", "60"] + list(bench_args)
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, (out.returncode, out.stderr[-2000:])
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("workload,extra", (("tiny", ()), ("c5", ("--systems", "3000", "--samples", "4"))))
+def test_bench_gather_runs_on_rccl(workload, extra):
+    """moments gather (tiny) and the whole-simulation bands gather (c5 shape, 1000 simulations x 3 trios) through RCCL."""
+    r = run_under_launcher("--workload", workload, "--steps", "2", "--warmup", "1", *extra)
+    c = r["config"]
+    assert c["collective"] == "nccl" and c["degraded"] is False and c["ranks_seen"] == 1 and r["n_gpus"] == 1
+    assert c["gather_ms"] > 0.0 and c["kernel_ms_min"] == c["kernel_ms_max"] > 0.0
+    assert c["gather_bytes_per_rank"] == (3000 // 3 * 6 * 4 if workload == "c5" else 512 * 4 * 8)
+    assert r["value"] > 0 and r["roofline"]["traffic_measured_in_run"] is False
