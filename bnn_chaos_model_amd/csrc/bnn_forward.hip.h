@@ -80,12 +80,15 @@ constexpr size_t fwd_lds_bytes() { return sizeof(float) * (FLAT_LDS + MAXK + BIA
 // MEGNO: hparams['fix_megno'] (spock_reg_model.py:360-362, 480-491, 509-510): the summary gains the time mean and unbiased std of
 // the RAW MEGNO column (read before the masks and before any noise), pooled with the same per-lane Welford + quad merge as the
 // latents; regress_nn.0 takes 42 inputs (an 11th k-step), the flat vector is Lay<true> (d = 7665).
-template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false>
+// XNOISE (noisy forms): the input and summary noise come from explicit tensors (parity mode: the reference's numbers) instead of
+// in-kernel Philox; a template parameter rather than a wave-uniform branch per noise block (7 branches + dead loads per tile).
+template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false, bool XNOISE = false>
 __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) {
     using WRL = WR<KIN>;
     using Y = Lay<MEGNO>;
     constexpr int D = Y::D;                                  // shadows the fix_megno = False constant
     static_assert(!MEGNO || !STATS, "the fused statistics tail is not built for fix_megno");
+    static_assert(!XNOISE || NOISY, "explicit input / summary noise belongs to the noisy forms");
     constexpr bool PREF = BNN_BIAS_PREFETCH && KIN == 31 && !MEGNO;   // the other forms have no registers to spare for it
     constexpr bool RBATCH = BNN_RELU_BATCH != 0;
     static_assert(!NOISY || (KIN == F && !FUSED && !STATS), "the noisy forward multiplies all 41 columns and takes materialised weights");
@@ -249,12 +252,11 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                 if constexpr (NOISY) {
                     const int t = 4 * it + ph0;
                     tblk = t * NIN_BLOCKS;
-                    if (p.eps_in) er = p.eps_in + (r * p.B + sysc0) * rowstride + (int64_t)t * F;
+                    if constexpr (XNOISE) er = p.eps_in + (r * p.B + sysc0) * rowstride + (int64_t)t * F;
                 }
-                const bool explicit_noise = NOISY && p.eps_in != nullptr;  // wave-uniform
                 auto noise6 = [&](int blk) {
                     float n6[6];
-                    if (explicit_noise) {
+                    if constexpr (XNOISE) {
 #pragma unroll
                         for (int j = 0; j < 6; ++j) n6[j] = (6 * blk + j < F) ? er[6 * blk + j] : 0.0f;
                     } else {
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         if constexpr (MEGNO) skeep[10] = g < 2 ? megscr[wave * MEGSCR + c * 2 + g] : 0.0f;   // torch.cat([summary_stats, megno_avg_std]) (:509-510)
         if constexpr (NOISY) {  // add_summary_noise (:448-450)
             const int64_t sc = validb ? sysb : b1 - 1;
-            if (p.eps_sum) {
+            if constexpr (XNOISE) {
                 const float* es = p.eps_sum + (r * p.B + sc) * Y::SM;
 #pragma unroll
                 for (int ks = 0; ks < 10; ++ks) skeep[ks] = skeep[ks] + es[kmap_summary(ks, g)] * nsc[F + kmap_summary(ks, g)];
@@ -538,16 +540,16 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     }
 }
 
-template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false>
+template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false, bool XNOISE = false>
 inline hipError_t launch_forward_form(unsigned nblk, hipStream_t st, const FwdParams& p) {
     static bool attr_set[MAX_DEVICES];  // the attribute belongs to the (function, device) pair
     const int slot = current_device_slot();
     if (!attr_set[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO, XNOISE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set[slot] = true;
     }
-    hipLaunchKernelGGL((bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO>), dim3(nblk), dim3(256), fwd_lds_bytes<KIN>(), st, p);
+    hipLaunchKernelGGL((bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO, XNOISE>), dim3(nblk), dim3(256), fwd_lds_bytes<KIN>(), st, p);
     return hipGetLastError();
 }
 

@@ -4,7 +4,8 @@
 
 namespace bnn {
 hipError_t launch_fwd_megno(bool k31, bool fused, bool noisy, unsigned nblk, hipStream_t st, const FwdParams& p) {
-    if (noisy) return launch_forward_form<F, false, true, false, true>(nblk, st, p);
+    if (noisy) return p.eps_in ? launch_forward_form<F, false, true, false, true, true>(nblk, st, p)
+                               : launch_forward_form<F, false, true, false, true, false>(nblk, st, p);
     if (k31) return fused ? launch_forward_form<31, true, false, false, true>(nblk, st, p) : launch_forward_form<31, false, false, false, true>(nblk, st, p);
     return fused ? launch_forward_form<F, true, false, false, true>(nblk, st, p) : launch_forward_form<F, false, false, false, true>(nblk, st, p);
 }

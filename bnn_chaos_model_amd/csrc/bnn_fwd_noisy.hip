@@ -4,6 +4,7 @@
 
 namespace bnn {
 hipError_t launch_fwd_noisy(unsigned nblk, hipStream_t st, const FwdParams& p) {
-    return launch_forward_form<F, false, true, false>(nblk, st, p);
+    return p.eps_in ? launch_forward_form<F, false, true, false, false, true>(nblk, st, p)
+                    : launch_forward_form<F, false, true, false, false, false>(nblk, st, p);
 }
 }  // namespace bnn
