@@ -547,11 +547,14 @@ int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host
     return (int)v.size();
 }
 
-static int pick_spc(const bnn_grid* g, int64_t csz) {
+static int pick_spc(const bnn_grid* g, int64_t csz, bool xcd_order) {
     if (g->systems_per_block > 0) return g->systems_per_block;
-    // The per-workgroup prologue (flat vector -> LDS operand images) is amortised over the block: prefer big blocks
-    // (512 systems: +1.7 % over 256 at configs[1]) as long as the grid still fills 256 CUs x 2 several times over.
+    // The per-workgroup prologue (flat vector -> weight registers, regress_nn fragments) is amortised over the block: prefer big
+    // blocks (512 systems: +1 % over 128 at configs[1]) as long as the grid still fills 256 CUs x 2 several times over.  When x is
+    // re-read from the XCD's 4 MiB L2 across draws (xcd_order) the block is also that L2's working set: 256 systems = 4.2 MB reach
+    // HBM 79 GB per configs[2] launch against 168 GB for 512 (8.4 MB), at the same kernel time (profiles/r03_spb_traffic.txt).
     for (int spc : {512, 256, 128}) {
+        if (xcd_order && spc > 256) continue;
         int64_t nsub = (csz + spc - 1) / spc;
         if (nsub * (int64_t)g->J >= 4096) return spc;
     }
@@ -569,9 +572,9 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     if (p.draw_id0 % g->nchunks) return fail(BNN_ERR_INVALID, "draw_id0 must be a multiple of nchunks");
     p.B = g->B; p.T = g->T; p.ntiles = g->T / 4; p.J = g->J; p.nch = g->nchunks;
     p.csz = (g->B + g->nchunks - 1) / g->nchunks;
-    p.spc = pick_spc(g, p.csz);
-    p.row_id0 = p.draw_id0 / g->nchunks;
     p.xcd_order = (g->nchunks > 1 || (double)g->B * g->T * F * sizeof(float) > 256.0 * 1024 * 1024) ? 1 : 0;
+    p.spc = pick_spc(g, p.csz, p.xcd_order != 0);
+    p.row_id0 = p.draw_id0 / g->nchunks;
     p.tab_f2 = pl->d_f2; p.tab_wr = noisy ? pl->d_f4n : pl->d_f4; p.rcp_tab = pl->d_rcp;
     p.zero_mask = pl->arch.zero_mask;
     p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);

@@ -102,7 +102,8 @@ def half_range_exceeded(x, zero_mask=V50_ZERO_MASK):
     constant-4 fill of unstable systems standardises the mass columns to 1.9e5 (figures/multiswag_5_planet.py:215).  Returns a bool
     tensor [B] on x's device (no host sync; `.any().item()` is the caller's).  The bfloat16 forms have fp32's range."""
     live = [c for c in range(41) if not (int(zero_mask) >> c) & 1]
-    return (x[..., live].abs() >= HALF_MAX).flatten(1).any(1)
+    hi, lo = torch.amax(x, dim=1), torch.amin(x, dim=1)            # [B,41] each: two passes over x, no x-sized temporary
+    return (torch.maximum(hi, -lo)[:, live] >= HALF_MAX).any(1)
 
 
 @_on_device_of(0)
