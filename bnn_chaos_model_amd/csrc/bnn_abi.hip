@@ -550,11 +550,12 @@ int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host
 static int pick_spc(const bnn_grid* g, int64_t csz, bool xcd_order) {
     if (g->systems_per_block > 0) return g->systems_per_block;
     // The per-workgroup prologue (flat vector -> weight registers, regress_nn fragments) is amortised over the block: prefer big
-    // blocks (512 systems: +1 % over 128 at configs[1]) as long as the grid still fills 256 CUs x 2 several times over.  When x is
-    // re-read from the XCD's 4 MiB L2 across draws (xcd_order) the block is also that L2's working set: 256 systems = 4.2 MB reach
-    // HBM 79 GB per configs[2] launch against 168 GB for 512 (8.4 MB), at the same kernel time (profiles/r03_spb_traffic.txt).
+    // blocks (512 systems: +1 % over 128 at configs[1]) as long as the grid still fills 256 CUs x 2 several times over.  Under the
+    // XCD work order the block is also the L2's working set across draws: 256-system blocks (4.2 MB) reach HBM 79 GB per configs[2]
+    // launch against 168 GB for 512 (8.4 MB) -- but HBM is at 3.5 % of its roof either way, the kernel time is the same within
+    // 0.3 %, and 256 costs 1.2 % more cycles (twice the prologues; profiles/r03_spb_traffic.txt): 512 stays.
+    (void)xcd_order;
     for (int spc : {512, 256, 128}) {
-        if (xcd_order && spc > 256) continue;
         int64_t nsub = (csz + spc - 1) / spc;
         if (nsub * (int64_t)g->J >= 4096) return spc;
     }
