@@ -1,6 +1,6 @@
 // bnn_forward.hip.h -- the forward kernel of the MultiSWAG path: feature_nn on
-// v_mfma_f32_4x4x1_16b_f32 with weights streamed from packed LDS images, time pool, sampled moments, regress_nn, soft_clamp,
-// optionally the in-prologue SWAG draw (FUSED), forward(noisy_val=True) (NOISY) or the fused statistics tail (STATS).
+// v_mfma_f32_4x4x1_16b_f32 with register-resident weights, time pool, sampled moments, regress_nn, soft_clamp, optionally the
+// in-prologue SWAG draw (FUSED), forward(noisy_val=True) (NOISY, XNOISE), the fused statistics tail (STATS), fix_megno (MEGNO).
 // Included by the bnn_fwd_*.hip translation units, each of which instantiates a few of the template's forms.
 //
 // lane = row, so there is no padding anywhere: 310 + 400 + 200 = 910 MFMAs of 8 cycles per 64 rows (113.75 pipe cycles per
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     const int64_t b1 = (b0 + p.spc < seg1) ? b0 + p.spc : seg1;
     if (b0 >= b1) return;
 
-    // ---- prologue: flat parameter vector of draw e -> LDS -> operand images
+    // ---- prologue: flat parameter vector of draw e -> LDS -> weight registers, bias image, regress_nn fragments
     bool bad_seed = false;
     if constexpr (FUSED) {
         int s = p.seed_idx[e];
