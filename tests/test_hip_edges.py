@@ -439,3 +439,46 @@ def test_mis_shaped_tensors_raise_before_any_launch(ops, swag_states):
         ops.multiswag(x[..., :40].contiguous(), wa, w2, pd, idx)
     mom = ops.moments(torch.zeros(3, 0, 2).cuda())                  # an empty shard (more ranks than systems)
     assert mom.shape == (0, 4)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomised_configurations_match_oracle(seed, ops, orc, swag_states):
+    """A seeded sweep over the shape space -- batch size, series length, chunking, number of samples, column mask, clamp floor,
+    fix_megno, block size, launch mode, two ensemble members with random picks -- each evaluated through ops.multiswag with explicit
+    noise and compared with the oracle's own MC driver (orc.multiswag: its torch.chunk partition, its draw, its forward)."""
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.choice([1, 2, 5, 16, 17, 63, 64, 65, 130, 257, int(rng.integers(1, 300))]))
+    T = int(rng.choice([8, 12, 36, 100, 104, 160]))
+    nch_req = int(rng.choice([1, 1, 2, 3, 7, 10]))
+    nch = len(torch.chunk(torch.arange(B), nch_req))
+    samples = int(rng.integers(1, 4))
+    megno = bool(rng.integers(0, 2))
+    if rng.integers(0, 2):
+        mask = ops.zero_mask_from_flags(fix_megno=megno, fix_megno2=not megno)          # the v50 column mask: 31-column kernels
+    else:
+        mask = int(sum(1 << int(c) for c in rng.choice(41, size=int(rng.integers(0, 12)), replace=False)))
+        if megno:
+            mask |= 1 << 7
+    lowest = float(rng.choice([0.5, 0.1]))
+    plan = ops.get_plan(mask, lowest, fix_megno=megno)
+    d = plan.d
+    S, K = 2, 30
+    st = [swag_states[0], swag_states[12]]
+    wa = np.zeros((S, d), np.float32); w2 = np.zeros((S, d), np.float32); pd = np.zeros((S, d, K), np.float32)
+    for s in range(S):   # fix_megno: the v50 state stretched to d = 7665 (values are arbitrary for this test, the layout is not)
+        reps = -(-d // 7583)
+        wa[s] = np.tile(st[s]["w_avg"], reps)[:d]
+        w2[s] = np.tile(st[s]["w2_avg"], reps)[:d]
+        pd[s] = np.tile(st[s]["pre_D"], (reps, 1))[:d]
+    J = samples * nch
+    idx = rng.integers(0, S, J).astype(np.int32)
+    z1 = rng.standard_normal((J, d), dtype=np.float32); z2 = rng.standard_normal((J, K), dtype=np.float32)
+    eps = rng.standard_normal((samples, B, 2, 20), dtype=np.float32)
+    x = synth(B, T, 50 + seed)
+    kw = dict(systems_per_block=int(rng.choice([0, 64, 128])), single_launch=bool(rng.integers(0, 2)))
+    out = ops.multiswag(dev(x), dev(wa), dev(w2), dev(pd), torch.as_tensor(idx), dev(z1), dev(z2), dev(eps), nchunks=nch, plan=plan,
+                        **kw).cpu().numpy()
+    arch = orc.make_arch(T=T, zero_mask=mask, lowest=lowest, fix_megno=megno)
+    want = orc.multiswag(x, wa, w2, pd, idx, z1, z2, eps, nchunks=nch, arch=arch, sched=sched(ops, orc, plan))
+    assert out.shape == want.shape == (samples, B, 2)
+    assert np.abs(out - want).max() <= 2e-6, (seed, B, T, nch, samples, hex(mask), megno, kw, np.abs(out - want).max())

@@ -39,3 +39,20 @@ def test_bench_gather_runs_on_rccl(workload, extra):
     assert c["gather_ms"] > 0.0 and c["kernel_ms_min"] == c["kernel_ms_max"] > 0.0
     assert c["gather_bytes_per_rank"] == (3000 // 3 * 6 * 4 if workload == "c5" else 512 * 4 * 8)
     assert r["value"] > 0 and r["roofline"]["traffic_measured_in_run"] is False
+
+
+def test_two_rank_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2` launching its own two ranks (both on cuda:0, gather staged through gloo: BNN_BENCH_REHEARSE=1): the N > 1
+    code path end to end -- self-launch, sharding by whole simulations, per-rank kernel times, gather timing, one JSON line."""
+    env = dict(os.environ, BNN_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c5", "--systems", "3000", "--samples", "4", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--rendezvous-timeout", "60"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stderr[-2000:])
+    r = json.loads(lines[0])
+    c = r["config"]
+    assert r["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["collective"] == "gloo" and c["degraded"] is True
+    assert c["gather_ms"] > 0 and 0 < c["kernel_ms_min"] <= c["kernel_ms_max"]
+    assert c["gather_bytes_per_rank"] == 1000 * 6 * 4 and "whole simulations" in c["sharding"]
+    assert r["value"] == pytest.approx(2 * 3000 * 4 * 2 / (r["ms_per_step"] * 2e-3), rel=1e-6)   # evals of BOTH ranks over the max-rank time
