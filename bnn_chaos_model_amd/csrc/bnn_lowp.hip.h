@@ -55,17 +55,32 @@ DEVINL float hi_as_f32(uint32_t pk) {
 template <bool H>
 constexpr uint32_t ONE_LO = H ? 0x00003C00u : 0x00003F80u;  // {0, 1.0}: the constant 1.0 of a bias slot in the low half
 
-// (a, b) -> NS packed parts; part p holds bf16 of what is left after parts < p (the subtractions are exact in fp32)
+// (a, b) -> NS packed parts; part p holds bf16 / half of what is left after parts < p (the subtractions are exact in fp32).
+// This translation unit is compiled with -fno-slp-vectorize (build.py), so packed fp32 instructions come from explicit two-element
+// vector arithmetic only -- and, for the half forms, the residual of a pair becomes TWO instructions: v_fma_mixlo_f16 /
+// v_fma_mixhi_f16 compute RN_half(fma(float(hi), -1, a)) straight from the packed hi part (the fma's result a - hi is exact, so
+// this is the same number as converting, subtracting and converting back: 3 instructions per pair instead of 5).  The compiler
+// only selects the mix forms for an fma whose multiplier it cannot see, hence the laundered -1.0 (`m1`).
 template <int NS, bool H>
-DEVINL void split_pair(float a, float b, uint32_t (&out)[NS]) {
+DEVINL void split_pair(float a, float b, float m1, uint32_t (&out)[NS]) {
+    if constexpr (H && NS == 2) {
+        out[0] = cvt_pk<H>(a, b);
+        const f16x2 hi = __builtin_bit_cast(f16x2, out[0]);
+        const f16x2 lo = {(_Float16)__builtin_fmaf((float)hi.x, m1, a), (_Float16)__builtin_fmaf((float)hi.y, m1, b)};
+        out[1] = __builtin_bit_cast(uint32_t, lo);
+    } else {
+        f32x2 v = {a, b};
 #pragma unroll
-    for (int p = 0; p < NS; ++p) {
-        out[p] = cvt_pk<H>(a, b);
-        if (p + 1 < NS) {
-            a = a - lo_as_f32<H>(out[p]);
-            b = b - hi_as_f32<H>(out[p]);
+        for (int p = 0; p < NS; ++p) {
+            out[p] = cvt_pk<H>(v.x, v.y);
+            if (p + 1 < NS) v = v - (f32x2){lo_as_f32<H>(out[p]), hi_as_f32<H>(out[p])};   // one v_pk_add_f32
         }
     }
+}
+DEVINL float laundered_minus_one() {
+    float m1 = -1.0f;
+    asm volatile("" : "+s"(m1));
+    return m1;
 }
 
 template <int NS>
@@ -113,12 +128,12 @@ DEVINL int lowp_widx(int layer, int mt, int s, int g, int m, int j) {
 }
 
 template <int NS, bool H>
-DEVINL Frag<NS> lowp_wfrag(const float* flat, int layer, int mt, int s, int g, int m) {
+DEVINL Frag<NS> lowp_wfrag(const float* flat, int layer, int mt, int s, int g, int m, float m1) {
     Frag<NS> f;
 #pragma unroll
     for (int jp = 0; jp < 4; ++jp) {
         uint32_t pk[NS];
-        split_pair<NS, H>(flat[lowp_widx(layer, mt, s, g, m, 2 * jp)], flat[lowp_widx(layer, mt, s, g, m, 2 * jp + 1)], pk);
+        split_pair<NS, H>(flat[lowp_widx(layer, mt, s, g, m, 2 * jp)], flat[lowp_widx(layer, mt, s, g, m, 2 * jp + 1)], m1, pk);
 #pragma unroll
         for (int p = 0; p < NS; ++p) f.part[p][jp] = pk[p];
     }
@@ -133,7 +148,7 @@ DEVINL uint32_t relu_pk16(uint32_t pk) {  // ReLU on two packed bf16 / half: one
 
 // ReLU + split of a layer's three accumulator tiles into the next layer's two B k-steps
 template <int NS, bool H>
-DEVINL void lowp_next_operand(const f32x4 (&acc)[3], Frag<NS>& b0, Frag<NS>& b1) {
+DEVINL void lowp_next_operand(const f32x4 (&acc)[3], float m1, Frag<NS>& b0, Frag<NS>& b1) {
     if constexpr (NS == 1) {  // round first, then ReLU on the packed pairs: bf16(relu(v)) == relu(bf16(v)), half the instructions
         b0.part[0][0] = relu_pk16(cvt_pk<H>(acc[0][0], acc[0][1]));
         b0.part[0][1] = relu_pk16(cvt_pk<H>(acc[0][2], acc[0][3]));
@@ -145,22 +160,22 @@ DEVINL void lowp_next_operand(const f32x4 (&acc)[3], Frag<NS>& b0, Frag<NS>& b1)
     }
     f32x4 t0 = relu4(acc[0]), t1 = relu4(acc[1]), t2 = relu4(acc[2]);
     uint32_t pk[NS];
-    split_pair<NS, H>(t0[0], t0[1], pk);
+    split_pair<NS, H>(t0[0], t0[1], m1, pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b0.part[p][0] = pk[p];
-    split_pair<NS, H>(t0[2], t0[3], pk);
+    split_pair<NS, H>(t0[2], t0[3], m1, pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b0.part[p][1] = pk[p];
-    split_pair<NS, H>(t1[0], t1[1], pk);
+    split_pair<NS, H>(t1[0], t1[1], m1, pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b0.part[p][2] = pk[p];
-    split_pair<NS, H>(t1[2], t1[3], pk);
+    split_pair<NS, H>(t1[2], t1[3], m1, pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b0.part[p][3] = pk[p];
-    split_pair<NS, H>(t2[0], t2[1], pk);
+    split_pair<NS, H>(t2[0], t2[1], m1, pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b1.part[p][0] = pk[p];
-    split_pair<NS, H>(t2[2], t2[3], pk);
+    split_pair<NS, H>(t2[2], t2[3], m1, pk);
 #pragma unroll
     for (int p = 0; p < NS; ++p) b1.part[p][1] = pk[p];
 }
@@ -208,18 +223,19 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
         if (tid == 0) flat[ZERO_IDX] = 0.0f;
     }
     __syncthreads();
+    const float m1 = laundered_minus_one();
     // feature_nn weights -> bf16 parts in registers (every wave builds its own copy)
     Frag<NS> A1[3], A2[3][2], A3[2][2];
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) A1[mt] = lowp_wfrag<NS, H>(flat, 0, mt, 0, g, c);
+    for (int mt = 0; mt < 3; ++mt) A1[mt] = lowp_wfrag<NS, H>(flat, 0, mt, 0, g, c, m1);
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) A2[mt][s] = lowp_wfrag<NS, H>(flat, 1, mt, s, g, c);
+        for (int s = 0; s < 2; ++s) A2[mt][s] = lowp_wfrag<NS, H>(flat, 1, mt, s, g, c, m1);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) A3[mt][s] = lowp_wfrag<NS, H>(flat, 2, mt, s, g, c);
+        for (int s = 0; s < 2; ++s) A3[mt][s] = lowp_wfrag<NS, H>(flat, 2, mt, s, g, c, m1);
     {   // regress_nn operands (exact fp32) replace the flat vector in place
         constexpr int PER = (NF2 + 3) / 4;
         int idx[PER];
@@ -331,16 +347,16 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
                     const float v[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
                     const float v6 = vb.z, v7 = vb.w;
                     uint32_t pk[NS];
-                    split_pair<NS, H>(v[0], v[1], pk);
+                    split_pair<NS, H>(v[0], v[1], m1, pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][0] = pk[q];
-                    split_pair<NS, H>(v[2], v[3], pk);
+                    split_pair<NS, H>(v[2], v[3], m1, pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][1] = pk[q];
-                    split_pair<NS, H>(v[4], v[5], pk);
+                    split_pair<NS, H>(v[4], v[5], m1, pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][2] = pk[q];
-                    split_pair<NS, H>(v6, v7, pk);
+                    split_pair<NS, H>(v6, v7, m1, pk);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) B1.part[q][3] = pk[q];
                 }
@@ -348,13 +364,13 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
                 f32x4 acc[3];
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) acc[mt] = mfma_split<NS, H>(A1[mt], B1, (f32x4){0, 0, 0, 0});
-                lowp_next_operand<NS, H>(acc, Bs0, Bs1);
+                lowp_next_operand<NS, H>(acc, m1, Bs0, Bs1);
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) {
                     acc[mt] = mfma_split<NS, H>(A2[mt][0], Bs0, (f32x4){0, 0, 0, 0});
                     acc[mt] = mfma_split<NS, H>(A2[mt][1], Bs1, acc[mt]);
                 }
-                lowp_next_operand<NS, H>(acc, Bs0, Bs1);
+                lowp_next_operand<NS, H>(acc, m1, Bs0, Bs1);
                 f32x4 y0 = mfma_split<NS, H>(A3[0][0], Bs0, (f32x4){0, 0, 0, 0});
                 y0 = mfma_split<NS, H>(A3[0][1], Bs1, y0);
                 f32x4 y1 = mfma_split<NS, H>(A3[1][0], Bs0, (f32x4){0, 0, 0, 0});
@@ -362,27 +378,27 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
                 // torch.mean / torch.std over time (:418-419).  y0[r] = neuron 4g + r, y1[r] = neuron 16 + 4g + r (a real neuron
                 // only for g = 0).  NS >= 2: Welford over this lane's timesteps, as in the fp32 kernel.  NS = 1: plain sums of y and
                 // y^2 (half the instructions; their fp32 cancellation error, ~1e-5 relative on the variance, is far below bf16's own).
-                if constexpr (NS == 1) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        mean0[i] += y0[i];
-                        m20[i] = fmaf(y0[i], y0[i], m20[i]);
-                        mean1[i] += y1[i];
-                        m21[i] = fmaf(y1[i], y1[i], m21[i]);
-                    }
+                auto lo2 = [](const f32x4& v) { return (f32x2){v.x, v.y}; };
+                auto hi2 = [](const f32x4& v) { return (f32x2){v.z, v.w}; };
+                auto put = [](f32x4& v, f32x2 a, f32x2 b) { v = (f32x4){a.x, a.y, b.x, b.y}; };
+                if constexpr (NS == 1) {   // two-element vector arithmetic: v_pk_add_f32 / v_pk_fma_f32 (no SLP vectoriser in this unit)
+                    auto acc = [&](f32x4& mean, f32x4& m2, const f32x4& y) {
+                        put(mean, lo2(mean) + lo2(y), hi2(mean) + hi2(y));
+                        put(m2, __builtin_elementwise_fma(lo2(y), lo2(y), lo2(m2)), __builtin_elementwise_fma(hi2(y), hi2(y), hi2(m2)));
+                    };
+                    acc(mean0, m20, y0);
+                    acc(mean1, m21, y1);
                 } else {
                     const float rcn = p.rcp_tab[it];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float dl = y0[i] - mean0[i];
-                        float mn = fmaf(dl, rcn, mean0[i]);
-                        m20[i] = fmaf(dl, y0[i] - mn, m20[i]);
-                        mean0[i] = mn;
-                        dl = y1[i] - mean1[i];
-                        mn = fmaf(dl, rcn, mean1[i]);
-                        m21[i] = fmaf(dl, y1[i] - mn, m21[i]);
-                        mean1[i] = mn;
-                    }
+                    const f32x2 rc2 = {rcn, rcn};
+                    auto welford = [&](f32x4& mean, f32x4& m2, const f32x4& y) {
+                        const f32x2 dl0 = lo2(y) - lo2(mean), dl1 = hi2(y) - hi2(mean);
+                        const f32x2 mn0 = __builtin_elementwise_fma(dl0, rc2, lo2(mean)), mn1 = __builtin_elementwise_fma(dl1, rc2, hi2(mean));
+                        put(m2, __builtin_elementwise_fma(dl0, lo2(y) - mn0, lo2(m2)), __builtin_elementwise_fma(dl1, hi2(y) - mn1, hi2(m2)));
+                        put(mean, mn0, mn1);
+                    };
+                    welford(mean0, m20, y0);
+                    welford(mean1, m21, y1);
                 }
                 // this tile's fragment reads were issued at its top: the buffer is free for the next tile.  The barrier keeps the
                 // writes (and the wait for the loads they need) HERE, a whole tile of work after the loads were issued: left alone,

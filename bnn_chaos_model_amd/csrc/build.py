@@ -16,6 +16,9 @@ HEADERS = ["bnn_layout.h", "bnn_tables.h", "bnn_internal.h", "bnn_common.hip.h",
            "bnn_lowp.hip.h", os.path.join("..", "..", "include", "bnn_chaos_hip.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
           "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+# per-unit flags: the reduced-precision unit writes its packed arithmetic out by hand and needs the SLP vectoriser off, or the
+# compiler rebuilds convert + v_pk_fma_f32 where v_fma_mixlo/hi_f16 is wanted (bnn_lowp.hip.h, split_pair)
+UNIT_FLAGS = {"bnn_fwd_lowp.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():
@@ -32,7 +35,7 @@ def _mtime(name):
 def source_hash(extra=()):
     """Content hash of everything the library is built from (file times do not survive a copy to another machine)."""
     import hashlib
-    h = hashlib.sha256(" ".join(CFLAGS + list(extra)).encode())
+    h = hashlib.sha256((" ".join(CFLAGS + list(extra)) + repr(sorted(UNIT_FLAGS.items()))).encode())
     for name in sorted(SRCS + HEADERS):
         h.update(name.encode())
         with open(os.path.join(HERE, name), "rb") as f:
@@ -61,7 +64,7 @@ def build(force=False, verbose=False, extra=(), out=None):
     os.makedirs(objdir, exist_ok=True)
     hdr_t = max(_mtime(h) for h in HEADERS)
     # objects are reusable only under the flags they were compiled with: the object directory carries a stamp of CFLAGS + extra
-    flags_stamp = " ".join(CFLAGS + list(extra))
+    flags_stamp = " ".join(CFLAGS + list(extra)) + repr(sorted(UNIT_FLAGS.items()))
     stamp_file = os.path.join(objdir, "FLAGS")
     try:
         with open(stamp_file) as f:
@@ -77,7 +80,7 @@ def build(force=False, verbose=False, extra=(), out=None):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         if not force and out is None and os.path.exists(obj) and os.path.getmtime(obj) > max(_mtime(src), hdr_t):
             return obj
-        cmd = [cc] + CFLAGS + list(extra) + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
+        cmd = [cc] + CFLAGS + UNIT_FLAGS.get(src, []) + list(extra) + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=HERE)

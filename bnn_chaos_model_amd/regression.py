@@ -114,7 +114,7 @@ class FeatureRegressor(object):
         -> [samples, B, 2].  rng="torch" consumes numpy's and torch's global generators exactly as that loop does
         (one randint + randn((1,d)) + randn((K,1)) + 2 randn_like([Bc,20]) per chunk per sample);
         rng="philox" draws the seed picks from numpy and everything else in-kernel.
-        precision: "f32" (the parity path) or an OPT-IN reduced-precision form of ops.forward ("f16x3": fp32-level error at ~1.65x
+        precision: "f32" (the parity path) or an OPT-IN reduced-precision form of ops.forward ("f16x3": fp32-level error at ~1.7x
         the throughput; "bf16", "f16", ...: approximate) -- DESIGN.md section 4.6.  The IEEE-half forms ("f16", "f16x3") require
         |X| < 65 504 in the live columns: rows beyond that (e.g. the script's constant-4 fill of unstable systems,
         figures/multiswag_5_planet.py:215) get finite but WRONG outputs; this method checks and warns (RuntimeWarning, with the
