@@ -6,11 +6,13 @@ One "step" = one pass of the hot path over one batch: every system of the batch 
 the timed region.  Default workload = BASELINE.json configs[2], the largest single-GPU configuration:
 1 000 000 systems x 100 MC samples (x = 16.4 GB, far beyond the 256 MiB Infinity Cache).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5|noisy|tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c4q|c5|noisy|tiny]
 
   c3 (default)  configs[2]: 1M systems x 100 samples per GPU, samples kept, moments gathered
   c4            configs[3], one GPU's share: 1.25M systems x 3000 draws (30 seeds x 100) through the native slab driver
                 (bnn_multiswag_moments_f64: 250 draws per launch, float64 moments), then the ONE all-gather of moments
+  c4q           the same share streamed to what the scripts consume (bnn_multiswag_bands_f32: fused statistics tail + quantile sketch),
+                then the all-gather of the per-system bands
   c5            configs[4], one GPU's share: 125 000 five-planet systems = 375 000 rows x 100 samples x 10 chunks; under --gpus N the
                 shards are WHOLE simulations (3 trios each), every rank reduces its samples to per-simulation bands and the bands
                 are gathered
@@ -53,6 +55,11 @@ WORKLOADS = {
     # reduced to float64 predictive moments slab by slab (distributed.MultiSwagSharded.local_moments -> bnn_multiswag_moments_f64)
     "c4": dict(systems=1_250_000, seeds=30, samples=100, slab=250, steps=3, warmup=1,
                name="configs[3] share: 1.25M systems x 30 seeds x 100 samples (3000 draws in slabs of 250) -> float64 moments, all-gather"),
+    # the same share reduced to what the evaluation scripts consume instead of moments: statistics epilogue fused in the forward tail,
+    # per-system quantile sketch (distributed.MultiSwagSharded.local_bands -> bnn_multiswag_bands_f32), bands + mean gathered
+    "c4q": dict(systems=1_250_000, seeds=30, samples=100, slab=250, bands=True, steps=3, warmup=1,
+                name="configs[3] share, streamed to bands: 1.25M systems x 3000 draws -> truncated-normal draw + prior + quantile sketch -> "
+                     "2.5/16/50/84/97.5 % bands + mean per system, all-gather"),
     "tiny": dict(systems=512, seeds=30, samples=2, name="smoke-sized grid"),
 }
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
@@ -322,7 +329,8 @@ def main():
     B, S, M = wl["systems"], wl["seeds"], wl["samples"]
     nch = wl.get("chunks", 1)
     trios = wl.get("trios", 1)
-    slab = wl.get("slab", 0)                      # > 0: the native slab driver reduces the draws to moments on the fly (c4)
+    slab = wl.get("slab", 0)                      # > 0: the native slab driver reduces the draws on the fly (c4: moments, c4q: bands)
+    stream_bands = bool(wl.get("bands"))
     if B % trios:
         sys.exit(f"--systems must be a multiple of {trios} for workload {args.workload} (whole simulations per rank)")
     J = wl.get("draws", S * M) if nch == 1 else M * nch
@@ -345,8 +353,8 @@ def main():
     out = None if slab else torch.empty((R, B, 2), dtype=torch.float32, device=dev)
     plan = ops.get_plan()
     W_noisy = ops.swag_draw(wa, w2, pd, seed_idx, philox_seed=99, plan=plan) if noisy else None
-    sketch = ops.QuantileSketch(B, group=trios, device=dev) if trios > 1 else None
-    stats = ops.stats_params(device=dev) if trios > 1 else None
+    sketch = ops.QuantileSketch(B, group=trios, device=dev) if (trios > 1 or stream_bands) else None
+    stats = ops.stats_params(device=dev) if (trios > 1 or stream_bands) else None
     BANDS_Q = (2.5, 16.0, 50.0, 84.0, 97.5)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -376,6 +384,13 @@ def main():
     def step(i, timed):
         if timed:
             ev0[i].record()          # on torch's current stream = the stream the ops launch on (ops.N.stream_ptr())
+        if slab and stream_bands:    # c4q: slabs of draws -> statistics epilogue in the forward tail -> quantile sketch, ONE native call
+            sketch.hist.zero_(); sketch.mom.zero_(); sketch.count = 0
+            ops.multiswag_bands(x, wa, w2, pd, seed_idx, sketch, st=stats, philox_seed=99, draw_id0=0, system_id0=lo, draws_per_launch=slab, plan=plan)
+            bands = torch.cat([sketch.percentiles(BANDS_Q), sketch.mean().float()[:, None]], 1)   # [B, 6]
+            if timed:
+                ev1[i].record()
+            return gather(bands, world * B, i, timed)
         if slab:                     # c4: slabs of draws -> float64 moments inside ONE native call
             mom = ops.multiswag_moments(x, wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, system_id0=lo, draws_per_launch=slab, plan=plan)
             if timed:
@@ -450,11 +465,12 @@ def main():
                 traffic = None
         kernel = ("bnn_forward_kernel<41,noisy> (ops.forward, noisy_val=True, in-kernel Philox)" if noisy else
                   "ops.swag_draw + ops.forward" if args.unfused else
+                  f"bnn_multiswag_bands_f32: {slab} draws per launch (draw + forward with fused statistics tail + sketch update), {J // slab} launches per step" if (slab and stream_bands) else
                   f"bnn_multiswag_moments_f64: {slab} draws per launch (draw + forward + moments kernels), {J // slab} launches per step" if slab else
                   ("multiswag, in-kernel draw per workgroup" if args.single_launch else "multiswag, draw-once workspace + forward"))
         if lowp:
             kernel = f"bnn_forward_lowp_kernel ({args.precision}): exact fp32 draw + feature_nn on the bf16 matrix pipe, {PRODUCTS_OF[args.precision]} product(s) per layer"
-        payload = ("bands [sims, 5 percentiles + mean] float32" if trios > 1 else "moments [systems, 4] float64")
+        payload = ("bands [sims, 5 percentiles + mean] float32" if (trios > 1 or stream_bands) else "moments [systems, 4] float64")
         res = {
             "metric": "system x MC-sample forward evals/sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,

@@ -30,14 +30,15 @@ def run_under_launcher(*bench_args):
     return json.loads(lines[-1])
 
 
-@pytest.mark.parametrize("workload,extra", (("tiny", ()), ("c5", ("--systems", "3000", "--samples", "4"))))
+@pytest.mark.parametrize("workload,extra", (("tiny", ()), ("c5", ("--systems", "3000", "--samples", "4")), ("c4q", ("--systems", "2048", "--samples", "2"))))
 def test_bench_gather_runs_on_rccl(workload, extra):
-    """moments gather (tiny) and the whole-simulation bands gather (c5 shape, 1000 simulations x 3 trios) through RCCL."""
+    """moments gather (tiny), the whole-simulation bands gather (c5 shape, 1000 simulations x 3 trios) and the streamed-bands gather
+    (c4q: slab driver with the fused statistics tail) through RCCL."""
     r = run_under_launcher("--workload", workload, "--steps", "2", "--warmup", "1", *extra)
     c = r["config"]
     assert c["collective"] == "nccl" and c["degraded"] is False and c["ranks_seen"] == 1 and r["n_gpus"] == 1
     assert c["gather_ms"] > 0.0 and c["kernel_ms_min"] == c["kernel_ms_max"] > 0.0
-    assert c["gather_bytes_per_rank"] == (3000 // 3 * 6 * 4 if workload == "c5" else 512 * 4 * 8)
+    assert c["gather_bytes_per_rank"] == {"c5": 3000 // 3 * 6 * 4, "c4q": 2048 * 6 * 4, "tiny": 512 * 4 * 8}[workload]
     assert r["value"] > 0 and r["roofline"]["traffic_measured_in_run"] is False
 
 
