@@ -30,6 +30,7 @@
 #ifndef BNN_ABLATE
 #define BNN_ABLATE 0
 #endif
+
 #ifndef BNN_BIAS_PREFETCH
 #define BNN_BIAS_PREFETCH 1
 #endif
