@@ -172,3 +172,32 @@ def test_configs4_share_f16x3_emulation_at_every_chunk_edge(c5_share):
                 assert (out[r, b] - o32[r, b]).abs().max().item() < 1e-4
                 n += 1
     assert n == 40 and worst <= 2e-5, worst
+
+
+def test_configs3_share_streamed_bands_equal_exact_order_statistics(c4_share):
+    """The streamed form at share size (what `bench.py --workload c4q` and MultiSwagSharded.local_bands run): the native slab driver
+    with the fused statistics tail + quantile sketch over all 1.25M systems x the 250-draw slab, against exact percentiles of the
+    post-epilogue times computed from the materialised samples for the first and the last 2000 systems -- within one bin width."""
+    o, f = c4_share["ops"], c4_share
+    q = (2.5, 16.0, 50.0, 84.0, 97.5)
+    sk = o.QuantileSketch(B4)
+    o.multiswag_bands(f["x"], f["wa"], f["w2"], f["pd"], f["idx"], sk, philox_seed=SEED, draw_id0=DRAW0_4, system_id0=SYS0_4, draws_per_launch=125)
+    got = sk.percentiles(q)
+    assert got.shape == (B4, 5) and torch.isfinite(got).all() and sk.count == NSLAB
+    for lo, hi in ((0, 2000), (B4 - 2000, B4)):
+        t = o.stats_draw(f["out"][:, lo:hi].contiguous(), philox_seed=SEED, row_id0=DRAW0_4, system_id0=SYS0_4 + lo)   # [250, 2000]
+        want = torch.quantile(t.double(), torch.tensor(q, dtype=torch.float64, device="cuda") / 100.0, dim=0).T
+        err = (got[lo:hi].double() - want).abs().cpu().numpy()
+        # a percentile is interpolated between two neighbouring order statistics, each of which the sketch places inside its own bin:
+        # the bound is the width of the coarser of those two bins (with only 250 draws the tail percentiles often straddle a segment
+        # boundary of the 1/128 | 1/32 | 1/2 wide bins)
+        srt = torch.sort(t.double(), dim=0).values.cpu().numpy()                      # [250, 2000]
+        res = np.vectorize(sk.resolution)
+        tol = np.empty_like(err)
+        for k, qq in enumerate(q):
+            r0 = int(np.floor(qq / 100.0 * (NSLAB - 1)))
+            r1 = min(r0 + 1, NSLAB - 1)
+            tol[:, k] = np.maximum(res(srt[r0]), res(srt[r1]))
+        assert (err <= tol * 1.0001).all(), (lo, err.max())
+        assert np.median(err) < 0.004
+        assert torch.allclose(sk.mean()[lo:hi], t.double().mean(0), rtol=1e-12)
