@@ -52,8 +52,21 @@ typedef struct {
     double lowest;      /* soft_clamp floor for std: 0.5, or 0.1 with lower_std (:363-365)            */
     int32_t fix_megno;  /* hparams['fix_megno'] (:360-362): the summary gains [mean_t, std_t] of the RAW MEGNO column (7),
                            regress_nn.0 and summary_noise_logvar are 2 wider (:488-491, :509-510, summarize_megno :480-484) */
+    int32_t depth_in;   /* hparams['in']:  `layers` of feature_nn = mlp(F, L, H, in)  (:301-321, :359)                        */
+    int32_t depth_out;  /* hparams['out']: `layers` of regress_nn = mlp(S, 2, H, out) (:360)                                  */
     int32_t reserved;
 } orc_arch;
+/* mlp(in_n, out_n, hidden, layers) (:301-321): layers == 0 is ONE Linear(in_n, out_n); otherwise Linear(in_n, hidden), ReLU,
+ * `layers` x [Linear(hidden, hidden), ReLU], Linear(hidden, out_n): layers + 2 Linear modules, ReLU after all but the last. */
+#define ORC_MAX_LIN 18
+static int mlp_nlin(int layers) { return layers == 0 ? 1 : layers + 2; }
+static int mlp_in(int l, int nlin, int in_n, int hidden) { (void)nlin; return l == 0 ? in_n : hidden; }
+static int mlp_out(int l, int nlin, int out_n, int hidden) { return l == nlin - 1 ? out_n : hidden; }
+static int mlp_params(int in_n, int out_n, int hidden, int layers) {
+    int n = 0, nlin = mlp_nlin(layers);
+    for (int l = 0; l < nlin; ++l) n += mlp_out(l, nlin, out_n, hidden) * mlp_in(l, nlin, in_n, hidden) + mlp_out(l, nlin, out_n, hidden);
+    return n;
+}
 #define MEGNO_COL 7 /* self.megno_location (:371) */
 
 /* Optional accumulation schedule.  The reference's summation order inside nn.Linear /
@@ -64,7 +77,9 @@ typedef struct {
  *   order[l][i]: i-th term accumulated into every output of Linear layer l (0..5): an input index,
  *                or -1 for the bias term.  If no -1 is listed the accumulator STARTS at the bias.
  *   pool_parts:  1, or 4 = Welford over the four strided partitions t = p + 4i, merged pairwise
- *                (p^1 then p^2) with the equal-count form of Chan's update.                        */
+ *                ((0,1), (2,3), then the halves) with Chan's update: its symmetric equal-count form where the two
+ *                counts agree (always, when T % 4 == 0), the general form otherwise (merge_consts below); any T >= 2.
+ *   Explicit orders name the six Linear layers of the depth (in, out) = (1, 1) network; other depths take the natural order. */
 typedef struct {
     const int32_t* order[6];
     int32_t order_len[6];
@@ -73,7 +88,8 @@ typedef struct {
 
 int FN(param_count)(const orc_arch* a) {
     int F = a->n_features, H = a->hidden, L = a->latent, S = 2 * L + (a->fix_megno ? 2 : 0);
-    return F + S + (H * F + H) + (H * H + H) + (L * H + L) + (H * S + H) + (H * H + H) + (2 * H + 2);
+    if (a->depth_in < 0 || a->depth_out < 0 || mlp_nlin(a->depth_in) > ORC_MAX_LIN || mlp_nlin(a->depth_out) > ORC_MAX_LIN) return -1;
+    return F + S + mlp_params(F, L, H, a->depth_in) + mlp_params(S, 2, H, a->depth_out);
 }
 
 /* ---- SWAG weight draw: SWAGModel.sample_weights (spock_reg_model.py:815-838) ------------------
@@ -135,11 +151,44 @@ static inline REAL soft_clamp(REAL x, double lo, double hi) {
     return s + (REAL)lo;
 }
 
+/* Merge of two Welford partitions a (count na) and b (count nb), Chan et al.  Equal counts use the symmetric form (both inputs
+ * enter alike, so a SIMD implementation whose lanes hold either side ends with the same bits); unequal counts the general one, with
+ * its two weights formed in float64 and rounded once: wb = nb/n, wab = na*nb/n.  An empty side leaves the other untouched. */
+typedef struct { int mode; REAL w1, w2; } pool_merge; /* mode 0: equal (w1 = na/2), 1: general (w1 = wb, w2 = wab), 2: keep a, 3: keep b */
+static pool_merge merge_consts(int na, int nb) {
+    pool_merge m;
+    m.w1 = 0; m.w2 = 0;
+    if (nb == 0) m.mode = 2;
+    else if (na == 0) m.mode = 3;
+    else if (na == nb) { m.mode = 0; m.w1 = (REAL)na * (REAL)0.5; }
+    else {
+        m.mode = 1;
+        m.w1 = (REAL)((double)nb / (double)(na + nb));
+        m.w2 = (REAL)((double)na * (double)nb / (double)(na + nb));
+    }
+    return m;
+}
+static inline void merge_apply(const pool_merge* m, REAL* ma, REAL* qa, REAL mb, REAL qb) {
+    if (m->mode == 2) return;
+    if (m->mode == 3) { *ma = mb; *qa = qb; return; }
+    REAL dl = mb - *ma;
+    if (m->mode == 0) {
+        REAL mm = (*ma + mb) * (REAL)0.5;
+        *qa = (*qa + qb) + (dl * dl) * m->w1;
+        *ma = mm;
+    } else {
+        REAL mm = FMA(dl, m->w1, *ma);
+        *qa = (*qa + qb) + (dl * dl) * m->w2;
+        *ma = mm;
+    }
+}
+
 /* ---- forward: VarModel.forward (:486-528) / the post-draw half of forward_swag_fast (:884-907) --
  *   x[B,T,F]; w = flat parameter vector; eps1, eps2 [B,L] = the two randn_like draws of
  *   compute_summary_stats (:426-427, ALWAYS consumed); eps_in [B,T,F] (:445) and eps_sum [B,2L] (:449)
  *   are consumed only by forward(noisy_val=True) -- pass NULL for forward_swag_fast / noisy_val=False.
  *   With fix_megno the summary is S = 2L + 2 wide (eps_sum [B,S], summary [B,S]).
+ *   feature_nn = mlp(F, L, H, depth_in), regress_nn = mlp(S, 2, H, depth_out) (:301-321, :359-360).
  *   Optional outputs: pre_clamp[B,2] (regress_nn output), summary[B,S] (before summary noise),
  *   latents[B,T,L] (feature_nn output). */
 int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, const REAL* eps_in, const REAL* eps1,
@@ -147,75 +196,90 @@ int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, cons
                 REAL* summary, REAL* latents) {
     if (!a || !x || !w || !eps1 || !eps2 || !out || B < 0) return -1;
     const int F = a->n_features, H = a->hidden, L = a->latent, T = a->T;
-    if (F <= 0 || F > 64 || H <= 0 || L <= 0 || T < 2) return -2;
+    if (F <= 0 || F > 128 || H <= 0 || L <= 0 || T < 2) return -2;
     const int P = sched ? sched->pool_parts : 1;
     if (P != 1 && P != 4) return -3;
-    if (P == 4 && T % 4) return -3;
     const int FM = a->fix_megno ? 1 : 0, S = 2 * L + 2 * FM;
     if (FM && F <= MEGNO_COL) return -2;
+    if (FN(param_count)(a) < 0) return -2;
+    const int n1 = mlp_nlin(a->depth_in), n2 = mlp_nlin(a->depth_out), NL = n1 + n2;
     const REAL* in_logvar = w;
     const REAL* sum_logvar = w + F;
-    const REAL* W1 = sum_logvar + S;
-    const REAL* b1 = W1 + H * F;
-    const REAL* W2 = b1 + H;
-    const REAL* b2 = W2 + H * H;
-    const REAL* W3 = b2 + H;
-    const REAL* b3 = W3 + L * H;
-    const REAL* W4 = b3 + L;
-    const REAL* b4 = W4 + H * S;
-    const REAL* W5 = b4 + H;
-    const REAL* b5 = W5 + H * H;
-    const REAL* W6 = b5 + H;
-    const REAL* b6 = W6 + 2 * H;
-    const int32_t* ord[6] = {0, 0, 0, 0, 0, 0};
-    int ordn[6] = {0, 0, 0, 0, 0, 0};
-    if (sched)
-        for (int l = 0; l < 6; ++l) { ord[l] = sched->order[l]; ordn[l] = sched->order_len[l]; }
+    /* Linear modules in state_dict order: feature_nn's, then regress_nn's (:734-761) */
+    const REAL* Wl[2 * ORC_MAX_LIN];
+    const REAL* bl[2 * ORC_MAX_LIN];
+    int nin[2 * ORC_MAX_LIN], nout[2 * ORC_MAX_LIN], wmax = F > S ? F : S;
+    {
+        const REAL* q = sum_logvar + S;
+        for (int l = 0; l < NL; ++l) {
+            const int feat = l < n1, ll = feat ? l : l - n1, nn = feat ? n1 : n2;
+            nin[l] = mlp_in(ll, nn, feat ? F : S, H);
+            nout[l] = mlp_out(ll, nn, feat ? L : 2, H);
+            Wl[l] = q; q += (size_t)nout[l] * nin[l];
+            bl[l] = q; q += nout[l];
+            if (nout[l] > wmax) wmax = nout[l];
+        }
+    }
+    const int32_t* ord[2 * ORC_MAX_LIN];
+    int ordn[2 * ORC_MAX_LIN];
+    for (int l = 0; l < NL; ++l) { ord[l] = 0; ordn[l] = 0; }
+    if (sched) {
+        int any = 0;
+        for (int l = 0; l < 6; ++l) any |= (sched->order[l] != 0);
+        if (any && !(a->depth_in == 1 && a->depth_out == 1)) return -3; /* explicit orders name the six layers of the (1, 1) network */
+        if (any)
+            for (int l = 0; l < 6; ++l) { ord[l] = sched->order[l]; ordn[l] = sched->order_len[l]; }
+    }
+    /* partition counts and merge constants (P = 4: partition p holds t = p, p + 4, ...) */
+    int cnt[4] = {T, 0, 0, 0};
+    if (P == 4)
+        for (int p = 0; p < 4; ++p) cnt[p] = p < T ? (T - p + 3) / 4 : 0;
+    const pool_merge m01 = merge_consts(cnt[0], cnt[1]), m23 = merge_consts(cnt[2], cnt[3]),
+                     m0123 = merge_consts(cnt[0] + cnt[1], cnt[2] + cnt[3]);
 
-    REAL in_scale[64];
+    REAL in_scale[128];
     if (eps_in)
         for (int f = 0; f < F; ++f) in_scale[f] = EXP(in_logvar[f] / (REAL)2); /* exp(logvar/2), :445 */
 
     int rc = 0;
 #pragma omp parallel
     {
-        REAL* xr = (REAL*)malloc(sizeof(REAL) * (size_t)(F + 3 * H + 2 * L + 2 + 2 * L * 4 + 8));
-        REAL* h1 = xr + F;
-        REAL* h2 = h1 + H;
-        REAL* y = h2 + H;        /* [L] */
-        REAL* s = y + L;         /* [S] summary */
-        REAL* mean = s + 2 * L + 2; /* [4][L] partition means */
-        REAL* m2 = mean + 4 * L; /* [4][L] partition M2    */
-        REAL gmean[4], gm2[4];   /* the same pool over the raw MEGNO column (fix_megno) */
+        REAL* buf0 = (REAL*)malloc(sizeof(REAL) * (size_t)(2 * wmax + S + 8 * L + 8));
+        REAL* buf1 = buf0 + wmax;
+        REAL* s = buf1 + wmax;    /* [S] summary */
+        REAL* mean = s + S;       /* [4][L] partition means */
+        REAL* m2 = mean + 4 * L;  /* [4][L] partition M2    */
+        REAL gmean[4], gm2[4];    /* the same pool over the raw MEGNO column (fix_megno) */
 #pragma omp for schedule(static)
         for (int64_t b = 0; b < B; ++b) {
             for (int i = 0; i < 4 * L; ++i) { mean[i] = 0; m2[i] = 0; }
             for (int i = 0; i < 4; ++i) { gmean[i] = 0; gm2[i] = 0; }
             for (int t = 0; t < T; ++t) {
                 const REAL* xi = x + ((size_t)b * T + t) * F;
+                const int p = (P == 4) ? (t & 3) : 0;
+                const int c = (P == 4) ? (t >> 2) + 1 : t + 1;
+                const REAL rc_n = (REAL)1 / (REAL)c;
                 if (FM) { /* summarize_megno (:480-484) sees x BEFORE zero_megno and before any noise (:488-491) */
-                    int p = (P == 4) ? (t & 3) : 0;
-                    int cnt = (P == 4) ? (t >> 2) + 1 : t + 1;
-                    REAL rc_n = (REAL)1 / (REAL)cnt;
                     REAL delta = xi[MEGNO_COL] - gmean[p];
                     REAL mnew = FMA(delta, rc_n, gmean[p]);
                     gm2[p] = FMA(delta, xi[MEGNO_COL] - mnew, gm2[p]);
                     gmean[p] = mnew;
                 }
+                REAL* cur = buf0;
+                REAL* nxt = buf1;
                 for (int f = 0; f < F; ++f) {
-                    /* zero_megno/mmr/nan/eplusminus: x - mask == 0 on masked columns (:452-478) */
-                    REAL v = ((a->zero_mask >> f) & 1) ? (REAL)0 : xi[f];
+                    /* zero_megno/mmr/nan/eplusminus: x - mask == 0 on masked columns (:452-478); bits past 63 do not exist */
+                    REAL v = (f < 64 && ((a->zero_mask >> f) & 1)) ? (REAL)0 : xi[f];
                     if (eps_in) v = v + eps_in[((size_t)b * T + t) * F + f] * in_scale[f]; /* add_input_noise :444-446 */
-                    xr[f] = v;
+                    cur[f] = v;
                 }
-                linear_row(W1, b1, H, F, xr, h1, 1, ord[0], ordn[0]); /* feature_nn (:359, :417) */
-                linear_row(W2, b2, H, H, h1, h2, 1, ord[1], ordn[1]);
-                linear_row(W3, b3, L, H, h2, y, 0, ord[2], ordn[2]);
+                for (int l = 0; l < n1; ++l) { /* feature_nn (:359, :417) */
+                    linear_row(Wl[l], bl[l], nout[l], nin[l], cur, nxt, l < n1 - 1, ord[l], ordn[l]);
+                    REAL* tmp = cur; cur = nxt; nxt = tmp;
+                }
+                const REAL* y = cur;
                 if (latents) memcpy(latents + ((size_t)b * T + t) * L, y, sizeof(REAL) * L);
                 /* mean / unbiased variance over t (torch.mean, torch.std: :418-419): Welford with fused updates */
-                int p = (P == 4) ? (t & 3) : 0;
-                int cnt = (P == 4) ? (t >> 2) + 1 : t + 1;
-                REAL rc_n = (REAL)1 / (REAL)cnt;
                 for (int n = 0; n < L; ++n) {
                     REAL delta = y[n] - mean[p * L + n];
                     REAL mnew = FMA(delta, rc_n, mean[p * L + n]);
@@ -223,33 +287,16 @@ int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, cons
                     mean[p * L + n] = mnew;
                 }
             }
-            if (P == 4) { /* merge partitions: (0,1),(2,3) then the two halves; equal counts */
-                REAL half_n = (REAL)(T / 4) * (REAL)0.5;
-                for (int stage = 0; stage < 2; ++stage) {
-                    int pa = 0, pb = stage == 0 ? 1 : 2;
-                    for (int rep = 0; rep < (stage == 0 ? 2 : 1); ++rep, pa += 2, pb += 2)
-                        for (int n = 0; n < L; ++n) {
-                            REAL dl = mean[pb * L + n] - mean[pa * L + n];
-                            REAL mm = (mean[pa * L + n] + mean[pb * L + n]) * (REAL)0.5;
-                            REAL q = (m2[pa * L + n] + m2[pb * L + n]) + (dl * dl) * half_n;
-                            mean[pa * L + n] = mm;
-                            m2[pa * L + n] = q;
-                        }
-                    half_n = half_n * (REAL)2;
+            if (P == 4) { /* merge partitions: (0,1), (2,3), then the two halves */
+                for (int n = 0; n < L; ++n) {
+                    merge_apply(&m01, &mean[n], &m2[n], mean[L + n], m2[L + n]);
+                    merge_apply(&m23, &mean[2 * L + n], &m2[2 * L + n], mean[3 * L + n], m2[3 * L + n]);
+                    merge_apply(&m0123, &mean[n], &m2[n], mean[2 * L + n], m2[2 * L + n]);
                 }
                 if (FM) {
-                    REAL hn = (REAL)(T / 4) * (REAL)0.5;
-                    for (int stage = 0; stage < 2; ++stage) {
-                        int pa = 0, pb = stage == 0 ? 1 : 2;
-                        for (int rep = 0; rep < (stage == 0 ? 2 : 1); ++rep, pa += 2, pb += 2) {
-                            REAL dl = gmean[pb] - gmean[pa];
-                            REAL mm = (gmean[pa] + gmean[pb]) * (REAL)0.5;
-                            REAL q = (gm2[pa] + gm2[pb]) + (dl * dl) * hn;
-                            gmean[pa] = mm;
-                            gm2[pa] = q;
-                        }
-                        hn = hn * (REAL)2;
-                    }
+                    merge_apply(&m01, &gmean[0], &gm2[0], gmean[1], gm2[1]);
+                    merge_apply(&m23, &gmean[2], &gm2[2], gmean[3], gm2[3]);
+                    merge_apply(&m0123, &gmean[0], &gm2[0], gmean[2], gm2[2]);
                 }
             }
             for (int n = 0; n < L; ++n) { /* compute_summary_stats, :418-431 */
@@ -270,15 +317,19 @@ int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, cons
             if (summary) memcpy(summary + (size_t)b * S, s, sizeof(REAL) * S);
             if (eps_sum) /* add_summary_noise :448-450 */
                 for (int n = 0; n < S; ++n) s[n] = s[n] + eps_sum[(size_t)b * S + n] * EXP(sum_logvar[n] / (REAL)2);
-            REAL r[2];
-            linear_row(W4, b4, H, S, s, h1, 1, ord[3], ordn[3]); /* regress_nn (:360, :438) */
-            linear_row(W5, b5, H, H, h1, h2, 1, ord[4], ordn[4]);
-            linear_row(W6, b6, 2, H, h2, r, 0, ord[5], ordn[5]);
-            if (pre_clamp) { pre_clamp[b * 2] = r[0]; pre_clamp[b * 2 + 1] = r[1]; }
-            out[b * 2 + 0] = soft_clamp(r[0], 4.0, 12.0);      /* :440 */
-            out[b * 2 + 1] = soft_clamp(r[1], a->lowest, 6.0); /* :441 */
+            REAL* cur = buf0;
+            REAL* nxt = buf1;
+            memcpy(cur, s, sizeof(REAL) * S);
+            for (int l = n1; l < NL; ++l) { /* regress_nn (:360, :438) */
+                linear_row(Wl[l], bl[l], nout[l], nin[l], cur, nxt, l < NL - 1, ord[l], ordn[l]);
+                REAL* tmp = cur; cur = nxt; nxt = tmp;
+            }
+            const REAL r0 = cur[0], r1 = cur[1];
+            if (pre_clamp) { pre_clamp[b * 2] = r0; pre_clamp[b * 2 + 1] = r1; }
+            out[b * 2 + 0] = soft_clamp(r0, 4.0, 12.0);      /* :440 */
+            out[b * 2 + 1] = soft_clamp(r1, a->lowest, 6.0); /* :441 */
         }
-        free(xr);
+        free(buf0);
     }
     return rc;
 }

@@ -15,7 +15,8 @@ _BUILD = os.path.join(_HERE, "_build")
 
 class OrcArch(C.Structure):
     _fields_ = [("n_features", C.c_int32), ("hidden", C.c_int32), ("latent", C.c_int32), ("T", C.c_int32),
-                ("zero_mask", C.c_uint64), ("lowest", C.c_double), ("fix_megno", C.c_int32), ("reserved", C.c_int32)]
+                ("zero_mask", C.c_uint64), ("lowest", C.c_double), ("fix_megno", C.c_int32), ("depth_in", C.c_int32),
+                ("depth_out", C.c_int32), ("reserved", C.c_int32)]
 
 
 class OrcSchedule(C.Structure):
@@ -87,10 +88,15 @@ def _arr(a, dt):
     return None if a is None else np.ascontiguousarray(a, dtype=dt)
 
 
-def make_arch(T=100, zero_mask=None, lowest=0.5, n_features=41, hidden=40, latent=20, fix_megno=False):
+def make_arch(T=100, zero_mask=None, lowest=0.5, n_features=41, hidden=40, latent=20, fix_megno=False, depth_in=1, depth_out=1):
+    """depth_in / depth_out = hparams['in'] / hparams['out'] (the `layers` argument of mlp(), spock_reg_model.py:301-321, 359-360)."""
     if zero_mask is None:
         zero_mask = zero_mask_from_flags(fix_megno=fix_megno)
-    return OrcArch(n_features, hidden, latent, T, zero_mask, lowest, int(bool(fix_megno)), 0)
+    return OrcArch(n_features, hidden, latent, T, zero_mask, lowest, int(bool(fix_megno)), int(depth_in), int(depth_out), 0)
+
+
+def param_count(arch):
+    return lib().orc32_param_count(C.byref(arch))
 
 
 def make_schedule(orders=None, pool_parts=1):

@@ -1,0 +1,135 @@
+"""Pins the CPU oracle's hparam-driven network (any hidden / latent / depth / n_features, any series length T >= 2, any SWAG
+rank) to vectors the UNMODIFIED reference produced with those shapes (tests/golden/make_golden_arch.py; reference
+spock_reg_model.py:301-321, 346-362, 416-435, 700-706).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import close_report, load_golden
+from oracle import oracle as orc
+
+CASES = ("h64l16", "h20l10", "h33l7", "deep22", "deep30", "lin00", "deriv82", "k40", "h48megno", "h128l32", "allcols")
+TLENS = (2, 3, 5, 6, 7, 99)
+
+
+def tp(z, pfx):
+    return [z[f"{pfx}_{i:03d}"] for i in range(int(z[pfx + "_n"]))]
+
+
+def hparams_of(z):
+    hp = json.loads(str(z["hparams_json"]))
+    for k, v in list(hp.items()):
+        if isinstance(v, str) and v in ("True", "False"):
+            hp[k] = v == "True"
+    return hp
+
+
+def arch_of(z, T=100):
+    """orc_arch from a fixture's hparams: the same reading of the flags as VarModel.__init__ (:346-365, 394-396)."""
+    hp = hparams_of(z)
+    mask = orc.zero_mask_from_flags(hp.get("fix_megno", False), hp.get("fix_megno2", False), hp["include_mmr"], hp["include_nan"],
+                                    hp.get("include_eplusminus", True))
+    return orc.make_arch(T=T, zero_mask=mask, lowest=0.1 if hp.get("lower_std", False) else 0.5, n_features=int(z["n_features"]),
+                         hidden=hp["hidden"], latent=hp["latent"], fix_megno=hp.get("fix_megno", False), depth_in=hp["in"],
+                         depth_out=hp["out"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_layout_and_param_count(name):
+    z = load_golden(f"case_arch_{name}.npz")
+    arch = arch_of(z)
+    assert orc.param_count(arch) == int(np.sum(z["state_sizes"])) == z["w_avg"].size
+    # state_dict order (:734-761): the two noise vectors, then feature_nn's Linear modules, then regress_nn's
+    keys = [str(k) for k in z["state_keys"]]
+    assert keys[:2] == ["input_noise_logvar", "summary_noise_logvar"]
+    assert all(k.startswith("feature_nn") for k in keys[2:2 + 2 * (1 if arch.depth_in == 0 else arch.depth_in + 2)])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_draw_and_forward_match_the_reference(name):
+    z = load_golden(f"case_arch_{name}.npz")
+    arch = arch_of(z)
+    L, S = arch.latent, 2 * arch.latent + 2 * arch.fix_megno
+    t = tp(z, "swagfast_tape")
+    assert [a.shape for a in t] == [(1, z["w_avg"].size), (z["pre_D"].shape[1], 1), (z["x"].shape[0], L), (z["x"].shape[0], L)]
+    w = orc.swag_draw(z["w_avg"], z["w2_avg"], z["pre_D"], t[0], t[1], scale=0.5)
+    assert np.abs(w.astype(np.float64) - z["swagfast_w"]).max() <= 2e-6
+    # natural accumulation order and the 4-partition pool (what the GPU engine uses): both within 1e-5 of the reference, 0 exceedances
+    for sched in (None, orc.make_schedule(None, pool_parts=4)):
+        out = orc.forward(z["x"], z["swagfast_w"], t[2], t[3], arch=arch, sched=sched)
+        nbad, mx = close_report(out, z["swagfast_out"])
+        assert nbad == 0, (name, nbad, mx)
+    for noisy in (0, 1):
+        t = tp(z, f"forward_noisy{noisy}_tape")
+        e1, e2 = (t[1], t[2]) if noisy else (t[0], t[1])
+        kw = dict(eps_in=t[0], eps_sum=t[3]) if noisy else {}
+        if noisy:
+            assert t[0].shape == z["x"].shape and t[3].shape == (z["x"].shape[0], S)
+        out, ex = orc.forward(z["x"], z["swagfast_w"], e1, e2, arch=arch, sched=orc.make_schedule(None, pool_parts=4), extras=True, **kw)
+        nbad, mx = close_report(out, z[f"forward_noisy{noisy}_out"])
+        assert nbad == 0, (name, noisy, nbad, mx)
+        ref = z[f"forward_noisy{noisy}_summary"]
+        assert ex["summary"].shape == ref.shape == (z["x"].shape[0], S)
+        nbad, mx = close_report(ex["summary"], ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+        assert nbad == 0, (name, noisy, nbad, mx)
+    # fp64 restatement stays within fp32 rounding of the fp32 reference run
+    t = tp(z, "swagfast_tape")
+    o64 = orc.forward(z["x"], z["swagfast_w"], t[2], t[3], arch=arch, dtype=np.float64)
+    assert np.abs(o64 - z["swagfast_out"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("T", TLENS)
+def test_series_lengths_on_the_pretrained_member(T, swag_states):
+    """x[:, :T] through the real v50_0: single-pass pool and the four strided partitions with unequal counts."""
+    z = load_golden("case_arch_tlen.npz")
+    st = swag_states[0]
+    x = z["x"][:, :T]
+    t = tp(z, f"T{T}_tape")
+    w = orc.swag_draw(st["w_avg"], st["w2_avg"], st["pre_D"], t[0], t[1], scale=0.5)
+    assert np.abs(w.astype(np.float64) - z[f"T{T}_w"]).max() <= 2e-6
+    arch = orc.make_arch(T=T)
+    # T = 2 is a cancellation regime (the variance is (y0 - y1)^2 / 2 of two nearly equal latents): two fp32 evaluations that
+    # differ only in summation order sit up to 1.2e-5 apart there, while each stays within 1e-5 of the float64 truth -- so for
+    # T = 2 the bar is "1e-5 of the truth on the same normals" for both, and 2e-5 between them; from T = 3 on the plain 1e-5 holds.
+    o64 = orc.forward(x, z[f"T{T}_w"], t[2], t[3], arch=arch, dtype=np.float64)
+    assert close_report(z[f"T{T}_out"], o64)[0] == 0
+    for sched in (None, orc.make_schedule(None, pool_parts=4)):
+        out = orc.forward(x, z[f"T{T}_w"], t[2], t[3], arch=arch, sched=sched)
+        assert close_report(out, o64)[0] == 0
+        nbad, mx = close_report(out, z[f"T{T}_out"], rtol=2e-5 if T == 2 else 1e-5)
+        assert nbad == 0, (T, nbad, mx)
+    t = tp(z, f"T{T}_noisy_tape")
+    out = orc.forward(x, z[f"T{T}_w"], t[1], t[2], eps_in=t[0], eps_sum=t[3], arch=arch, sched=orc.make_schedule(None, pool_parts=4))
+    nbad, mx = close_report(out, z[f"T{T}_noisy_out"], rtol=2e-5 if T == 2 else 1e-5)
+    assert nbad == 0, (T, nbad, mx)
+
+
+def test_partition_pool_equals_the_old_form_when_counts_agree(inputs, swag_states):
+    """T % 4 == 0: the generalised merge is the equal-count one the fast kernels are pinned to (bit for bit vs the single-pass
+    result is NOT expected; the two 4-partition code paths must agree with each other exactly)."""
+    x = inputs["slow"][:8, :96]
+    rng = np.random.default_rng(5)
+    e1, e2 = rng.standard_normal((8, 20), dtype=np.float32), rng.standard_normal((8, 20), dtype=np.float32)
+    w = swag_states[0]["w_avg"]
+    a = orc.forward(x, w, e1, e2, arch=orc.make_arch(T=96), sched=orc.make_schedule(None, pool_parts=4), extras=True)[1]["summary"]
+    # by hand: four Welford partitions of the latents, symmetric merges
+    lat = orc.forward(x, w, e1, e2, arch=orc.make_arch(T=96), extras=True)[1]["latents"].astype(np.float32)
+    f = np.float32
+    mean = np.zeros((4, 8, 20), f); m2 = np.zeros((4, 8, 20), f)
+    for t in range(96):
+        p, c = t & 3, f(1) / f((t >> 2) + 1)
+        d = lat[:, t] - mean[p]
+        mn = (d.astype(np.float64) * c + mean[p]).astype(f)           # fma: exact product, one rounding
+        m2[p] = (d.astype(np.float64) * (lat[:, t] - mn).astype(np.float64) + m2[p]).astype(f)
+        mean[p] = mn
+    def mrg(ma, qa, mb, qb, half):
+        dl = mb - ma
+        return ((ma + mb) * f(0.5)).astype(f), ((qa + qb) + (dl * dl) * f(half)).astype(f)
+    ma, qa = mrg(mean[0], m2[0], mean[1], m2[1], 12.0)
+    mb, qb = mrg(mean[2], m2[2], mean[3], m2[3], 12.0)
+    mm, qq = mrg(ma, qa, mb, qb, 24.0)
+    sd = np.sqrt((qq / f(95)).astype(f)).astype(f)
+    var = (sd * sd).astype(f)
+    mu_s = (e1 * np.sqrt((var / f(96)).astype(f)).astype(f) + mm).astype(f)
+    assert np.array_equal(a[:, :20], mu_s)
