@@ -6,7 +6,7 @@ One "step" = one pass of the hot path over one batch: every system of the batch 
 the timed region.  Default workload = BASELINE.json configs[2], the largest single-GPU configuration:
 1 000 000 systems x 100 MC samples (x = 16.4 GB, far beyond the 256 MiB Infinity Cache).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c4q|c5|noisy|tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c4q|c5|noisy|tiny] [--engine generic] [--net H,L,IN,OUT[,F]]
 
   c3 (default)  configs[2]: 1M systems x 100 samples per GPU, samples kept, moments gathered
   c4            configs[3], one GPU's share: 1.25M systems x 3000 draws (30 seeds x 100) through the native slab driver
@@ -16,6 +16,10 @@ the timed region.  Default workload = BASELINE.json configs[2], the largest sing
   c5            configs[4], one GPU's share: 125 000 five-planet systems = 375 000 rows x 100 samples x 10 chunks; under --gpus N the
                 shards are WHOLE simulations (3 trios each), every rank reduces its samples to per-simulation bands and the bands
                 are gathered
+
+--engine generic runs the same workload through the generic forward engine (weights streamed from LDS: what every network other than
+the pretrained ensemble's, and every series length T % 4 != 0, runs on); --net 64,16,1,1 benches another hparams-built network
+(hidden, latent, depth in, depth out[, features 41|82]) on a seeded synthetic ensemble.  Neither is a BASELINE configuration.
 
 --gpus N > 1 from a plain invocation launches N rank processes itself (a torch.distributed.run child, started BEFORE this
 process touches the GPU); under torch.distributed.run (WORLD_SIZE set) it is a rank.  One rank per GPU over RCCL: systems
@@ -71,19 +75,37 @@ DTYPE_OF = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate (feature_nn); f
 PRODUCTS_OF = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16": 1, "f16x3": 3}
 
 
-def synthetic_x(B, device, seed):
+def net_flop_per_eval(F, H, L, din, dout, T=100, live_cols=None):
+    """2 x MACs of one evaluation of mlp(F, L, H, din) per timestep + mlp(2L, 2, H, dout) once (spock_reg_model.py:301-321, 359-360)."""
+    def mlp_macs(i, o, h, layers):
+        return i * o if layers == 0 else i * h + layers * h * h + h * o
+    f = mlp_macs(F, L, H, din) - ((F - live_cols) * (L if din == 0 else H) if live_cols else 0)
+    return 2 * (T * f + mlp_macs(2 * L, 2, H, dout))
+
+
+def synthetic_net_ensemble(S, d, K, device):
+    """A seeded synthetic SWAG ensemble for a network no pretrained checkpoint has (throughput does not depend on the values)."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(2025)
+    wa = 0.15 * torch.randn(S, d, generator=g, device=device)
+    w2 = wa ** 2 + (0.02 * torch.rand(S, d, generator=g, device=device)) ** 2
+    pd = wa[:, :, None] + 0.05 * torch.randn(S, d, K, generator=g, device=device)
+    return wa, w2, pd
+
+
+def synthetic_x(B, device, seed, F=41):
     """SURVEY.md section 8(d) 'slow' inputs: per-system base + 0.1 noise, column 0 = standardised time.  Built in slabs of
     systems so that the temporaries stay small next to the 16.4 GB result at B = 1e6."""
     import torch
     g = torch.Generator(device=device).manual_seed(seed)
-    x = torch.empty((B, 100, 41), dtype=torch.float32, device=device)
+    x = torch.empty((B, 100, F), dtype=torch.float32, device=device)
     t0 = torch.linspace(-1.71, 1.74, 100, device=device)[None]
     slab = 65536
     for b0 in range(0, B, slab):
         n = min(slab, B - b0)
         xs = x[b0:b0 + n]
         xs.normal_(generator=g).mul_(0.1)
-        xs.add_(torch.randn(n, 1, 41, generator=g, device=device))
+        xs.add_(torch.randn(n, 1, F, generator=g, device=device))
         xs[:, :, 0] = t0
     return x
 
@@ -136,7 +158,7 @@ def host_threads():
     return n
 
 
-def cpu_baseline(x_cpu, wa, w2, pd, budget_s=15.0):
+def cpu_baseline(x_cpu, wa, w2, pd, budget_s=15.0, net=None):
     """The oracle (oracle/bnn_oracle.c: fp32 C restatement, OpenMP over systems) on a BOUNDED sample of the same workload:
     the first systems of the same synthetic batch, the same ensemble, as many draws as fit in about `budget_s` seconds."""
     import numpy as np
@@ -144,14 +166,16 @@ def cpu_baseline(x_cpu, wa, w2, pd, budget_s=15.0):
     cores = host_threads()
     os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle library is first loaded
     rng = np.random.default_rng(0)
+    arch = orc.make_arch(T=x_cpu.shape[1], **net) if net else None
+    latent = net["latent"] if net else 20
 
     def run(Bs, Js):
         seed_idx = (np.arange(Js) % wa.shape[0]).astype(np.int32)
         z1 = rng.standard_normal((Js, wa.shape[1]), dtype=np.float32)
         z2 = rng.standard_normal((Js, pd.shape[2]), dtype=np.float32)
-        eps = rng.standard_normal((Js, Bs, 2, 20), dtype=np.float32)
+        eps = rng.standard_normal((Js, Bs, 2, latent), dtype=np.float32)
         t0 = time.perf_counter()
-        orc.multiswag(x_cpu[:Bs], wa, w2, pd, seed_idx, z1, z2, eps)
+        orc.multiswag(x_cpu[:Bs], wa, w2, pd, seed_idx, z1, z2, eps, arch=arch)
         return time.perf_counter() - t0
 
     Bmax = x_cpu.shape[0]
@@ -211,6 +235,15 @@ def torch_cpu_baseline(x_cpu, wa, w2, pd, budget_s=8.0):
             "sample": f"first {B} systems of the batch x {Js} draws in {t:.1f} s, torch {torch.__version__}, {cores} threads"}
 
 
+def library_id():
+    """Which native library produced the numbers: the default in-tree build reports {"variant": false}; an A/B or ablation build
+    (BNN_CHAOS_SO, extra compile-time switches) is named so that its line cannot pass for a headline number."""
+    from bnn_chaos_model_amd import _native as N
+    flags = N.lib().bnn_build_flags().decode()
+    override = os.environ.get("BNN_CHAOS_SO")
+    return {"variant": bool(flags or override), "build_flags": flags, "path": os.path.relpath(N.SO_PATH, ROOT) if override else "default"}
+
+
 def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
@@ -240,6 +273,8 @@ def parse(argv=None):
     ap.add_argument("--single-launch", action="store_true", help="in-kernel draw in every workgroup prologue (no workspace)")
     ap.add_argument("--spb", type=int, default=0, help="systems per workgroup (0 = auto)")
     ap.add_argument("--precision", default="f32", choices=sorted(DTYPE_OF), help="opt-in reduced-precision forward (workload c5 / c3 / c2)")
+    ap.add_argument("--engine", default="auto", choices=("auto", "generic"), help="generic: force the generic forward engine (LDS-streamed weights)")
+    ap.add_argument("--net", default="", help="hidden,latent,in,out[,features]: another hparams-built network on a synthetic ensemble (generic engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-systems", type=int, default=8192, help="systems of the batch the CPU baselines are timed on")
     ap.add_argument("--allow-gloo", action="store_true", help="accept a gloo moments gather when RCCL cannot start (the line says degraded)")
@@ -343,15 +378,22 @@ def main():
     # Weak scaling: every rank holds B systems (B / trios whole simulations); this rank's global systems are [lo, hi).
     lo, hi = shard_bounds(world * B, world, trios)[rank]
     assert hi - lo == B
-    x = synthetic_x(B, dev, seed=123 + rank)          # this rank's shard
-    wa, w2, pd = synthetic_ensemble(S, dev)           # replicated ensemble (29 MB)
+    net = None
+    if args.net:
+        v = [int(t) for t in args.net.split(",")]
+        net = dict(hidden=v[0], latent=v[1], depth_in=v[2], depth_out=v[3], n_features=v[4] if len(v) > 4 else 41)
+        if lowp or slab or trios > 1 or args.single_launch:
+            sys.exit("--net applies to the dense fp32 workloads (c3, c2, noisy, tiny)")
+    NF = net["n_features"] if net else 41
+    plan = ops.get_plan(**net) if net else ops.get_plan()
+    x = synthetic_x(B, dev, seed=123 + rank, F=NF)    # this rank's shard
+    wa, w2, pd = synthetic_net_ensemble(S, plan.d, 30, dev) if net else synthetic_ensemble(S, dev)   # replicated ensemble (29 MB)
     if nch == 1:
         seed_idx = (torch.arange(J, dtype=torch.int32) % S).to(dev)  # dense grid: every seed x every sample
     else:                                                            # one random member per chunk per sample (regression.py:78)
         import numpy as np
         seed_idx = torch.as_tensor(np.random.default_rng(7).integers(0, S, J).astype(np.int32)).to(dev)
     out = None if slab else torch.empty((R, B, 2), dtype=torch.float32, device=dev)
-    plan = ops.get_plan()
     W_noisy = ops.swag_draw(wa, w2, pd, seed_idx, philox_seed=99, plan=plan) if noisy else None
     sketch = ops.QuantileSketch(B, group=trios, device=dev) if (trios > 1 or stream_bands) else None
     stats = ops.stats_params(device=dev) if (trios > 1 or stream_bands) else None
@@ -397,14 +439,14 @@ def main():
                 ev1[i].record()
             return gather(mom, world * B, i, timed)
         if noisy:
-            o = ops.forward(x, W_noisy, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan, noisy=True, systems_per_block=args.spb)
+            o = ops.forward(x, W_noisy, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan, noisy=True, systems_per_block=args.spb, engine=args.engine)
         elif args.unfused:
             W = ops.swag_draw(wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, plan=plan)
-            o = ops.forward(x, W, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan, systems_per_block=args.spb)
+            o = ops.forward(x, W, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan, systems_per_block=args.spb, engine=args.engine)
         else:
             o = ops.multiswag(x, wa, w2, pd, seed_idx, nchunks=nch, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan,
-                              out=None if lowp else out, systems_per_block=args.spb, single_launch=args.single_launch,
-                              precision=args.precision)
+                              out=None if lowp else out, systems_per_block=args.spb, single_launch=args.single_launch or None,
+                              precision=args.precision, engine=args.engine)
         if timed:
             ev1[i].record()
         if trios > 1:   # c5: what the 5-planet script does with the samples (multiswag_5_planet.py:388-428, 484-489), per simulation
@@ -448,9 +490,18 @@ def main():
     if rank == 0:
         evals_per_launch = B * R
         kin = 41 if noisy else 31
-        ach_tflops = evals_per_launch * ALG_FLOP_PER_EVAL / (kern_ms * 1e-3) / 1e12
-        exe_tflops = evals_per_launch * EXEC_FLOP_PER_EVAL[kin] / (kern_ms * 1e-3) / 1e12
-        ach_gbs = evals_per_launch * ALG_BYTES_PER_EVAL / (kern_ms * 1e-3) / 1e9
+        generic = bool(net) or args.engine == "generic"
+        alg_flop, exe_flop, alg_bytes = ALG_FLOP_PER_EVAL, EXEC_FLOP_PER_EVAL[kin], ALG_BYTES_PER_EVAL
+        if net:   # another network: the same two counts from its shapes (the v50 mask leaves 31 of the first 41 columns live)
+            a5 = (NF, net["hidden"], net["latent"], net["depth_in"], net["depth_out"])
+            alg_flop = net_flop_per_eval(*a5)
+            exe_flop = net_flop_per_eval(*a5, live_cols=NF if noisy else NF - 10)
+            alg_bytes = 100 * NF * 4 + 8
+        elif generic and not noisy:
+            exe_flop = net_flop_per_eval(41, 40, 20, 1, 1, live_cols=33)   # the generic engine skips whole masked quads only: 33 columns multiplied
+        ach_tflops = evals_per_launch * alg_flop / (kern_ms * 1e-3) / 1e12
+        exe_tflops = evals_per_launch * exe_flop / (kern_ms * 1e-3) / 1e12
+        ach_gbs = evals_per_launch * alg_bytes / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch: NOT measured in this run.  The PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, gfx950
         # correction of MI355X_MICROARCH.md) run the same command under the profiler (scripts/profile_r03.sh) and leave the
         # per-launch figure in profiles/pmc_traffic.json; it is quoted here with its source so that the line is self-describing.
@@ -468,6 +519,10 @@ def main():
                   f"bnn_multiswag_bands_f32: {slab} draws per launch (draw + forward with fused statistics tail + sketch update), {J // slab} launches per step" if (slab and stream_bands) else
                   f"bnn_multiswag_moments_f64: {slab} draws per launch (draw + forward + moments kernels), {J // slab} launches per step" if slab else
                   ("multiswag, in-kernel draw per workgroup" if args.single_launch else "multiswag, draw-once workspace + forward"))
+        if generic:
+            kernel = ("bnn_forward_generic_kernel (weight registers streamed from an LDS image; draw-once workspace)" +
+                      (f", network hidden={net['hidden']} latent={net['latent']} in={net['depth_in']} out={net['depth_out']} features={NF}" if net else
+                       ", the pretrained network forced onto the generic engine"))
         if lowp:
             kernel = f"bnn_forward_lowp_kernel ({args.precision}): exact fp32 draw + feature_nn on the bf16 matrix pipe, {PRODUCTS_OF[args.precision]} product(s) per layer"
         payload = ("bands [sims, 5 percentiles + mean] float32" if (trios > 1 or stream_bands) else "moments [systems, 4] float64")
@@ -476,7 +531,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_OF[args.precision], "data": "synthetic",
             "config": {"workload": wl["name"], "systems_per_gpu": B, "seeds": S, "mc_samples": M, "draws": J, "chunks": nch, "timesteps": 100,
-                       "features": 41, "noise": "in-kernel Philox4x32-10", "kernel": kernel,
+                       "features": NF, "kernel": kernel,
+                       "noise": ("in-kernel Philox: Philox4x32-7 for the input-noise stream (4 100 of the 4 180 normals of a noisy evaluation), "
+                                 "Philox4x32-10 for every other stream" if noisy else "in-kernel Philox4x32-10"),
+                       "library": library_id(),
                        "sharding": (f"whole simulations ({trios} trios each) over {world} rank(s), all-gather of {payload}" if trios > 1 else
                                     f"systems over {world} rank(s), all-gather of {payload}"),
                        "collective": (dist.get_backend() if use_dist else "none"), "degraded": degraded, "ranks_seen": ranks_seen,
@@ -488,7 +546,7 @@ def main():
                          "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_measured_in_run": False,
                          "traffic_source": traffic_src,
                          "achieved_executed": exe_tflops, "frac_executed": exe_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "kernel_ms": kern_ms, "flop_per_eval": ALG_FLOP_PER_EVAL, "flop_per_eval_executed": EXEC_FLOP_PER_EVAL[kin],
+                         "kernel_ms": kern_ms, "flop_per_eval": alg_flop, "flop_per_eval_executed": exe_flop,
                          "note": "frac counts the algorithm's 814 560 flop/eval (SURVEY 8d); frac_executed counts the MACs the kernel issues "
                                  "(the v50 mask drops 10 of 41 input columns); kernel_ms = HIP events around the compute launches of a step "
                                  "(rank 0); traffic = HBM bytes per launch from separate rocprofv3 PMC passes of this command, null when "
@@ -506,13 +564,14 @@ def main():
             ns = min(B, args.cpu_sample_systems)
             xs = x[:ns].cpu().numpy()
             try:
-                res["cpu_baseline"] = cpu_baseline(xs, wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
+                res["cpu_baseline"] = cpu_baseline(xs, wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy(), net=net)
             except Exception as e:  # the oracle is a checker, never a dependency of the measured path
                 res["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-            try:
-                res["cpu_baseline_torch"] = torch_cpu_baseline(xs, wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
-            except Exception as e:
-                res["cpu_baseline_torch"] = {"value": None, "sample": f"failed: {e}"}
+            if not net:   # (the eager-torch port below is written for the pretrained network's shapes)
+                try:
+                    res["cpu_baseline_torch"] = torch_cpu_baseline(xs, wa.cpu().numpy(), w2.cpu().numpy(), pd.cpu().numpy())
+                except Exception as e:
+                    res["cpu_baseline_torch"] = {"value": None, "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -13,17 +13,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("BNN_CHAOS_SO") or os.path.join(_HERE, "csrc", "libbnn_chaos_hip.so")  # override: A/B builds
 
 BNN_OK = 0
+ABI_VERSION = 3  # include/bnn_chaos_hip.h: BNN_ABI_VERSION
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_RANGE = -1, -2, -3, -4, -5
 
 
 class BnnArch(C.Structure):
     _fields_ = [("n_features", C.c_int32), ("hidden", C.c_int32), ("latent", C.c_int32), ("fix_megno", C.c_int32),
-                ("zero_mask", C.c_uint64), ("lowest_std", C.c_float), ("pad", C.c_float)]
+                ("zero_mask", C.c_uint64), ("lowest_std", C.c_float), ("pad", C.c_float), ("depth_in", C.c_int32), ("depth_out", C.c_int32)]
 
 
 class BnnGrid(C.Structure):
     _fields_ = [("B", C.c_int64), ("T", C.c_int32), ("J", C.c_int32), ("nchunks", C.c_int32),
-                ("systems_per_block", C.c_int32), ("noisy", C.c_int32), ("reserved", C.c_int32)]
+                ("systems_per_block", C.c_int32), ("noisy", C.c_int32), ("engine", C.c_int32)]
 
 
 class BnnStats(C.Structure):
@@ -94,8 +95,9 @@ def lib():
     L.bnn_group_min_f32.argtypes = [_vp, C.c_int64, C.c_int32, _vp, _vp]
     L.bnn_quantiles_f32.argtypes = [_vp, C.c_int64, C.c_int64, _vp, C.c_int32, _vp, _vp]
     L.bnn_feature_pack_f64.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, _vp]
-    L.bnn_philox_normal_f32.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+    L.bnn_philox_normal_f32.argtypes = [C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                         _vp, _vp]
+    L.bnn_build_flags.restype = C.c_char_p
     L.bnn_philox_raw_u32.argtypes = [C.c_uint32] * 6 + [C.c_int64, _vp, _vp]
     L.bnn_prior_table_f32.argtypes = [C.c_double, C.c_double, C.c_int32, _vp, C.POINTER(C.c_double)]
     L.bnn_stats_draw_f32.argtypes = [_vp, C.c_int64, C.c_int64, C.POINTER(BnnStats), C.c_uint64, C.c_int64, C.c_int64, _vp, _vp]
@@ -109,13 +111,13 @@ def lib():
     L.bnn_multiswag_bands_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_float, C.c_uint64,
                                           C.c_int64, C.c_int64, C.c_int32, _vp, _vp, C.POINTER(BnnStats), C.c_int32, C.POINTER(BnnSketch),
                                           _vp, _vp, _vp]
-    if L.bnn_abi_version() != 2:
-        raise NativeError(-1, "ABI version mismatch")
+    if L.bnn_abi_version() != ABI_VERSION:
+        raise NativeError(-1, f"ABI version mismatch: {SO_PATH} reports {L.bnn_abi_version()}, this binding is written for {ABI_VERSION}")
     _lib = L
     return L
 
 
-EXPORTS = ("bnn_abi_version", "bnn_last_error", "bnn_device_count", "bnn_param_count", "bnn_plan_create",
+EXPORTS = ("bnn_abi_version", "bnn_last_error", "bnn_device_count", "bnn_param_count", "bnn_build_flags", "bnn_plan_create",
            "bnn_plan_destroy", "bnn_plan_layer_order", "bnn_layer_order", "bnn_fragment_table", "bnn_swag_draw_f32", "bnn_forward_f32", "bnn_multiswag_f32",
            "bnn_moments_f64", "bnn_truncnorm_f32", "bnn_prior_resample_f32", "bnn_regress_f32", "bnn_group_min_f32", "bnn_quantiles_f32", "bnn_feature_pack_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32",
            "bnn_prior_table_f32", "bnn_stats_draw_f32", "bnn_multiswag_stats_f32", "bnn_sketch_bins", "bnn_sketch_update_u32",
@@ -142,21 +144,27 @@ def stream_ptr():
 
 
 class Plan:
-    """Owns a bnn_plan (device operand tables) for one architecture / column mask."""
+    """Owns a bnn_plan (device operand tables) for one architecture / column mask.
+    depth_in / depth_out = hparams['in'] / hparams['out'] (the `layers` argument of the reference's mlp(), spock_reg_model.py:301-321)."""
 
-    def __init__(self, zero_mask, lowest_std=0.5, n_features=41, hidden=40, latent=20, fix_megno=False):
-        self.arch = BnnArch(n_features, hidden, latent, int(bool(fix_megno)), zero_mask, lowest_std, 0.0)
+    def __init__(self, zero_mask, lowest_std=0.5, n_features=41, hidden=40, latent=20, fix_megno=False, depth_in=1, depth_out=1):
+        self.arch = BnnArch(n_features, hidden, latent, int(bool(fix_megno)), zero_mask, lowest_std, 0.0, int(depth_in), int(depth_out))
         self.d = check(lib().bnn_param_count(C.byref(self.arch)))
         self.fix_megno = bool(fix_megno)
+        self.n_features, self.hidden, self.latent = int(n_features), int(hidden), int(latent)
+        self.depth_in, self.depth_out = int(depth_in), int(depth_out)
         self.summary_width = 2 * latent + (2 if fix_megno else 0)   # [mu_sample | std_sample | megno mean, megno std]
+        # the pretrained ensemble's network runs on the register-resident kernels (at T % 4 == 0), everything else on the generic engine
+        self.v50net = (self.n_features, self.hidden, self.latent, self.depth_in, self.depth_out) == (41, 40, 20, 1, 1)
+        self.n_linear = (1 if depth_in == 0 else depth_in + 2) + (1 if depth_out == 0 else depth_out + 2)
         h = _vp()
         check(lib().bnn_plan_create(C.byref(self.arch), C.byref(h)))
         self.handle = h
 
     def layer_order(self, layer, noisy=False):
         import numpy as np
-        buf = np.zeros(64, np.int32)
-        n = check(lib().bnn_plan_layer_order(self.handle, layer, int(noisy), buf.ctypes.data, 64))
+        buf = np.zeros(256, np.int32)
+        n = check(lib().bnn_plan_layer_order(self.handle, layer, int(noisy), buf.ctypes.data, 256))
         return buf[:n].copy()
 
     def __del__(self):

@@ -10,6 +10,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fmaf/MFMA are the only fusions).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -105,6 +106,48 @@ __global__ __launch_bounds__(128) void bnn_regress_kernel(RegressParams p) {
     float sd = (0.5f * (tanhf(r[1]) + 1.0f)) * p.std_span + p.std_lo;
     *reinterpret_cast<f32x2*>(p.out + o * 2) = (f32x2){mu, sd};
     if (p.pre) *reinterpret_cast<f32x2*>(p.pre + o * 2) = (f32x2){r[0], r[1]};
+}
+
+// The same for the hparam-built network (generic engine): regress_nn = mlp(SM, 2, hidden, depth_out) with run-time shapes, natural
+// accumulation order (bias, then inputs ascending) = the tail of bnn_forward_generic_kernel, bit for bit.  One thread per system,
+// activations in registers-per-thread LDS rows, weights straight from the flat vector (L1/L2: every thread of a block reads the
+// same address).
+struct GenRegressParams {
+    const float* summary;  // [J,B,SM]
+    const float* W;        // [J,d]
+    float* out;
+    float* pre;
+    int64_t B;
+    float std_lo, std_span;
+    int32_t d, SM, n_reg, ld;
+    GenLayer layer[GEN_MAX_LAYERS / 2 + 1];
+};
+__global__ __launch_bounds__(64) void bnn_regress_generic_kernel(GenRegressParams p) {
+    extern __shared__ float rs[];   // [2][64][ld]
+    const int tid = threadIdx.x, j = blockIdx.y;
+    const float* wj = p.W + (int64_t)j * p.d;
+    const int64_t b = (int64_t)blockIdx.x * 64 + tid;
+    const bool live = b < p.B;
+    const int64_t o = (int64_t)j * p.B + b;
+    float* cur = rs + tid * p.ld;
+    float* nxt = rs + (64 + tid) * p.ld;
+    for (int k = 0; k < p.SM; ++k) cur[k] = live ? p.summary[o * p.SM + k] : 0.0f;
+    for (int l = 0; l < p.n_reg; ++l) {
+        const GenLayer ly = p.layer[l];
+        for (int n = 0; n < ly.N; ++n) {
+            float acc = wj[ly.off_b + n];
+            const float* wr = wj + ly.off_w + (int64_t)n * ly.K;
+            for (int k = 0; k < ly.K; ++k) acc = fmaf(wr[k], cur[k], acc);
+            nxt[n] = ly.relu ? fmaxf(acc, 0.0f) : acc;
+        }
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    if (!live) return;
+    const float r0 = cur[0], r1 = cur[1];
+    float mu = (0.5f * (tanhf(r0) + 1.0f)) * 8.0f + 4.0f;
+    float sd = (0.5f * (tanhf(r1) + 1.0f)) * p.std_span + p.std_lo;
+    *reinterpret_cast<f32x2*>(p.out + o * 2) = (f32x2){mu, sd};
+    if (p.pre) *reinterpret_cast<f32x2*>(p.pre + o * 2) = (f32x2){r0, r1};
 }
 
 // Per-system percentiles over the draws: one workgroup bitonic-sorts one (system, channel) column of R values in LDS.
@@ -240,7 +283,7 @@ __global__ void bnn_feature_pack_kernel(const double* __restrict__ ts, const dou
     else put(o, v);
 }
 
-__global__ void bnn_philox_fill_kernel(int kind, uint64_t seed, int64_t id0, int64_t n_rows, int64_t B, int64_t sys0, int width,
+__global__ void bnn_philox_fill_kernel(int kind, uint64_t seed, int64_t id0, int64_t n_rows, int64_t B, int64_t sys0, int width, int aux,
                                        float* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (kind == 0 || kind == 1) {
@@ -249,8 +292,8 @@ __global__ void bnn_philox_fill_kernel(int kind, uint64_t seed, int64_t id0, int
         int64_t row = i / width;
         int el = (int)(i % width);
         out[i] = philox_z(kind == 0 ? TAG_Z1 : TAG_Z2, id0 + row, el, seed);
-    } else if (kind == 2 || kind == 4) {   // eps [n_rows,B,2,20]; eps_sum [n_rows,B,SM] with SM = width (40, or 42 with fix_megno)
-        const int SM = kind == 4 && width > 0 ? width : S2;
+    } else if (kind == 2 || kind == 4) {   // eps [n_rows,B,2,L] with L = width (0: 20); eps_sum [n_rows,B,SM] with SM = width (0: 40)
+        const int SM = kind == 4 ? (width > 0 ? width : S2) : 2 * (width > 0 ? width : L);
         int64_t total = n_rows * B * SM;
         if (i >= total) return;
         int el = (int)(i % SM);
@@ -268,14 +311,14 @@ __global__ void bnn_philox_fill_kernel(int kind, uint64_t seed, int64_t id0, int
         int64_t sys = i % B, row = i / B;
         const uint4 q = philox4x32_10(philox_sys_ctr(TAG_US, id0 + row, sys0 + sys, 0), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
         out[i] = ((float)(q.x >> 8) + 1.0f) * 5.9604644775390625e-8f;
-    } else {  // kind 3: eps_in [n_rows, B, T = width, 41]: block t*7 + col/6, normal col%6 (bnn_common.hip.h)
-        const int T = width;
-        int64_t per = (int64_t)T * F, total = n_rows * B * per;
+    } else {  // kind 3: eps_in [n_rows, B, T = width, NF = aux (0: 41)]: block t * ceil(NF/6) + col/6, normal col%6 (bnn_common.hip.h)
+        const int T = width, NF = aux > 0 ? aux : F, nblk = (NF + NIN_PER_BLOCK - 1) / NIN_PER_BLOCK;
+        int64_t per = (int64_t)T * NF, total = n_rows * B * per;
         if (i >= total) return;
-        int col = (int)(i % F), t = (int)((i / F) % T);
+        int col = (int)(i % NF), t = (int)((i / NF) % T);
         int64_t sys = (i / per) % B, row = i / (per * B);
         float n6[6];
-        philox_in6(id0 + row, sys0 + sys, t * NIN_BLOCKS + col / NIN_PER_BLOCK, seed, n6);
+        philox_in6(id0 + row, sys0 + sys, t * nblk + col / NIN_PER_BLOCK, seed, n6);
         const int j = col % NIN_PER_BLOCK;
         out[i] = j == 0 ? n6[0] : j == 1 ? n6[1] : j == 2 ? n6[2] : j == 3 ? n6[3] : j == 4 ? n6[4] : n6[5];
     }
@@ -297,7 +340,7 @@ __global__ __launch_bounds__(256) void bnn_swag_draw_kernel(const float* __restr
                                                             const float* __restrict__ z2, float c1, float c2, float scale,
                                                             uint64_t seed, int64_t draw_id0, float* __restrict__ W_out) {
     __shared__ float slabs[4 * SLAB];
-    __shared__ float zsh[MAXK];
+    __shared__ float zsh[MAXK_DRAW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int DRAW_SLICES = (D + 255) / 256;
     const int64_t e = blockIdx.x / DRAW_SLICES;
@@ -305,19 +348,25 @@ __global__ __launch_bounds__(256) void bnn_swag_draw_kernel(const float* __restr
     int s = seed_idx[e];
     const bool bad = (s < 0 || s >= S);
     if (bad) s = 0;
-    if (threadIdx.x < K)
-        zsh[threadIdx.x] = z2 ? z2[e * K + threadIdx.x] : philox_z(TAG_Z2, draw_id0 + e, threadIdx.x, seed);
+    for (int k = threadIdx.x; k < K; k += 256) zsh[k] = z2 ? z2[e * K + k] : philox_z(TAG_Z2, draw_id0 + e, k, seed);
     const int i0 = (slice * 4 + wave) * 64;
     const float* pd = pre_D + (int64_t)s * D * K;
-    if (i0 < D) draw_stage(pd, i0, D, K, lane, slabs + wave * SLAB);
-    __syncthreads();
     const int i = i0 + lane;
-    if (i < D) {
-        float z1v = z1 ? z1[e * (int64_t)D + i] : philox_z(TAG_Z1, draw_id0 + e, i, seed);
-        float w = draw_row(w_avg + (int64_t)s * D, w2_avg + (int64_t)s * D, i, K, lane, slabs + wave * SLAB, zsh, z1v, c1, c2,
-                           scale);
-        W_out[e * (int64_t)D + i] = bad ? __builtin_nanf("") : w;
+    const bool live = i < D;
+    const float wa = live ? w_avg[(int64_t)s * D + i] : 0.0f;
+    float w = 0.0f, dot = 0.0f;
+    if (live) {
+        const float z1v = z1 ? z1[e * (int64_t)D + i] : philox_z(TAG_Z1, draw_id0 + e, i, seed);
+        w = draw_head(wa, w2_avg[(int64_t)s * D + i], z1v, c1);
     }
+    for (int kc = 0; kc < K; kc += MAXK) {   // the deviation columns, 32 at a time through the slab; the dot product runs on in k order
+        const int Kc = K - kc < MAXK ? K - kc : MAXK;
+        if (kc) __syncthreads();
+        if (i0 < D) draw_stage(pd, i0, D, K, kc, Kc, lane, slabs + wave * SLAB);
+        __syncthreads();
+        if (live) dot = draw_dot(slabs + wave * SLAB + lane * Kc, wa, zsh + kc, Kc, dot);
+    }
+    if (live) W_out[e * (int64_t)D + i] = bad ? __builtin_nanf("") : draw_finish(w, dot, c2, scale);
 }
 
 // The Philox form of the statistics epilogue on materialised (mu, std) pairs: the same per-evaluation routine as the forward
@@ -441,21 +490,31 @@ static int fail(int code, const std::string& msg) {
 struct bnn_plan {
     bnn_arch arch;
     bool megno = false;  // arch.fix_megno
+    bool v50net = false; // the pretrained ensemble's network: 41 -> 40 -> 40 -> 20 / 40 (42) -> 40 -> 40 -> 2 (register-resident kernels)
     int d = D;           // length of the flat parameter vector
-    Tables tab[2];  // [0] = arch mask, [1] = all 41 columns (noisy forward)
+    Tables tab[2];  // [0] = arch mask, [1] = all 41 columns (noisy forward)      (v50net only)
     int16_t* d_f2 = nullptr;   // regress_nn fragment gather table
     int16_t* d_f4 = nullptr;   // feature_nn weight-register table (4x4x1 path) for the plan's mask
     int16_t* d_f4n = nullptr;  // ... with every column live (noisy forward)
     float* d_rcp = nullptr;    // [RCP_N] 1/(i+1)
+    GenArch gen;               // generic engine: every plan has one (the v50 network falls back to it for T % 4 != 0 or T < 8)
+    GenArch* d_gen = nullptr;
     int device = 0;
 };
 
-static int check_arch(const bnn_arch* a) {
+static bool is_v50net(const bnn_arch* a) {
+    return a->n_features == F && a->hidden == H && a->latent == L && a->depth_in == 1 && a->depth_out == 1;
+}
+
+static int check_arch(const bnn_arch* a, GenArch* gen_out = nullptr) {
     if (!a) return fail(BNN_ERR_INVALID, "arch is NULL");
-    if (a->n_features != F || a->hidden != H || a->latent != L)
-        return fail(BNN_ERR_UNSUPPORTED, "only the 41->40->40->20 / 40->40->40->2 network of the pretrained ensemble is built");
-    if (a->zero_mask >> F) return fail(BNN_ERR_INVALID, "zero_mask has bits beyond column 40");
     if (a->fix_megno != 0 && a->fix_megno != 1) return fail(BNN_ERR_INVALID, "fix_megno must be 0 or 1");
+    GenArch g;
+    const char* why = "";
+    if (gen_build(a->n_features, a->hidden, a->latent, a->depth_in, a->depth_out, a->fix_megno != 0, &g, &why))
+        return fail(BNN_ERR_UNSUPPORTED, why);
+    if (a->n_features < 64 && (a->zero_mask >> a->n_features)) return fail(BNN_ERR_INVALID, "zero_mask has bits beyond the last column");
+    if (gen_out) *gen_out = g;
     return 0;
 }
 
@@ -471,9 +530,15 @@ int bnn_device_count(void) {
     return n;
 }
 
+#ifndef BNN_BUILD_FLAGS
+#define BNN_BUILD_FLAGS ""
+#endif
+const char* bnn_build_flags(void) { return BNN_BUILD_FLAGS; }
+
 int bnn_param_count(const bnn_arch* arch) {
-    int rc = check_arch(arch);
-    return rc ? rc : layout_of(arch->fix_megno != 0).D;
+    GenArch g;
+    int rc = check_arch(arch, &g);
+    return rc ? rc : g.d;
 }
 
 static bool upload(const void* host, size_t bytes, void** dev) {
@@ -481,25 +546,33 @@ static bool upload(const void* host, size_t bytes, void** dev) {
 }
 
 int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
-    int rc = check_arch(arch);
+    GenArch g;
+    int rc = check_arch(arch, &g);
     if (rc) return rc;
     if (!out) return fail(BNN_ERR_INVALID, "out is NULL");
     bnn_plan* pl = new bnn_plan();
     pl->arch = *arch;
     pl->megno = arch->fix_megno != 0;
-    pl->d = layout_of(pl->megno).D;
-    pl->tab[0] = build_tables(arch->zero_mask, false, pl->megno);
-    pl->tab[1] = build_tables(arch->zero_mask, true, pl->megno);
+    pl->v50net = is_v50net(arch);
+    pl->gen = g;
+    pl->d = g.d;
+    if (pl->v50net) {
+        pl->tab[0] = build_tables(arch->zero_mask, false, pl->megno);
+        pl->tab[1] = build_tables(arch->zero_mask, true, pl->megno);
+        if (pl->d != layout_of(pl->megno).D) { delete pl; return fail(BNN_ERR_INVALID, "internal: the two engines disagree on the parameter count"); }
+    }
     if (hipGetDevice(&pl->device) != hipSuccess) {
         delete pl;
         return fail(BNN_ERR_NO_DEVICE, "no HIP device");
     }
     std::vector<float> rcp(RCP_N);
     for (int i = 0; i < RCP_N; ++i) rcp[i] = 1.0f / (float)(i + 1);
-    if (!upload(pl->tab[0].f2.data(), pl->tab[0].f2.size() * sizeof(int16_t), (void**)&pl->d_f2) ||
-        !upload(pl->tab[0].f4.data(), pl->tab[0].f4.size() * sizeof(int16_t), (void**)&pl->d_f4) ||
-        !upload(pl->tab[1].f4.data(), pl->tab[1].f4.size() * sizeof(int16_t), (void**)&pl->d_f4n) ||
-        !upload(rcp.data(), RCP_N * sizeof(float), (void**)&pl->d_rcp)) {
+    bool ok = upload(rcp.data(), RCP_N * sizeof(float), (void**)&pl->d_rcp) && upload(&pl->gen, sizeof(GenArch), (void**)&pl->d_gen);
+    if (ok && pl->v50net)
+        ok = upload(pl->tab[0].f2.data(), pl->tab[0].f2.size() * sizeof(int16_t), (void**)&pl->d_f2) &&
+             upload(pl->tab[0].f4.data(), pl->tab[0].f4.size() * sizeof(int16_t), (void**)&pl->d_f4) &&
+             upload(pl->tab[1].f4.data(), pl->tab[1].f4.size() * sizeof(int16_t), (void**)&pl->d_f4n);
+    if (!ok) {
         bnn_plan_destroy(pl);
         return fail(BNN_ERR_HIP, "plan table upload failed");
     }
@@ -513,12 +586,27 @@ int bnn_plan_destroy(bnn_plan* pl) {
     if (pl->d_f4) (void)hipFree(pl->d_f4);
     if (pl->d_f4n) (void)hipFree(pl->d_f4n);
     if (pl->d_rcp) (void)hipFree(pl->d_rcp);
+    if (pl->d_gen) (void)hipFree(pl->d_gen);
     delete pl;
     return 0;
 }
 
+// natural order of the generic engine: the live inputs ascending (layer 0 drops the masked columns unless `noisy`)
+static int natural_order(const GenArch& g, uint64_t zero_mask, int layer, int noisy, int32_t* host_order, int cap) {
+    if (layer < 0 || layer >= g.n_feat + g.n_reg) return fail(BNN_ERR_INVALID, "layer index beyond the network's Linear modules");
+    int n = 0;
+    for (int k = 0; k < g.layer[layer].K; ++k) {
+        if (layer == 0 && !noisy && k < 64 && ((zero_mask >> k) & 1ull)) continue;
+        if (host_order && n < cap) host_order[n] = k;
+        ++n;
+    }
+    return n;
+}
+
 int bnn_plan_layer_order(const bnn_plan* pl, int layer, int noisy, int32_t* host_order, int cap) {
-    if (!pl || layer < 0 || layer > 5) return fail(BNN_ERR_INVALID, "bad plan/layer");
+    if (!pl) return fail(BNN_ERR_INVALID, "plan is NULL");
+    if (!pl->v50net) return natural_order(pl->gen, pl->arch.zero_mask, layer, noisy, host_order, cap);
+    if (layer < 0 || layer > 5) return fail(BNN_ERR_INVALID, "bad plan/layer");
     const std::vector<int32_t>& o = pl->tab[noisy ? 1 : 0].order[layer];
     if (host_order)
         for (int i = 0; i < (int)o.size() && i < cap; ++i) host_order[i] = o[i];
@@ -526,8 +614,10 @@ int bnn_plan_layer_order(const bnn_plan* pl, int layer, int noisy, int32_t* host
 }
 
 int bnn_layer_order(const bnn_arch* arch, int layer, int noisy, int32_t* host_order, int cap) {
-    int rc = check_arch(arch);
+    GenArch g;
+    int rc = check_arch(arch, &g);
     if (rc) return rc;
+    if (!is_v50net(arch)) return natural_order(g, arch->zero_mask, layer, noisy, host_order, cap);
     if (layer < 0 || layer > 5) return fail(BNN_ERR_INVALID, "layer must be 0..5");
     Tables t = build_tables(arch->zero_mask, noisy != 0, arch->fix_megno != 0);
     const std::vector<int32_t>& o = t.order[layer];
@@ -539,6 +629,7 @@ int bnn_layer_order(const bnn_arch* arch, int layer, int noisy, int32_t* host_or
 int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host_table, int cap) {
     int rc = check_arch(arch);
     if (rc) return rc;
+    if (!is_v50net(arch)) return fail(BNN_ERR_UNSUPPORTED, "fragment tables belong to the pretrained network's kernels; the generic engine builds its LDS image in the kernel prologue");
     if (which != 1 && which != 2) return fail(BNN_ERR_INVALID, "which must be 1 (feature_nn images) or 2 (regress_nn fragments)");
     Tables t = build_tables(arch->zero_mask, noisy != 0, arch->fix_megno != 0);
     const std::vector<int16_t>& v = which == 1 ? t.f4 : t.f2;
@@ -562,18 +653,37 @@ static int pick_spc(const bnn_grid* g, int64_t csz, bool xcd_order) {
     return 64;
 }
 
+static GenMerge gen_merge_consts(int na, int nb) {   // oracle/bnn_oracle.c merge_consts, constant for constant
+    GenMerge m{2, 0.0f, 0.0f};
+    if (nb == 0) m.mode = 2;
+    else if (na == 0) m.mode = 3;
+    else if (na == nb) { m.mode = 0; m.w1 = (float)na * 0.5f; }
+    else {
+        m.mode = 1;
+        m.w1 = (float)((double)nb / (double)(na + nb));
+        m.w2 = (float)((double)na * (double)nb / (double)(na + nb));
+    }
+    return m;
+}
+
 static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, bool fused, bool noisy, void* stream, int lowp = 0) {
     if (!pl || !g) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
     if (g->B < 0 || g->J < 0 || g->nchunks < 1) return fail(BNN_ERR_INVALID, "negative size");
     if (g->J % g->nchunks) return fail(BNN_ERR_INVALID, "J must be a multiple of nchunks");
-    if (g->T < 8 || (g->T % 4) || g->T / 4 > RCP_N) return fail(BNN_ERR_UNSUPPORTED, "T must be a multiple of 4 in [8, 16384]");
+    if (g->T < 2 || (g->T + 3) / 4 > RCP_N) return fail(BNN_ERR_UNSUPPORTED, "T must be in [2, 16384] (torch.std of a single timestep is NaN)");
     if (g->systems_per_block < 0 || (g->systems_per_block % 64)) return fail(BNN_ERR_INVALID, "systems_per_block must be a multiple of 64");
+    // the pretrained network's kernels take whole tiles of 4 timesteps and at least two of them; everything else is the generic engine's
+    if (g->engine != 0 && g->engine != 1) return fail(BNN_ERR_INVALID, "grid.engine must be 0 (choose) or 1 (generic)");
+    const bool generic = !pl->v50net || (g->T % 4) != 0 || g->T < 8 || g->engine == 1;
+    if (generic && lowp) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels are built for the pretrained network at T % 4 == 0 only");
+    if (generic && fused) return fail(BNN_ERR_UNSUPPORTED, "the in-prologue draw (W_workspace = NULL) exists for the pretrained network at T % 4 == 0 only: pass a [J, d] workspace");
     if (g->B == 0 || g->J == 0) return 0;
     if (!p.x || !(p.out || p.sink)) return fail(BNN_ERR_INVALID, "x/out is NULL");
     if (p.draw_id0 % g->nchunks) return fail(BNN_ERR_INVALID, "draw_id0 must be a multiple of nchunks");
-    p.B = g->B; p.T = g->T; p.ntiles = g->T / 4; p.J = g->J; p.nch = g->nchunks;
+    const int NF = pl->arch.n_features;
+    p.B = g->B; p.T = g->T; p.ntiles = (g->T + 3) / 4; p.J = g->J; p.nch = g->nchunks;
     p.csz = (g->B + g->nchunks - 1) / g->nchunks;
-    p.xcd_order = (g->nchunks > 1 || (double)g->B * g->T * F * sizeof(float) > 256.0 * 1024 * 1024) ? 1 : 0;
+    p.xcd_order = (g->nchunks > 1 || (double)g->B * g->T * NF * sizeof(float) > 256.0 * 1024 * 1024) ? 1 : 0;
     p.spc = pick_spc(g, p.csz, p.xcd_order != 0);
     p.row_id0 = p.draw_id0 / g->nchunks;
     p.tab_f2 = pl->d_f2; p.tab_wr = noisy ? pl->d_f4n : pl->d_f4; p.rcp_tab = pl->d_rcp;
@@ -584,8 +694,22 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     if (nblk > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "grid too large; split the draws");
     static_assert(Lay<true>::NF2 * 64 <= FLAT_LDS, "regress_nn fragments overwrite the flat vector in place");
     hipStream_t st = (hipStream_t)stream;
-    const bool k31 = pl->tab[0].kin4 == 31;
     hipError_t e;
+    if (generic) {
+        GenParams P{};
+        P.f = p;
+        P.g = pl->d_gen;
+        int cnt[4];
+        for (int q = 0; q < 4; ++q) cnt[q] = q < g->T ? (g->T - q + 3) / 4 : 0;   // timesteps t = q, q + 4, ... below T
+        P.m01 = gen_merge_consts(cnt[0], cnt[1]);
+        P.m23 = gen_merge_consts(cnt[2], cnt[3]);
+        P.m0123 = gen_merge_consts(cnt[0] + cnt[1], cnt[2] + cnt[3]);
+        P.noisy = noisy ? 1 : 0;
+        e = launch_fwd_generic(pl->gen, (unsigned)nblk, st, P);
+        if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("generic forward kernel launch: ") + hipGetErrorString(e));
+        return 0;
+    }
+    const bool k31 = pl->tab[0].kin4 == 31;
     if (pl->megno && (lowp || p.sink)) return fail(BNN_ERR_UNSUPPORTED, "fix_megno: the reduced-precision and fused-statistics forms are not built");
     if (pl->megno) e = launch_fwd_megno(k31, fused, noisy, (unsigned)nblk, st, p);
     else if (lowp) e = launch_fwd_lowp(lowp, (unsigned)nblk, st, p);
@@ -597,8 +721,9 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     return 0;
 }
 
-static int draw_consts(int K, float scale, float* c1, float* c2) {
-    if (K < 2 || K > MAXK) return fail(BNN_ERR_RANGE, "SWAG rank K must be in [2, 32]");
+static int draw_consts(int K, float scale, float* c1, float* c2, int kmax = MAXK_DRAW) {
+    if (K < 2 || K > kmax) return fail(BNN_ERR_RANGE, kmax == MAXK ? "SWAG rank K above 32 needs the draw-once form (W_workspace): the in-prologue draw takes K in [2, 32]"
+                                                                  : "SWAG rank K must be in [2, 256]");
     *c1 = (float)((double)scale * (1.0 / std::sqrt(2.0)));  // scale * (1.0/np.sqrt(2.0)), :834
     *c2 = (float)std::sqrt(2.0 * (K - 1));                   // np.sqrt(2*(K-1)), :835
     return 0;
@@ -644,7 +769,7 @@ int bnn_forward_lowp_f32(const bnn_plan* plan, const bnn_grid* grid, const float
                          int64_t draw_id0, int64_t system_id0, int32_t precision, float* out, float* pre_clamp, float* summary, void* stream) {
     if (!plan || !grid) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
     if (precision < BNN_PREC_BF16 || precision > BNN_PREC_F16X3) return fail(BNN_ERR_INVALID, "precision must be one of BNN_PREC_BF16 .. BNN_PREC_F16X3");
-    if (plan->tab[0].kin4 != 31) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels are built for the v50 column mask only");
+    if (!plan->v50net || plan->tab[0].kin4 != 31) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels are built for the pretrained network with the v50 column mask only");
     if (grid->noisy) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels have no noisy form");
     if (grid->B == 0 || grid->J == 0) return 0;
     if (!W) return fail(BNN_ERR_INVALID, "W is NULL");
@@ -673,7 +798,7 @@ int bnn_multiswag_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x
     if ((z1 == nullptr) != (z2 == nullptr)) return fail(BNN_ERR_INVALID, "z1 and z2 must both be given or both be NULL");
     if (S < 1) return fail(BNN_ERR_INVALID, "bad S");
     FwdParams p{};
-    int rc = draw_consts(K, scale, &p.c1, &p.c2);
+    int rc = draw_consts(K, scale, &p.c1, &p.c2, MAXK);
     if (rc) return rc;
     p.scale = scale; p.K = K; p.S = S;
     p.x = x; p.w_avg = w_avg; p.w2_avg = w2_avg; p.pre_D = pre_D; p.seed_idx = seed_idx; p.z1 = z1; p.z2 = z2; p.eps = eps;
@@ -710,6 +835,25 @@ int bnn_regress_f32(const bnn_plan* pl, const float* summary, const float* W, in
     if (J < 0 || B < 0) return fail(BNN_ERR_INVALID, "bad J/B");
     if (J == 0 || B == 0) return 0;
     if (!summary || !W || !out) return fail(BNN_ERR_INVALID, "NULL argument");
+    if ((B + 127) / 128 > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many systems for one launch");
+    if (!pl->v50net) {   // the hparam-built network: natural accumulation order, the generic forward kernel's tail bit for bit
+        const GenArch& g = pl->gen;
+        GenRegressParams q{};
+        q.B = B; q.std_lo = pl->arch.lowest_std; q.std_span = (float)(6.0 - (double)pl->arch.lowest_std);
+        q.d = g.d; q.SM = g.SM; q.n_reg = g.n_reg;
+        int ld = g.SM;
+        for (int l = 0; l < g.n_reg; ++l) { q.layer[l] = g.layer[g.n_feat + l]; ld = std::max(ld, q.layer[l].N); }
+        q.ld = ld | 1;   // odd: conflict-free per-thread rows
+        for (int64_t j0 = 0; j0 < J; j0 += 65535) {
+            const int64_t nj = J - j0 < 65535 ? J - j0 : 65535;
+            q.summary = summary + j0 * B * g.SM; q.W = W + j0 * g.d; q.out = out + j0 * B * 2;
+            q.pre = pre_clamp ? pre_clamp + j0 * B * 2 : nullptr;
+            hipLaunchKernelGGL(bnn_regress_generic_kernel, dim3((unsigned)((B + 63) / 64), (unsigned)nj), dim3(64), (size_t)2 * 64 * q.ld * sizeof(float),
+                               (hipStream_t)stream, q);
+            HIP_TRY(hipGetLastError());
+        }
+        return 0;
+    }
     RegressParams p;
     p.summary = summary; p.W = W; p.out = out; p.pre = pre_clamp; p.B = B;
     p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);
@@ -719,7 +863,6 @@ int bnn_regress_f32(const bnn_plan* pl, const float* summary, const float* W, in
         if ((int)o.size() != (l == 0 ? SM : H)) return fail(BNN_ERR_INVALID, "internal: regress_nn order table");
         for (int i = 0; i < (int)o.size(); ++i) p.ord[l][i] = (int8_t)o[i];
     }
-    if ((B + 127) / 128 > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many systems for one launch");
     for (int64_t j0 = 0; j0 < J; j0 += 65535) {  // grid.y limit
         const int64_t nj = J - j0 < 65535 ? J - j0 : 65535;
         RegressParams q = p;
@@ -792,14 +935,16 @@ int bnn_moments_f64(const float* samples, int64_t R, int64_t B, double* moments,
 }
 
 int bnn_philox_normal_f32(int32_t kind, uint64_t philox_seed, int64_t id0, int64_t n_rows, int64_t B, int64_t system_id0, int32_t width,
-                          float* out, void* stream) {
-    if (!out || kind < 0 || kind > 6 || n_rows < 0) return fail(BNN_ERR_INVALID, "bad argument");
-    if (kind == 4 && width != 0 && width != S2 && width != S2 + 2) return fail(BNN_ERR_INVALID, "eps_sum is 40 wide (42 with fix_megno)");
-    int64_t total = kind == 2 ? n_rows * B * S2 : kind == 4 ? n_rows * B * (int64_t)(width > 0 ? width : S2) : kind == 3 ? n_rows * B * (int64_t)width * F : kind == 5 ? n_rows * B * (int64_t)width
-                    : kind == 6 ? n_rows * B : n_rows * (int64_t)width;
+                          int32_t n_features, float* out, void* stream) {
+    if (!out || kind < 0 || kind > 6 || n_rows < 0 || width < 0) return fail(BNN_ERR_INVALID, "bad argument");
+    if (kind == 3 && n_features != 0 && n_features != F && n_features != 2 * F) return fail(BNN_ERR_INVALID, "n_features must be 41 or 82");
+    const int NF = n_features > 0 ? n_features : F;
+    int64_t total = kind == 2 ? n_rows * B * 2 * (int64_t)(width > 0 ? width : L) : kind == 4 ? n_rows * B * (int64_t)(width > 0 ? width : S2)
+                    : kind == 3 ? n_rows * B * (int64_t)width * NF : kind == 5 ? n_rows * B * (int64_t)width : kind == 6 ? n_rows * B : n_rows * (int64_t)width;
     if (total == 0) return 0;
+    if ((total + 255) / 256 > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many normals for one launch");
     hipLaunchKernelGGL(bnn_philox_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind, philox_seed,
-                       id0, n_rows, B, system_id0, width, out);
+                       id0, n_rows, B, system_id0, width, NF, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "bnn_internal.h"
 
 namespace bnn {
@@ -149,6 +151,21 @@ DEVINL void philox_in6(int64_t row, int64_t sys, int block, uint64_t seed, float
 DEVINL f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 DEVINL f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
+// v_mfma_f32_4x4x1_16b_f32 with CBSZ = 4: the A operand (4 neurons x 1 input) of block ABID serves all 16 blocks
+// (scripts/probes/cbsz_probe.hip confirms the semantics on gfx950).  cbsz / abid are immediates: compile-time loops below.
+template <int ABID>
+DEVINL f32x4 mfma4b(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0); }
+
+template <class Fn, int... I>
+DEVINL void static_for_impl(Fn&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class Fn>
+DEVINL void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// the same with an early exit: f returns false to stop (short-circuit: the remaining steps are branched over)
+template <class Fn, int... I>
+DEVINL void static_while_impl(Fn&& f, std::integer_sequence<int, I...>) { (void)(f(std::integral_constant<int, I>{}) && ...); }
+template <int N, class Fn>
+DEVINL void static_while(Fn&& f) { static_while_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // nn.ReLU as ONE integer max on the bit pattern: negative floats (and -0.0) are negative ints -> +0.0.
 DEVINL float relu1(float v) {
     int b = __builtin_bit_cast(int, v);
@@ -178,39 +195,42 @@ DEVINL f32x2 soft_clamp2(float r0, float r1, float std_lo, float std_span) {
 
 // ------------------------------------------------------------------------------------------------
 // SWAG draw of rows [i0, i0+64) by one wave (SWAGModel.sample_weights, spock_reg_model.py:815-838).
-// pre_D rows are staged through a wave-private LDS slab so the HBM/L2 read is one contiguous
-// 64*K-float run; lane l then owns row i0+l and accumulates its K-term dot product in k order.
-// Callers bracket the two phases with workgroup barriers (stage -> barrier -> compute -> barrier).
+// pre_D rows are staged through a wave-private LDS slab, MAXK columns at a time (for K <= 32 the read is one contiguous
+// 64*K-float run); lane l then owns row i0+l and accumulates its K-term dot product in k order.
+// Callers bracket the two phases with workgroup barriers (stage -> barrier -> compute -> barrier), once per chunk of columns.
 // ------------------------------------------------------------------------------------------------
-DEVINL void draw_stage(const float* __restrict__ pre_D_s, int i0, int d, int K, int lane, float* slab) {
-    const int64_t base = (int64_t)i0 * K, lim = (int64_t)d * K;
-    for (int n = 0; n < K; ++n) {
-        int idx = n * 64 + lane;
-        if (base + idx < lim) slab[idx] = pre_D_s[base + idx];
+DEVINL void draw_stage(const float* __restrict__ pre_D_s, int i0, int d, int K, int kc, int Kc, int lane, float* slab) {
+    // columns [kc, kc + Kc) of rows [i0, i0 + 64): slab[r * Kc + c].  With kc = 0, Kc = K (every K <= 32) this is one contiguous run.
+    for (int n = 0; n < Kc; ++n) {
+        const int idx = n * 64 + lane, r = idx / Kc, c = idx - r * Kc;
+        if (i0 + r < d) slab[idx] = pre_D_s[(int64_t)(i0 + r) * K + kc + c];
     }
 }
 
-DEVINL float draw_row(const float* __restrict__ w_avg_s, const float* __restrict__ w2_avg_s, int i, int K, int lane,
-                      const float* slab, const float* zsh, float z1v, float c1, float c2, float scale) {
-    // D = pre_D - w_avg[:,None] (:826); sigma = abs(diag(w2_avg - w_avg**2)) (:832)
-    // w = w_avg + scale/sqrt2 * z1 @ sigma**0.5 (:834);  w += scale * (D @ z2).T / sqrt(2(K-1)) (:835)
-    float wa = w_avg_s[i], w2 = w2_avg_s[i];
+// D = pre_D - w_avg[:,None] (:826); sigma = abs(diag(w2_avg - w_avg**2)) (:832)
+// w = w_avg + scale/sqrt2 * z1 @ sigma**0.5 (:834);  w += scale * (D @ z2).T / sqrt(2(K-1)) (:835)
+// The K-term dot product is accumulated in k order, a chunk of columns at a time (draw_dot), then draw_finish adds it.
+DEVINL float draw_head(float wa, float w2, float z1v, float c1) {
     float sq = wa * wa;
     float var = w2 - sq;
     float sd = sqrtf(fabsf(var));
     float t1 = (c1 * z1v) * sd;
-    float w = wa + t1;
-    float dot = 0.0f;
-    const float* row = slab + lane * K;
-    for (int k = 0; k < K; ++k) {
+    return wa + t1;
+}
+DEVINL float draw_dot(const float* row, float wa, const float* zc, int Kc, float dot) {
+    for (int k = 0; k < Kc; ++k) {
         float Dk = row[k] - wa;
-        dot = fmaf(Dk, zsh[k], dot);
+        dot = fmaf(Dk, zc[k], dot);
     }
+    return dot;
+}
+DEVINL float draw_finish(float w, float dot, float c2, float scale) {
     float t2 = (scale * dot) / c2;
     return w + t2;
 }
 
 constexpr int SLAB = 64 * MAXK;  // floats per wave
+constexpr int MAXK_DRAW = 256;   // SWAG rank the draw kernel takes (the in-prologue draw of the v50 kernels: MAXK)
 
 // Slab-free variant for the single-launch prologue: thread-per-element, the K-term row read straight from L2.
 // Same operation sequence as draw_row, hence the same bits.

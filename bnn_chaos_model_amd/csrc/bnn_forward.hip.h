@@ -16,8 +16,6 @@
 // co-issues with it, from either wave of the SIMD, so the kernel's time is the SUM of its matrix and vector instructions and the
 // loop below is written to need as few vector instructions as the arithmetic allows.
 #pragma once
-#include <utility>
-
 #include "bnn_common.hip.h"
 #include "bnn_stats.hip.h"
 
@@ -39,16 +37,6 @@
 #endif
 
 namespace bnn {
-
-// v_mfma_f32_4x4x1_16b_f32 with CBSZ = 4: the A operand (4 neurons x 1 input) of block ABID serves all 16 blocks
-// (scripts/probes/cbsz_probe.hip confirms the semantics on gfx950).  cbsz / abid are immediates: compile-time loop below.
-template <int ABID>
-DEVINL f32x4 mfma4b(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0); }
-
-template <class Fn, int... I>
-DEVINL void static_for_impl(Fn&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class Fn>
-DEVINL void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int KIN>
 DEVINL void load_row(const float* __restrict__ rp, float (&xv)[KIN]) {

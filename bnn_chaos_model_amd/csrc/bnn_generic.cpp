@@ -1,0 +1,82 @@
+// bnn_generic.cpp -- host side of the generic forward engine: turns (n_features, hidden, latent, depth in / out, fix_megno) into
+// the layer descriptor the kernel walks (bnn_generic.h), picks the register bucket and fits the LDS budget.
+#include "bnn_generic.h"
+
+#include <algorithm>
+
+namespace bnn {
+
+namespace {
+constexpr int LDS_BYTES = 160 * 1024;   // per CU on gfx950; one workgroup may take all of it
+constexpr int HQ_BUCKETS[] = {12, 16, 24, 32};
+
+int mlp_nlin(int layers) { return layers == 0 ? 1 : layers + 2; }   // mlp() (spock_reg_model.py:301-321)
+}  // namespace
+
+int gen_build(int F, int H, int L, int depth_in, int depth_out, bool megno, GenArch* out, const char** why) {
+    static const char* msg_f = "n_features must be 41 or 82 (time_series_features x (1 + include_derivatives))";
+    static const char* msg_w = "hidden and latent must be in [1, 128] and the summary width 2 latent (+ 2) at most 128";
+    static const char* msg_d = "depth `in` / `out` must be >= 0 with at most 16 Linear modules in the two MLPs together";
+    static const char* msg_l = "feature_nn's weights do not fit the 160 KB of LDS (roughly F*H + in*H*H + H*L <= 36 000 floats)";
+    if (F != 41 && F != 82) { *why = msg_f; return -2; }
+    const int SM = 2 * L + (megno ? 2 : 0);
+    if (H < 1 || H > GEN_MAX_WIDTH || L < 1 || L > GEN_MAX_WIDTH || SM > GEN_MAX_WIDTH) { *why = msg_w; return -2; }
+    if (depth_in < 0 || depth_out < 0 || mlp_nlin(depth_in) + mlp_nlin(depth_out) > GEN_MAX_LAYERS) { *why = msg_d; return -2; }
+    GenArch g{};
+    g.F = F; g.H = H; g.L = L; g.SM = SM; g.megno = megno ? 1 : 0;
+    g.n_feat = mlp_nlin(depth_in); g.n_reg = mlp_nlin(depth_out);
+    g.lq = (L + 3) / 4; g.smq = (SM + 3) / 4;
+    g.fq = F == 41 ? 11 : 21;
+    g.nin_blocks = (F + 5) / 6;
+    g.off_inlv = 0; g.off_sumlv = F;
+    int off = F + SM, bias0 = 0, need = std::max(g.smq, g.lq);
+    const int nl = g.n_feat + g.n_reg;
+    for (int l = 0; l < nl; ++l) {
+        const bool feat = l < g.n_feat;
+        const int ll = feat ? l : l - g.n_feat, nn = feat ? g.n_feat : g.n_reg;
+        GenLayer& y = g.layer[l];
+        y.K = ll == 0 ? (feat ? F : SM) : H;
+        y.N = ll == nn - 1 ? (feat ? L : 2) : H;
+        y.relu = ll < nn - 1 ? 1 : 0;
+        y.nkq = (y.K + 3) / 4;
+        const int groups = (y.N + 3) / 4;
+        y.nblk = (groups + 3) / 4;
+        y.ng_last = groups - 4 * (y.nblk - 1);
+        y.off_w = off; off += y.N * y.K;
+        y.off_b = off; off += y.N;
+        y.bias0 = bias0; bias0 += 16 * y.nblk;
+        y.wreg0 = -1;
+        need = std::max(need, 4 * y.nblk);
+        if (l > 0) need = std::max(need, y.nkq);
+    }
+    g.d = off;
+    g.nbias = bias0;
+    g.hq = 0;
+    for (int b : HQ_BUCKETS)
+        if (!g.hq && need <= b) g.hq = b;
+    if (!g.hq) { *why = msg_w; return -2; }
+    // LDS: feature_nn's registers must be resident; regress_nn's are if that costs no waves
+    int nfeat_regs = 0, nreg_regs = 0;
+    for (int l = 0; l < nl; ++l) (l < g.n_feat ? nfeat_regs : nreg_regs) += g.layer[l].nblk * g.layer[l].nkq;
+    auto waves_for = [&](int nwreg, int reg_in_lds) {
+        GenArch t = g;
+        t.nwreg = nwreg;
+        t.reg_in_lds = reg_in_lds;
+        for (int nw : {4, 2, 1})
+            if ((int64_t)(gen_shared_floats(t) + nw * gen_wave_floats(t)) * 4 <= LDS_BYTES) return nw;
+        return 0;
+    };
+    const int w_all = waves_for(nfeat_regs + nreg_regs, 1), w_feat = waves_for(nfeat_regs, 0);
+    if (!w_feat) { *why = msg_l; return -2; }
+    g.reg_in_lds = (w_all >= w_feat) ? 1 : 0;
+    g.nwaves = g.reg_in_lds ? w_all : w_feat;
+    g.nwreg = nfeat_regs + (g.reg_in_lds ? nreg_regs : 0);
+    int wreg = 0;
+    for (int l = 0; l < nl; ++l)
+        if (l < g.n_feat || g.reg_in_lds) { g.layer[l].wreg0 = wreg; wreg += g.layer[l].nblk * g.layer[l].nkq; }
+    g.lds_bytes = (gen_shared_floats(g) + g.nwaves * gen_wave_floats(g)) * 4;
+    *out = g;
+    return 0;
+}
+
+}  // namespace bnn

@@ -1,0 +1,72 @@
+// bnn_generic.h -- descriptor of the GENERIC forward engine: the network the reference builds from hparams
+// (spock_reg_model.py:301-321 mlp(), :346-362: any `hidden`, `latent`, depth `in` / `out`, 41 or 82 features, fix_megno), any
+// series length T >= 2.  Shared by the host (plan construction, bnn_abi.hip) and the kernel (bnn_generic.hip.h).
+//
+// Engine: lane = row as in the v50 kernel, v_mfma_f32_4x4x1_16b_f32 with the CBSZ/ABID broadcast, but the
+// weight registers are STREAMED from an LDS image instead of living in VGPRs: one ds_read_b32 (256 B per wave) feeds 16 MFMAs =
+// 4 consecutive inputs x 4 neuron groups.  A Linear layer with K inputs and N outputs is cut into
+//   nblk = ceil(N / 16) output blocks of 4 neuron groups (16 neurons; the last block may hold 1..4 groups: ng_last),
+//   nkq  = ceil(K / 4) input quads,
+// and weight register (nb, kq) of the layer -- LDS image entry [(wreg0 + nb * nkq + kq) * 64 + lane] -- holds, in lane 4a + i with
+// a = 4 kk + q:  W[neuron 16 nb + 4 q + i][input 4 kq + kk]   (zero outside the layer or on a masked input column).
+// MFMA a of the register multiplies input 4 kq + kk into neuron group 4 nb + q; per output the accumulation order is bias, then
+// the inputs ascending: the oracle's natural order, and bit for bit the v50 kernel's for feature_nn.
+#pragma once
+#include <stdint.h>
+
+#include "bnn_layout.h"
+
+namespace bnn {
+
+constexpr int GEN_MAX_LAYERS = 16;   // Linear modules of feature_nn and regress_nn together
+constexpr int GEN_MAX_WIDTH = 128;   // hidden, latent and summary width (2 latent + 2) supported by the register buckets
+
+struct GenLayer {
+    int32_t K, N;         // inputs, outputs of the Linear module
+    int32_t nkq, nblk;    // input quads, output blocks of 16 neurons
+    int32_t ng_last;      // neuron groups (of 4) in the last block: 1..4
+    int32_t off_w, off_b; // offsets of weight [N,K] and bias [N] in the flat parameter vector
+    int32_t wreg0;        // first weight register of the layer in the LDS image (regress_nn layers kept out of LDS: -1)
+    int32_t bias0;        // first float of the layer's bias image (16 * nblk floats, zero padded)
+    int32_t relu;         // nn.ReLU behind it (every Linear of an mlp() but the last)
+};
+
+// Chan merge of two Welford partitions with counts (na, nb) (oracle/bnn_oracle.c merge_consts): mode 0 = equal counts, symmetric
+// form, w1 = na / 2; 1 = general form, w1 = nb / n, w2 = na nb / n (float64 quotients rounded once); 2 = keep a; 3 = keep b.
+struct GenMerge {
+    int32_t mode;
+    float w1, w2;
+};
+
+struct GenArch {
+    int32_t F, H, L, SM, d;       // features, hidden, latent, summary width (2L, +2 with fix_megno), parameter count
+    int32_t megno;
+    int32_t n_feat, n_reg;        // Linear modules of feature_nn / regress_nn: layer[0 .. n_feat) / layer[n_feat .. n_feat + n_reg)
+    int32_t nwreg, nbias;         // LDS image sizes: (nwreg + 1) * 64 floats of weight registers, nbias floats of biases
+    int32_t fq, hq;               // register buckets the kernel was instantiated for: input quads (11 | 21), activation quads
+    int32_t lq, smq;              // latent groups ceil(L / 4), summary quads ceil(SM / 4)
+    int32_t nin_blocks;           // Philox blocks of six normals per row of input noise: ceil(F / 6)
+    int32_t reg_in_lds;           // 1: regress_nn's weight registers are in the LDS image too; 0: gathered from the flat vector
+    int32_t nwaves;               // waves per workgroup (4, 2 or 1) that the LDS budget allows
+    int32_t lds_bytes;            // dynamic LDS of the launch
+    int32_t off_inlv, off_sumlv;  // input_noise_logvar [F], summary_noise_logvar [SM]
+    GenLayer layer[GEN_MAX_LAYERS];
+};
+
+// Host: build the descriptor.  Returns 0, or a negative code with *why set (unsupported width / depth, LDS budget).
+//   depth_in / depth_out = hparams['in'] / hparams['out'] (the `layers` argument of mlp()).
+int gen_build(int n_features, int hidden, int latent, int depth_in, int depth_out, bool megno, GenArch* out, const char** why);
+
+// Per-wave LDS floats: pool state (mean, M2 per latent group, lane-major), Philox scratch, summaries, MEGNO partitions, and -- when
+// regress_nn's registers are not in the image -- a staging area for one block of them.
+BNN_HD inline int gen_eps_stride(const GenArch& g) { return 4 * ((2 * g.L + 3) / 4); }
+BNN_HD inline int gen_sum_stride(const GenArch& g) { return 4 * g.smq; }
+BNN_HD inline int gen_wave_floats(const GenArch& g) {
+    return 2 * g.lq * 256 + 16 * gen_eps_stride(g) + 16 * gen_sum_stride(g) + 128 + (g.reg_in_lds ? 0 : g.hq * 64);
+}
+// Workgroup-shared LDS floats: weight registers (+ one pad register for the read-ahead), biases, noise scales.
+BNN_HD inline int gen_wimg_floats(const GenArch& g) { return (g.nwreg + 1) * 64; }
+BNN_HD inline int gen_nsc_floats(const GenArch& g) { return 4 * ((g.F + 3) / 4) + 4 * ((g.SM + 3) / 4) + 8 * g.nin_blocks * 2; }
+BNN_HD inline int gen_shared_floats(const GenArch& g) { return gen_wimg_floats(g) + g.nbias + gen_nsc_floats(g); }
+
+}  // namespace bnn

@@ -1,0 +1,478 @@
+// bnn_generic.hip.h -- the GENERIC forward engine: VarModel.forward / forward_swag_fast for the network the
+// reference builds from hparams (spock_reg_model.py:301-321, 346-362: any hidden / latent up to 128, depth `in` / `out`, 41 or 82
+// features, fix_megno), any series length T >= 2 (:416-435), quiet or noisy (:444-450), optionally with the statistics tail.
+// The pretrained ensemble's 41->40->40->20 / 40->40->40->2 network at T % 4 == 0 keeps its own kernel (bnn_forward.hip.h, weights
+// register-resident); everything else the reference accepts runs here.
+//
+// Same decomposition as that kernel -- lane = row (lane l = system l >> 2 of the wave's 16, timestep 4 it + (l & 3)),
+// v_mfma_f32_4x4x1_16b_f32 with the CBSZ/ABID broadcast, activations in registers from layer to layer, per-lane Welford over the
+// lane's timesteps -- with the shapes taken from a descriptor (bnn_generic.h) instead of template constants:
+//   * weight registers are streamed from an LDS image: one ds_read_b32 feeds 16 MFMAs (4 inputs x 4 neuron groups); a block's
+//     registers are all requested up front, so the reads of a block are in flight together;
+//   * a layer is a run-time loop over output blocks of 16 neurons; inside, the input quads are a compile-time loop with an early
+//     exit (register arrays need compile-time indices), sized by the template bucket HQ = activation quads (48 / 64 / 96 / 128 wide);
+//   * the pool state (mean, M2 per latent and lane) lives in LDS, so the latent width is a run-time number; lanes whose timestep
+//     lies past T skip the update, and the four partitions (t & 3) are merged with their own counts (equal counts: the
+//     symmetric form, i.e. the v50 kernel's bits; unequal: Chan's general form; constants from the host, as in the oracle);
+//   * regress_nn runs through the same layer routine with lane = system (the four lanes of a quad repeat the work: 3 280 of
+//     407 280 MACs for the v50 shapes), its weight registers from the LDS image when they fit, else gathered from the flat vector.
+// Accumulation order per output: bias, then inputs ascending -- the oracle's natural order for every layer.
+#pragma once
+#include "bnn_common.hip.h"
+#include "bnn_generic.h"
+#include "bnn_stats.hip.h"
+
+namespace bnn {
+
+template <int FQ>
+DEVINL void gen_load_row(const float* __restrict__ rp, f32x4 (&xr)[FQ]) {
+    static_assert(FQ == 11 || FQ == 21, "41 or 82 features");
+    constexpr int NFULL = FQ - 1;
+#pragma unroll
+    for (int q = 0; q < NFULL; ++q) xr[q] = *reinterpret_cast<const f32x4u*>(rp + 4 * q);
+    if constexpr (FQ == 11) {
+        xr[10] = (f32x4){rp[40], 0.0f, 0.0f, 0.0f};
+    } else {
+        const f32x2 t = *reinterpret_cast<const f32x2u*>(rp + 80);
+        xr[20] = (f32x4){t.x, t.y, 0.0f, 0.0f};
+    }
+}
+
+// 4 kk x NG MFMAs per input quad: input 4 kq + kk into neuron group q of the block (bias first, then inputs ascending).
+// The block's weight registers are requested a chunk of up to 16 at a time (one ds_read_b32 each, all of a chunk in flight
+// together) -- 16 rather than all NQI so that the widest bucket keeps 16 registers free.
+template <int NG, int NQI>
+DEVINL void gen_block(f32x4 (&acc)[4], const float* wp, const f32x4 (&in)[NQI], int nkq) {
+    constexpr int CH = NQI < 16 ? NQI : 16;
+    static_while<(NQI + CH - 1) / CH>([&](auto C) {
+        constexpr int k0 = C * CH;
+        if (k0 >= nkq) return false;
+        float wv[CH];
+        static_while<CH>([&](auto J) {
+            constexpr int kq = k0 + J;
+            if (kq >= NQI || kq >= nkq) return false;
+            wv[J] = wp[kq * 64];
+            return true;
+        });
+        static_while<CH>([&](auto J) {
+            constexpr int kq = k0 + J;
+            if (kq >= NQI || kq >= nkq) return false;
+            static_for<16>([&](auto A) {
+                constexpr int a = A, kk = a >> 2, q = a & 3;
+                if constexpr (q < NG) acc[q] = mfma4b<a>(wv[J], in[kq < NQI ? kq : 0][kk], acc[q]);
+            });
+            return true;
+        });
+        return true;
+    });
+}
+
+// nn.ReLU (lim = 0) or identity (lim = INT_MIN) as one integer max on the bit pattern.  The element goes through a scalar
+// parameter first: __builtin_bit_cast applied to a vector element directly reads element 0 (hipcc 7.2; bnn_forward.hip.h has the
+// same note) -- the first version of this routine replicated neuron 4g of every group.
+DEVINL float relu_lim1(float v, int lim) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > lim ? b : lim);
+}
+DEVINL f32x4 relu_lim4(f32x4 v, int lim) {
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = relu_lim1(v[i], lim);
+    return o;
+}
+
+// One Linear (+ ReLU) for the wave's 64 rows; weight register (nb, kq) = LDS image entry [(wreg0 + nb * nkq + kq) * 64 + lane].
+// TRIM: the last block issues only its live neuron groups (feature_nn: the hot loop); without it the padded groups are multiplied
+// by zero weights (regress_nn: once per 16 systems).
+DEVINL void gen_stage_block(const GenLayer ly, int nb, const float* __restrict__ We, float* stage, int lane);
+template <int NQI, int NQO, bool TRIM, bool STAGED = false>
+DEVINL void gen_layer(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLayer ly, const float* wimg, const float* bimg, int lane,
+                      const float* __restrict__ We = nullptr, float* stage = nullptr) {
+    const int nkq = ly.nkq, nblk = ly.nblk;
+    const int lim = ly.relu ? 0 : (int)0x80000000;
+    for (int nb = 0; nb < nblk; ++nb) {
+        const float* wp = wimg + (size_t)(ly.wreg0 + nb * nkq) * 64 + lane;
+        if constexpr (STAGED) {
+            if (ly.wreg0 < 0) {   // not in the LDS image: this block's registers come through the wave's staging area
+                __builtin_amdgcn_wave_barrier();
+                gen_stage_block(ly, nb, We, stage, lane);
+                __builtin_amdgcn_wave_barrier();
+                wp = stage + lane;
+            }
+        }
+        f32x4 acc[4];
+        const f32x4* bq = reinterpret_cast<const f32x4*>(bimg + ly.bias0 + 16 * nb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = bq[q];
+        const int ng = (TRIM && nb == nblk - 1) ? ly.ng_last : 4;
+        if (ng == 4) gen_block<4>(acc, wp, in, nkq);
+        else if (ng == 3) gen_block<3>(acc, wp, in, nkq);
+        else if (ng == 2) gen_block<2>(acc, wp, in, nkq);
+        else gen_block<1>(acc, wp, in, nkq);
+        static_for<NQO / 4>([&](auto NB) {
+            constexpr int b = NB;
+            if (nb == b) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out[4 * b + q] = relu_lim4(acc[q], lim);
+            }
+        });
+    }
+}
+
+// A regress_nn layer whose registers did not fit the LDS image: block nb's registers are gathered from the flat vector (L2) into the
+// wave's staging area, eight loads in flight, and the layer routine above then runs one block at a time from there.
+DEVINL void gen_stage_block(const GenLayer ly, int nb, const float* __restrict__ We, float* stage, int lane) {
+    const int a_ = lane >> 2, kk = a_ >> 2, q = a_ & 3, i = lane & 3;
+    const int neuron = 16 * nb + 4 * q + i;
+    const bool nlive = neuron < ly.N;
+    const float* wrow = We + ly.off_w + (int64_t)(nlive ? neuron : 0) * ly.K;
+#pragma unroll 8
+    for (int kq = 0; kq < ly.nkq; ++kq) {
+        const int k = 4 * kq + kk;
+        const bool live = nlive && k < ly.K;
+        const float v = wrow[live ? k : 0];
+        stage[kq * 64 + lane] = live ? v : 0.0f;
+    }
+}
+
+DEVINL void gen_merge(const GenMerge mg, float& ma, float& qa, float mb, float qb) {
+    if (mg.mode == 2) return;
+    if (mg.mode == 3) { ma = mb; qa = qb; return; }
+    const float dl = mb - ma;
+    if (mg.mode == 0) {
+        const float mm = (ma + mb) * 0.5f;
+        qa = (qa + qb) + (dl * dl) * mg.w1;
+        ma = mm;
+    } else {
+        const float mm = fmaf(dl, mg.w1, ma);
+        qa = (qa + qb) + (dl * dl) * mg.w2;
+        ma = mm;
+    }
+}
+
+template <int FQ, int HQ>
+__global__ __launch_bounds__(256, 1) void bnn_forward_generic_kernel(const GenParams P) {
+    const FwdParams& p = P.f;
+    const GenArch& G = *P.g;
+    constexpr int NBLK_IN = FQ == 11 ? 7 : 14;   // Philox blocks of six normals per input row (41 / 82 columns)
+    constexpr int FCOLS = FQ == 11 ? 41 : 82;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wimg = lds;
+    float* bimg = wimg + gen_wimg_floats(G);
+    float* nsc = bimg + G.nbias;   // exp(input_noise_logvar / 2) [4 * fq] | exp(summary_noise_logvar / 2) [4 * smq] | per noise block [8] scales | [8] keep-masks
+    float* nsc_sum = nsc + 4 * FQ;
+    float* nsc_blk = nsc_sum + 4 * G.smq;
+    float* wave0 = nsc + gen_nsc_floats(G);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int sl0 = lane >> 2, ph0 = lane & 3;
+    const int F = G.F, L = G.L, SM = G.SM, lq = G.lq, smq = G.smq;
+
+    const WorkItem wi = work_item(p);
+    const int e = wi.e;
+    const int64_t sub = wi.sub;
+    const int ch = e % p.nch;
+    const int64_t r = e / p.nch;  // output row
+    const int64_t seg0 = (int64_t)ch * p.csz;
+    const int64_t seg1 = (seg0 + p.csz < p.B) ? seg0 + p.csz : p.B;
+    const int64_t b0 = seg0 + sub * p.spc;
+    const int64_t b1 = (b0 + p.spc < seg1) ? b0 + p.spc : seg1;
+    if (b0 >= b1) return;
+
+    // ---- prologue: the draw's flat parameter vector (global) -> weight-register image, bias image, noise scales (LDS)
+    const float* __restrict__ We = p.W + (int64_t)e * G.d;
+    const int nl = G.n_feat + G.n_reg;
+    {
+        const int a_ = lane >> 2, kk = a_ >> 2, q = a_ & 3, i = lane & 3;
+#pragma unroll 4
+        for (int R = wave; R < G.nwreg; R += nwaves) {
+            int li = 0;
+            for (int l = 1; l < nl; ++l)
+                if (G.layer[l].wreg0 >= 0 && R >= G.layer[l].wreg0) li = l;
+            const GenLayer ly = G.layer[li];
+            const int rr = R - ly.wreg0, nb = rr / ly.nkq, kq = rr - nb * ly.nkq;
+            const int neuron = 16 * nb + 4 * q + i, k = 4 * kq + kk;
+            // zero_megno / zero_mmr / zero_nan / zero_eplusminus (:452-500) as zero weights on the masked input columns; the noisy
+            // forward keeps them (masked columns carry pure noise)
+            const bool masked = li == 0 && !P.noisy && k < 64 && ((p.zero_mask >> k) & 1ull);
+            const bool live = neuron < ly.N && k < ly.K && !masked;
+            const float v = We[live ? ly.off_w + neuron * ly.K + k : 0];
+            wimg[R * 64 + lane] = live ? v : 0.0f;
+        }
+        if (wave == 0) wimg[G.nwreg * 64 + lane] = 0.0f;
+        for (int j = tid; j < G.nbias; j += blockDim.x) {
+            int li = 0;
+            for (int l = 1; l < nl; ++l)
+                if (j >= G.layer[l].bias0) li = l;
+            const int n = j - G.layer[li].bias0;
+            bimg[j] = n < G.layer[li].N ? We[G.layer[li].off_b + n] : 0.0f;
+        }
+        if (P.noisy) {   // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
+            for (int j = tid; j < 4 * FQ; j += blockDim.x) nsc[j] = j < F ? expf(We[G.off_inlv + j] / 2.0f) : 0.0f;
+            for (int j = tid; j < 4 * smq; j += blockDim.x) nsc_sum[j] = j < SM ? expf(We[G.off_sumlv + j] / 2.0f) : 0.0f;
+            for (int j = tid; j < 8 * NBLK_IN; j += blockDim.x) {   // the input scales per noise block, and keep-masks of the unmasked columns
+                const int col = NIN_PER_BLOCK * (j >> 3) + (j & 7);
+                const bool live = (j & 7) < NIN_PER_BLOCK && col < F;
+                nsc_blk[j] = live ? expf(We[G.off_inlv + col] / 2.0f) : 0.0f;
+                nsc_blk[8 * NBLK_IN + j] = __builtin_bit_cast(float, (live && !(col < 64 && ((p.zero_mask >> col) & 1ull))) ? 0xFFFFFFFFu : 0u);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int T = p.T, ntiles = p.ntiles;
+    const float nm1 = (float)(T - 1), nT = (float)T;
+    const int64_t rowstride = (int64_t)T * F;
+    const int EPS = gen_eps_stride(G), SMS = gen_sum_stride(G);
+    float* poolm = wave0 + (size_t)wave * gen_wave_floats(G);   // [lq][64 lanes][4] running means
+    float* poolq = poolm + lq * 256;                            // [lq][64][4] running M2
+    float* epsscr = poolq + lq * 256;                           // [16 systems][EPS] pool normals
+    float* sumscr = epsscr + 16 * EPS;                          // [16][SMS] summaries
+    float* megscr = sumscr + 16 * SMS;                          // [64 lanes][2] MEGNO partitions
+    float* stage = megscr + 128;                                // [hq][64] weight registers of one block (regress_nn layers outside the image)
+    f32x4* poolm4 = reinterpret_cast<f32x4*>(poolm);
+    f32x4* poolq4 = reinterpret_cast<f32x4*>(poolq);
+
+    for (int64_t wb0 = b0 + (int64_t)wave * 16; wb0 < b1; wb0 += (int64_t)nwaves * 16) {
+        const int64_t sys0 = wb0 + sl0;
+        const bool valid0 = sys0 < b1;
+        const int64_t sysc0 = valid0 ? sys0 : b1 - 1;
+        const float* sysp = p.x + sysc0 * rowstride;
+        for (int g = 0; g < lq; ++g) {
+            poolm4[g * 64 + lane] = (f32x4){0, 0, 0, 0};
+            poolq4[g * 64 + lane] = (f32x4){0, 0, 0, 0};
+        }
+        float gmean = 0.0f, gm2 = 0.0f;
+        // XPREF: the next tile's rows are fetched right behind layer 1 of the current one (a tile of work to land).  The widest
+        // bucket has no registers to hold them across the other layers (two 128-register activation arrays): it loads at the top of
+        // the tile and waits (about 1 us of a tile of 20 us or more at those widths).
+        constexpr bool XPREF = HQ < 32;
+        f32x4 xr[FQ];
+        if constexpr (XPREF) {
+            gen_load_row<FQ>(sysp + (int64_t)(ph0 < T ? ph0 : T - 1) * F, xr);
+            asm volatile("" ::: "memory");
+        }
+        f32x4 a[HQ], b[HQ];
+        // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps, state in LDS
+        auto pool = [&](const f32x4 (&y)[HQ], float rcn) {
+            static_while<HQ>([&](auto GI) {
+                constexpr int g = GI;
+                if (g >= lq) return false;
+                f32x4 mean = poolm4[g * 64 + lane], m2 = poolq4[g * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float dl = y[g][i] - mean[i];
+                    const float mn = fmaf(dl, rcn, mean[i]);
+                    m2[i] = fmaf(dl, y[g][i] - mn, m2[i]);
+                    mean[i] = mn;
+                }
+                poolm4[g * 64 + lane] = mean;
+                poolq4[g * 64 + lane] = m2;
+                return true;
+            });
+        };
+
+        for (int it = 0; it < ntiles; ++it) {
+            const int t = 4 * it + ph0;
+            const bool tv = t < T;
+            const int tc = tv ? t : T - 1;
+            const float rcn = p.rcp_tab[it];
+            if constexpr (!XPREF) gen_load_row<FQ>(sysp + (int64_t)tc * F, xr);
+            if (G.megno && tv) {   // summarize_megno (:480-484): the RAW column, before the masks and before any noise
+                const float xm = xr[MEGNO_COL >> 2][MEGNO_COL & 3];
+                const float dl = xm - gmean;
+                const float mn = fmaf(dl, rcn, gmean);
+                gm2 = fmaf(dl, xm - mn, gm2);
+                gmean = mn;
+            }
+            if (P.noisy) {   // masks, then add_input_noise (:486-506): masked columns become pure noise
+                const float* er = p.eps_in ? p.eps_in + ((r * p.B + sysc0) * T + tc) * (int64_t)F : nullptr;
+                static_for<NBLK_IN>([&](auto BLK) {
+                    constexpr int blk = BLK;
+                    float n6[6];
+                    if (er) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) n6[j] = (6 * blk + j < F) ? er[6 * blk + j] : 0.0f;
+                    } else {
+                        philox_in6(p.row_id0 + r, p.sys_id0 + sysc0, tc * NBLK_IN + blk, p.seed, n6);
+                    }
+                    const f32x4* nb4 = reinterpret_cast<const f32x4*>(nsc_blk + 8 * blk);
+                    const f32x4 s0 = nb4[0], s1 = nb4[1], k0 = nb4[2 * NBLK_IN], k1 = nb4[2 * NBLK_IN + 1];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const int col = 6 * blk + j;
+                        if (col < FCOLS) {
+                            const float sc = j < 4 ? s0[j] : s1[j - 4], kp = j < 4 ? k0[j] : k1[j - 4];
+                            const float xv = xr[col >> 2][col & 3];   // (through scalars: see relu_lim1)
+                            const float xm = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, xv) & __builtin_bit_cast(uint32_t, kp));
+                            const float nz = n6[j] * sc;          // randn * exp(logvar / 2): a multiply ...
+                            xr[col >> 2][col & 3] = xm + nz;      // ... then an add (:445)
+                        }
+                    }
+                });
+            }
+            gen_layer<FQ, HQ, true>(xr, a, G.layer[0], wimg, bimg, lane);
+            // x of this tile is dead: fetch the next tile's rows into the same registers
+            if constexpr (XPREF) {
+                const int tn = 4 * (it + 1) + ph0;
+                gen_load_row<FQ>(sysp + (int64_t)(tn < T ? tn : T - 1) * F, xr);
+                asm volatile("" ::: "memory");
+            }
+            // the remaining Linear modules of feature_nn, ping-pong between the two register arrays
+            int l = 1;
+            for (; l + 1 < G.n_feat; l += 2) {
+                gen_layer<HQ, HQ, true>(a, b, G.layer[l], wimg, bimg, lane);
+                gen_layer<HQ, HQ, true>(b, a, G.layer[l + 1], wimg, bimg, lane);
+            }
+            if (l < G.n_feat) {
+                gen_layer<HQ, HQ, true>(a, b, G.layer[l], wimg, bimg, lane);
+                if (tv) pool(b, rcn);   // lanes past T sit the tile out
+            } else if (tv) {
+                pool(a, rcn);
+            }
+        }
+
+        // ---- tail: merge the four partitions of every latent, sampled moments (compute_summary_stats :420-431)
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        const int sl = lane_t >> 2, ph = lane_t & 3;
+        const int64_t sys = wb0 + sl;
+        const bool valid = sys < b1;
+        const int64_t sysc = valid ? sys : b1 - 1;
+        const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + sysc;
+        if (G.megno) { megscr[lane_t * 2] = gmean; megscr[lane_t * 2 + 1] = gm2; }
+        if (!p.eps) {   // the system's 2 L pool normals: Philox blocks ph, ph + 4, ... of the quad's four lanes
+            for (int qd = ph; 4 * qd < EPS; qd += 4) *reinterpret_cast<f32x4*>(epsscr + sl * EPS + 4 * qd) = philox_eps4(grow, gsys, qd, p.seed);
+        }
+        __builtin_amdgcn_wave_barrier();   // the pool state and the normals written above are read across lanes below (one wave's LDS
+                                           // operations complete in order: no wait is needed, only the compiler must not reorder)
+        for (int n = ph; n < L; n += 4) {
+            const int g = n >> 2, c = n & 3;
+            float m[4], q2[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int idx = (g * 64 + 4 * sl + pp) * 4 + c;
+                m[pp] = poolm[idx];
+                q2[pp] = poolq[idx];
+            }
+            gen_merge(P.m01, m[0], q2[0], m[1], q2[1]);
+            gen_merge(P.m23, m[2], q2[2], m[3], q2[3]);
+            gen_merge(P.m0123, m[0], q2[0], m[2], q2[2]);
+            float e1, e2;
+            if (p.eps) {
+                const float* ep = p.eps + (r * p.B + sysc) * 2 * L;
+                e1 = ep[n];
+                e2 = ep[L + n];
+            } else {
+                e1 = epsscr[sl * EPS + n];
+                e2 = epsscr[sl * EPS + L + n];
+            }
+            const float sample_mu = m[0];
+            const float sd = sqrtf(q2[0] / nm1);   // torch.std (unbiased)
+            const float sample_var = sd * sd;      // **2
+            const float std_in_mu = sqrtf(sample_var / nT);
+            const float std_in_var = sqrtf((2.0f * (sample_var * sample_var)) / nm1);
+            const float mu_s = e1 * std_in_mu + sample_mu;
+            const float var_s = e2 * std_in_var + sample_var;
+            const float sd_s = sqrtf(fabsf(var_s) + 1e-5f);  // EPSILON (:337)
+            sumscr[sl * SMS + n] = mu_s;
+            sumscr[sl * SMS + L + n] = sd_s;
+            if (p.summary && valid) {
+                float* sp = p.summary + (r * p.B + sys) * SM;
+                sp[n] = mu_s;
+                sp[L + n] = sd_s;
+            }
+        }
+        if (ph == 0) {
+            if (G.megno) {   // torch.cat([summary_stats, megno_avg_std]) (:509-510): mean and unbiased std of the raw column
+                float m[4], q2[4];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) { m[pp] = megscr[(4 * sl + pp) * 2]; q2[pp] = megscr[(4 * sl + pp) * 2 + 1]; }
+                gen_merge(P.m01, m[0], q2[0], m[1], q2[1]);
+                gen_merge(P.m23, m[2], q2[2], m[3], q2[3]);
+                gen_merge(P.m0123, m[0], q2[0], m[2], q2[2]);
+                const float gstd = sqrtf(q2[0] / nm1);
+                sumscr[sl * SMS + 2 * L] = m[0];
+                sumscr[sl * SMS + 2 * L + 1] = gstd;
+                if (p.summary && valid) {
+                    float* sp = p.summary + (r * p.B + sys) * SM + 2 * L;
+                    sp[0] = m[0];
+                    sp[1] = gstd;
+                }
+            }
+            for (int n = SM; n < SMS; ++n) sumscr[sl * SMS + n] = 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (P.noisy) {   // add_summary_noise (:448-450), on the LDS copy: lane ph takes summary quads ph, ph + 4, ...
+            const float* es = p.eps_sum ? p.eps_sum + (r * p.B + sysc) * SM : nullptr;
+            for (int kq = ph; kq < smq; kq += 4) {
+                f32x4 nz;
+                if (es) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nz[j] = (4 * kq + j < SM) ? es[4 * kq + j] : 0.0f;
+                } else {
+                    nz = philox_sys4(TAG_SUM, grow, gsys, kq, p.seed);
+                }
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(nsc_sum + 4 * kq);
+                f32x4 sv = *reinterpret_cast<const f32x4*>(sumscr + sl * SMS + 4 * kq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t2 = nz[j] * sc[j];
+                    sv[j] = sv[j] + t2;
+                }
+                *reinterpret_cast<f32x4*>(sumscr + sl * SMS + 4 * kq) = sv;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- regress_nn + soft_clamp (predict_instability :437-442): lane = system (the quad's four lanes repeat the work)
+        static_while<HQ>([&](auto KQ) {
+            constexpr int kq = KQ;
+            if (kq >= smq) return false;
+            a[kq] = *reinterpret_cast<const f32x4*>(sumscr + sl * SMS + 4 * kq);
+            return true;
+        });
+        float r0, r1;
+        {
+            int l = G.n_feat;
+            for (; l + 1 < nl; l += 2) {
+                gen_layer<HQ, HQ, false, true>(a, b, G.layer[l], wimg, bimg, lane, We, stage);
+                gen_layer<HQ, HQ, false, true>(b, a, G.layer[l + 1], wimg, bimg, lane, We, stage);
+            }
+            if (l < nl) {
+                gen_layer<HQ, HQ, false, true>(a, b, G.layer[l], wimg, bimg, lane, We, stage);
+                r0 = b[0][0]; r1 = b[0][1];
+            } else {
+                r0 = a[0][0]; r1 = a[0][1];
+            }
+        }
+        if (ph == 0 && valid) {
+            const f32x2 ms = soft_clamp2(r0, r1, p.std_lo, p.std_span);
+            if (p.sink) {
+                p.sink[r * p.B + sys] = stats_draw(p.st, ms.x, ms.y, grow, p.sys_id0 + sys, p.seed);
+            } else {
+                const int64_t o = (r * p.B + sys) * 2;
+                *reinterpret_cast<f32x2*>(p.out + o) = ms;
+                if (p.pre_clamp) *reinterpret_cast<f32x2*>(p.pre_clamp + o) = (f32x2){r0, r1};
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // scratch is reused by the next wave-batch
+    }
+}
+
+template <int FQ, int HQ>
+inline hipError_t launch_generic_form(unsigned nblk, hipStream_t st, const GenParams& P, int nwaves, size_t lds_bytes) {
+    static bool attr_set[MAX_DEVICES];  // the attribute belongs to the (function, device) pair
+    const int slot = current_device_slot();
+    if (!attr_set[slot]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_generic_kernel<FQ, HQ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set[slot] = true;
+    }
+    hipLaunchKernelGGL((bnn_forward_generic_kernel<FQ, HQ>), dim3(nblk), dim3(64 * nwaves), lds_bytes, st, P);
+    return hipGetLastError();
+}
+
+}  // namespace bnn

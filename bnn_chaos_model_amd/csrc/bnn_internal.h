@@ -5,13 +5,16 @@
 //   bnn_fwd_k41.hip     forward kernel, all 41 columns (any other mask), quiet           (workspace + in-prologue draw)
 //   bnn_fwd_noisy.hip   forward kernel, forward(noisy_val=True)
 //   bnn_fwd_megno.hip   forward kernel forms for hparams['fix_megno'] = True (42-wide summary, d = 7665)
-//   bnn_fwd_bf16.hip    reduced-precision forward kernels (bf16 matrix pipe; opt-in, configs[4])
-//   bnn_small.hip       SWAG draw, moments, regress_nn, statistics epilogue, feature packing, Philox fills
-//   bnn_abi.hip         extern "C" entry points of include/bnn_chaos_hip.h
+//   bnn_fwd_lowp.hip    reduced-precision forward kernels (bf16 / half matrix pipe; opt-in, configs[4])
+//   bnn_fwd_generic.hip generic forward engine: the network built from hparams (any hidden / latent / depth, 41 | 82 features), any T
+//   bnn_generic.cpp     host: descriptor of that engine (layers, LDS image, register bucket)
+//   bnn_abi.hip         extern "C" entry points of include/bnn_chaos_hip.h + the small kernels (SWAG draw, moments, regress_nn,
+//                       statistics epilogue, feature packing, Philox fills)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bnn_generic.h"
 #include "bnn_layout.h"
 
 namespace bnn {
@@ -61,6 +64,14 @@ struct FwdParams {
     StatsParams st;
 };
 
+// generic forward engine (bnn_generic.hip.h): the common block + the descriptor (device copy owned by the plan) + pool merges
+struct GenParams {
+    FwdParams f;
+    const GenArch* g;
+    GenMerge m01, m23, m0123;   // partitions (0,1), (2,3), then the halves; counts from T
+    int32_t noisy;              // forward(noisy_val=True): input + summary noise, masked columns keep their weights
+};
+
 constexpr int RCP_N = 4096;  // supports T up to 16384 timesteps
 
 // Each returns hipGetLastError() after the launch.  grid = (draw, block-of-systems) pairs, 256 threads.
@@ -70,6 +81,8 @@ hipError_t launch_fwd_noisy(unsigned nblk, hipStream_t st, const FwdParams& p);
 hipError_t launch_fwd_stats(bool k31, unsigned nblk, hipStream_t st, const FwdParams& p);  // quiet forward + fused statistics tail
 hipError_t launch_fwd_lowp(int precision, unsigned nblk, hipStream_t st, const FwdParams& p);  // bf16 / half matrix pipe (bnn_precision)
 hipError_t launch_fwd_megno(bool k31, bool fused, bool noisy, unsigned nblk, hipStream_t st, const FwdParams& p);  // hparams['fix_megno'] layout
+
+hipError_t launch_fwd_generic(const GenArch& g, unsigned nblk, hipStream_t st, const GenParams& P);  // any hparams network, any T >= 2
 
 constexpr int MAX_DEVICES = 64;
 inline int current_device_slot() {

@@ -48,14 +48,29 @@ def zero_mask_from_flags(fix_megno=False, fix_megno2=True, include_mmr=False, in
     return sum(1 << c for c in set(cols))
 
 
-def get_plan(zero_mask=V50_ZERO_MASK, lowest_std=0.5, device=None, fix_megno=False):
-    """fix_megno: hparams['fix_megno'] (spock_reg_model.py:360-362): 42-wide summary, d = 7665; the mask must zero column 7."""
+def get_plan(zero_mask=V50_ZERO_MASK, lowest_std=0.5, device=None, fix_megno=False, n_features=41, hidden=40, latent=20,
+             depth_in=1, depth_out=1):
+    """One plan per (device, network, column mask).  n_features / hidden / latent / depth_in / depth_out describe the network the
+    reference builds from hparams (spock_reg_model.py:301-321, 346-362; depth = hparams['in'] / ['out']); the defaults are the
+    pretrained ensemble's.  fix_megno: hparams['fix_megno'] (:360-362): summary two wider; the mask must zero column 7."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    key = (dev, int(zero_mask), float(lowest_std), bool(fix_megno))
+    key = (dev, int(zero_mask), float(lowest_std), bool(fix_megno), int(n_features), int(hidden), int(latent), int(depth_in), int(depth_out))
     if key not in _plans:
         with torch.cuda.device(dev):
-            _plans[key] = N.Plan(int(zero_mask), float(lowest_std), fix_megno=fix_megno)
+            _plans[key] = N.Plan(int(zero_mask), float(lowest_std), n_features=n_features, hidden=hidden, latent=latent,
+                                 fix_megno=fix_megno, depth_in=depth_in, depth_out=depth_out)
     return _plans[key]
+
+
+def _check_x(x, plan):
+    if x.dim() != 3 or x.shape[2] != plan.n_features:
+        raise NotImplementedError(f"x must be [B, T, {plan.n_features}]")  # figures/spock/regression.py:210-211
+    return x
+
+
+def fused_draw_available(plan, T, K):
+    """The in-prologue draw (one launch, no workspace) exists in the pretrained network's kernels only: T % 4 == 0, T >= 8, K <= 32."""
+    return plan.v50net and T % 4 == 0 and T >= 8 and K <= 32
 
 
 def _f32(t, name):
@@ -66,8 +81,11 @@ def _f32(t, name):
     return t.contiguous()
 
 
-def _grid(B, T, J, nchunks, spb, noisy=False):
-    return N.BnnGrid(int(B), int(T), int(J), int(nchunks), int(spb), int(bool(noisy)), 0)
+ENGINES = {"auto": 0, "generic": 1}
+
+
+def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto"):
+    return N.BnnGrid(int(B), int(T), int(J), int(nchunks), int(spb), int(bool(noisy)), ENGINES[engine])
 
 
 @_on_device_of(0)
@@ -108,7 +126,7 @@ def half_range_exceeded(x, zero_mask=V50_ZERO_MASK):
 
 @_on_device_of(0)
 def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0, draw_id0=0, system_id0=0, plan=None,
-            debug=False, systems_per_block=0, noisy=False, precision="f32"):
+            debug=False, systems_per_block=0, noisy=False, precision="f32", engine="auto"):
     """VarModel.forward (spock_reg_model.py:486-528) for materialised weight vectors W[J,d] -> out[J/nchunks,B,2].
 
     eps [R,B,2,20] = the two randn_like of compute_summary_stats (:426-427) or None (Philox);
@@ -116,13 +134,15 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     is noisy_val=True with every normal generated in-kernel (Philox).
     precision: "f32" (default: the parity path) or the OPT-IN reduced-precision forms "bf16" / "bf16x3" / "bf16x6" / "f16" /
     "f16x3" (feature_nn on the bf16 / half matrix pipe; BASELINE configs[4] sweep; v50 mask, quiet forward only).
+    engine: "auto" = the pretrained network at T % 4 == 0, T >= 8 runs on its register-resident kernels, every other shape on the
+    generic engine; "generic" forces the generic engine (cross-checks, measurements).
     PRECONDITION of "f16" / "f16x3": |x| < 65 504 in the live columns (half_range_exceeded(x) names the rows that violate it;
     their outputs are finite but wrong).  This op never synchronises, so it does not check; the FeatureRegressor surface does."""
     plan = plan or get_plan()
     x, W = _f32(x, "x"), _f32(W, "W")
-    if x.dim() != 3 or x.shape[2] != 41:
-        raise NotImplementedError("x must be [B, T, 41]")  # figures/spock/regression.py:210-211
-    B, T, _ = x.shape
+    _check_x(x, plan)
+    B, T, NF = x.shape
+    LAT = plan.latent
     if W.dim() != 2 or W.shape[1] != plan.d:
         raise ValueError(f"W must be [J,{plan.d}]")
     J = W.shape[0]
@@ -130,17 +150,17 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     R = J // nchunks
     eps, eps_in, eps_sum = _f32(eps, "eps"), _f32(eps_in, "eps_in"), _f32(eps_sum, "eps_sum")
     _check_same_device(x, W=W, eps=eps, eps_in=eps_in, eps_sum=eps_sum)
-    if eps is not None and tuple(eps.shape) != (R, B, 2, LATENT):
-        raise ValueError(f"eps must be [{R},{B},2,{LATENT}]")
+    if eps is not None and tuple(eps.shape) != (R, B, 2, LAT):
+        raise ValueError(f"eps must be [{R},{B},2,{LAT}]")
     if (eps_in is None) != (eps_sum is None):
         raise ValueError("eps_in and eps_sum must both be given or both be None")
     SM = plan.summary_width
-    if eps_in is not None and (tuple(eps_in.shape) != (R, B, T, 41) or tuple(eps_sum.shape) != (R, B, SM)):
-        raise ValueError(f"eps_in must be [{R},{B},{T},41] and eps_sum [{R},{B},{SM}]")
+    if eps_in is not None and (tuple(eps_in.shape) != (R, B, T, NF) or tuple(eps_sum.shape) != (R, B, SM)):
+        raise ValueError(f"eps_in must be [{R},{B},{T},{NF}] and eps_sum [{R},{B},{SM}]")
     out = torch.empty((R, B, 2), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, SM), dtype=torch.float32, device=x.device) if debug else None
-    g = _grid(B, T, J, nchunks, systems_per_block, noisy)
+    g = _grid(B, T, J, nchunks, systems_per_block, noisy, engine)
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
     if precision != "f32":
@@ -186,7 +206,8 @@ def _workspace(J, d, device):
 
 @_on_device_of(0)
 def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nchunks=1, scale=0.5, philox_seed=0,
-              draw_id0=0, system_id0=0, plan=None, debug=False, systems_per_block=0, out=None, single_launch=None, precision="f32"):
+              draw_id0=0, system_id0=0, plan=None, debug=False, systems_per_block=0, out=None, single_launch=None, precision="f32",
+              engine="auto"):
     """Fused SWAGModel.forward_swag_fast (spock_reg_model.py:878-908) over the MC loop of
     figures/multiswag_5_planet.py:295-298 -> out[J/nchunks, B, 2].
 
@@ -203,8 +224,7 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
             return out
         return res
     x = _f32(x, "x")
-    if x.dim() != 3 or x.shape[2] != 41:
-        raise NotImplementedError("x must be [B, T, 41]")
+    _check_x(x, plan)
     w_avg, w2_avg, pre_D, S, d, K = _ensemble(plan, w_avg, w2_avg, pre_D)
     B, T, _ = x.shape
     seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()
@@ -217,15 +237,19 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
         raise ValueError("z1 and z2 must both be given or both be None")
     if z1 is not None and (tuple(z1.shape) != (J, d) or tuple(z2.shape) != (J, K)):
         raise ValueError("z1 must be [J,d] and z2 [J,K]")
-    if eps is not None and tuple(eps.shape) != (R, B, 2, LATENT):
-        raise ValueError(f"eps must be [{R},{B},2,{LATENT}]")
+    if eps is not None and tuple(eps.shape) != (R, B, 2, plan.latent):
+        raise ValueError(f"eps must be [{R},{B},2,{plan.latent}]")
     if out is None:
         out = torch.empty((R, B, 2), dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != (R, B, 2) or out.dtype != torch.float32 or not out.is_contiguous():
         raise ValueError("out has the wrong shape/dtype")
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, plan.summary_width), dtype=torch.float32, device=x.device) if debug else None
-    g = _grid(B, T, J, nchunks, systems_per_block)
+    g = _grid(B, T, J, nchunks, systems_per_block, engine=engine)
+    if not fused_draw_available(plan, T, K) or engine == "generic":
+        if single_launch:
+            raise NotImplementedError("single_launch (in-prologue draw) exists for the pretrained network at T % 4 == 0, K <= 32 only")
+        single_launch = False
     if single_launch is None:
         single_launch = -(-B // max(nchunks, 1)) <= 256
     ws = None if single_launch else _workspace(J, d, x.device)
@@ -297,14 +321,14 @@ def regress(summary, W, plan=None, debug=False):
     return (out, pre) if debug else out
 
 
-def philox_normal(kind, philox_seed, id0, n_rows, width=0, B=0, system_id0=0, device="cuda"):
-    """The normals the kernels generate in-kernel: kind 0 -> z1[n_rows,width], 1 -> z2[n_rows,width], 2 -> eps[n_rows,B,2,20],
-    3 -> eps_in[n_rows,B,T=width,41], 4 -> eps_sum[n_rows,B,40] (width=42 with fix_megno); statistics epilogue: 5 -> truncated-normal candidates
-    [n_rows,B,nsamp=width], 6 -> survival level of the prior draw [n_rows,B]."""
-    shape = {2: (n_rows, B, 2, LATENT), 3: (n_rows, B, width, 41), 4: (n_rows, B, width or 2 * LATENT), 5: (n_rows, B, width),
+def philox_normal(kind, philox_seed, id0, n_rows, width=0, B=0, system_id0=0, device="cuda", n_features=41):
+    """The normals the kernels generate in-kernel: kind 0 -> z1[n_rows,width], 1 -> z2[n_rows,width], 2 -> eps[n_rows,B,2,latent=width or 20],
+    3 -> eps_in[n_rows,B,T=width,n_features], 4 -> eps_sum[n_rows,B,width or 40] (the summary width: 2 latent, + 2 with fix_megno);
+    statistics epilogue: 5 -> truncated-normal candidates [n_rows,B,nsamp=width], 6 -> survival level of the prior draw [n_rows,B]."""
+    shape = {2: (n_rows, B, 2, width or LATENT), 3: (n_rows, B, width, n_features), 4: (n_rows, B, width or 2 * LATENT), 5: (n_rows, B, width),
              6: (n_rows, B)}.get(kind, (n_rows, width))
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    N.check(N.lib().bnn_philox_normal_f32(kind, int(philox_seed), int(id0), n_rows, B, int(system_id0), width, N.ptr(out),
+    N.check(N.lib().bnn_philox_normal_f32(kind, int(philox_seed), int(id0), n_rows, B, int(system_id0), width, int(n_features), N.ptr(out),
                                           N.stream_ptr()))
     return out
 
@@ -361,8 +385,7 @@ def multiswag_stats(x, w_avg, w2_avg, pre_D, seed_idx, st=None, z1=None, z2=None
     Bit-identical to stats_draw(multiswag(...), row_id0=draw_id0 // nchunks, system_id0=system_id0)."""
     plan = plan or get_plan()
     x = _f32(x, "x")
-    if x.dim() != 3 or x.shape[2] != 41:
-        raise NotImplementedError("x must be [B, T, 41]")
+    _check_x(x, plan)
     w_avg, w2_avg, pre_D, S, d, K = _ensemble(plan, w_avg, w2_avg, pre_D)
     B, T, _ = x.shape
     seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()
@@ -373,8 +396,8 @@ def multiswag_stats(x, w_avg, w2_avg, pre_D, seed_idx, st=None, z1=None, z2=None
     _check_same_device(x, w_avg=w_avg, w2_avg=w2_avg, pre_D=pre_D, z1=z1, z2=z2, eps=eps)
     if (z1 is None) != (z2 is None) or (z1 is not None and (tuple(z1.shape) != (J, d) or tuple(z2.shape) != (J, K))):
         raise ValueError("z1 must be [J,d] and z2 [J,K] (or both None)")
-    if eps is not None and tuple(eps.shape) != (R, B, 2, LATENT):
-        raise ValueError(f"eps must be [{R},{B},2,{LATENT}]")
+    if eps is not None and tuple(eps.shape) != (R, B, 2, plan.latent):
+        raise ValueError(f"eps must be [{R},{B},2,{plan.latent}]")
     st = st or stats_params(device=x.device)
     if out is None:
         out = torch.empty((R, B), dtype=torch.float32, device=x.device)
@@ -450,8 +473,7 @@ class QuantileSketch:
 def _slab_common(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, draws_per_launch, draw_id0, plan):
     plan = plan or get_plan()
     x = _f32(x, "x")
-    if x.dim() != 3 or x.shape[2] != 41:
-        raise NotImplementedError("x must be [B, T, 41]")
+    _check_x(x, plan)
     w_avg, w2_avg, pre_D, S, d, K = _ensemble(plan, w_avg, w2_avg, pre_D)
     _check_same_device(x, w_avg=w_avg, w2_avg=w2_avg, pre_D=pre_D)
     seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()

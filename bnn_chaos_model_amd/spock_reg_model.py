@@ -84,16 +84,25 @@ def mlp(in_n, out_n, hidden, layers):
     return nn.Sequential(*result)
 
 
-def _state_layout(fix_megno=False):
-    """state_dict order and shapes (reference :734-761); with fix_megno the summary is 42 wide (:360-362): d = 7665."""
-    sm = 42 if fix_megno else 40
-    return (("input_noise_logvar", (41,)), ("summary_noise_logvar", (sm,)),
-            ("feature_nn.0.weight", (40, 41)), ("feature_nn.0.bias", (40,)),
-            ("feature_nn.2.weight", (40, 40)), ("feature_nn.2.bias", (40,)),
-            ("feature_nn.4.weight", (20, 40)), ("feature_nn.4.bias", (20,)),
-            ("regress_nn.0.weight", (40, sm)), ("regress_nn.0.bias", (40,)),
-            ("regress_nn.2.weight", (40, 40)), ("regress_nn.2.bias", (40,)),
-            ("regress_nn.4.weight", (2, 40)), ("regress_nn.4.bias", (2,)))
+def _mlp_layout(prefix, in_n, out_n, hidden, layers):
+    """state_dict keys / shapes of mlp(in_n, out_n, hidden, layers) (:301-321): a bare Linear for layers == 0, else a Sequential whose
+    Linear modules sit at the even indices."""
+    if layers == 0:
+        return [(prefix + ".weight", (out_n, in_n)), (prefix + ".bias", (out_n,))]
+    dims = [(in_n, hidden)] + [(hidden, hidden)] * layers + [(hidden, out_n)]
+    out = []
+    for i, (k, n) in enumerate(dims):
+        out += [(f"{prefix}.{2 * i}.weight", (n, k)), (f"{prefix}.{2 * i}.bias", (n,))]
+    return out
+
+
+def _state_layout(fix_megno=False, n_features=41, hidden=40, latent=20, depth_in=1, depth_out=1):
+    """state_dict order and shapes (reference :734-761: own parameters, then feature_nn, then regress_nn) of the network VarModel builds
+    from hparams (:358-362); with fix_megno the summary is two wider."""
+    sm = 2 * latent + (2 if fix_megno else 0)
+    return tuple([("input_noise_logvar", (n_features,)), ("summary_noise_logvar", (sm,))]
+                 + _mlp_layout("feature_nn", n_features, latent, hidden, depth_in)
+                 + _mlp_layout("regress_nn", sm, 2, hidden, depth_out))
 
 
 _STATE_LAYOUT = _state_layout(False)
@@ -125,10 +134,14 @@ class VarModel:
         self.fix_megno2 = hparams.get("fix_megno2", False)
         self.include_angles = hparams.get("include_angles", False)
         self.n_features = hparams["time_series_features"] * (1 + int(hparams["include_derivatives"]))
-        if (self.n_features, hparams["hidden"], hparams["latent"], hparams["in"], hparams["out"]) != (41, 40, 20, 1, 1):
-            raise NotImplementedError("only the 41->40->40->20 / 40(42)->40->40->2 network of the pretrained ensemble "
-                                      "(in=1, out=1) is built for gfx950")
         self.fix_megno = bool(self.fix_megno)
+        self._arch = dict(n_features=int(self.n_features), hidden=int(hparams["hidden"]), latent=int(hparams["latent"]),
+                          depth_in=int(hparams["in"]), depth_out=int(hparams["out"]))
+        if self.n_features not in (41, 82):
+            raise NotImplementedError("time_series_features must be 41 (82 with include_derivatives): the reference's feature packing "
+                                      "produces nothing else (figures/spock/regression.py:210-211)")
+        if max(self._arch["hidden"], self._arch["latent"], 2 * self._arch["latent"] + 2 * int(self.fix_megno)) > 128:
+            raise NotImplementedError("hidden / latent / summary widths above 128 are not built for gfx950 (DESIGN.md section 4.9)")
         # reference init order (:359-362): feature_nn, regress_nn, then the two noise parameters
         feature_nn = mlp(self.n_features, hparams["latent"], hparams["hidden"], hparams["in"])
         regress_nn = mlp(hparams["latent"] * 2 + int(self.fix_megno) * 2, 2, hparams["hidden"], hparams["out"])
@@ -140,7 +153,7 @@ class VarModel:
             sd["feature_nn." + k] = v
         for k, v in regress_nn.state_dict().items():
             sd["regress_nn." + k] = v
-        self._layout = _state_layout(self.fix_megno)
+        self._layout = _state_layout(self.fix_megno, **self._arch)
         assert tuple((k, tuple(v.shape)) for k, v in sd.items()) == self._layout
         self._pending_draw = None
         self._w = torch.cat([v.detach().reshape(-1) for v in sd.values()]).float().contiguous()  # flat vector [d]
@@ -238,17 +251,22 @@ class VarModel:
         return ops.zero_mask_from_flags(self.fix_megno, self.fix_megno2, self.include_mmr, self.include_nan,
                                         self.include_eplusminus)
 
-    def _plan(self):
-        return ops.get_plan(self.zero_mask(), self.lowest, fix_megno=self.fix_megno)
+    def _plan(self, zero_mask=None):
+        return ops.get_plan(self.zero_mask() if zero_mask is None else zero_mask, self.lowest, fix_megno=self.fix_megno, **self._arch)
+
+    @property
+    def _latent(self):
+        return self._arch["latent"]
 
     @property
     def _summary_width(self):
-        return 42 if self.fix_megno else 40
+        return 2 * self._latent + (2 if self.fix_megno else 0)
 
-    @staticmethod
-    def _check_x(x):
-        if x.dim() != 3 or x.shape[-1] != 41:
-            raise NotImplementedError("x must be [batch, time, 41]")  # figures/spock/regression.py:210-211
+    def _check_x(self, x):
+        if x.dim() != 3 or x.shape[-1] != self.n_features:
+            raise NotImplementedError(f"x must be [batch, time, {self.n_features}]")  # figures/spock/regression.py:210-211
+        if x.shape[1] < 2:
+            raise ValueError("the time pool needs at least 2 timesteps (torch.std of one is NaN, spock_reg_model.py:419)")
         return x
 
     def _next_philox_id(self, n=1):
@@ -258,7 +276,7 @@ class VarModel:
 
     def _masked(self, x):
         m = self.zero_mask()
-        cols = [c for c in range(41) if (m >> c) & 1]
+        cols = [c for c in range(min(64, self.n_features)) if (m >> c) & 1]
         x = x.clone()
         x[..., cols] = 0
         return x
@@ -288,8 +306,8 @@ class VarModel:
             # the reference's draws, in its order, on its devices (:445, :426-427, :449)
             if noisy:
                 eps_in = torch.randn_like(x.detach().float())
-            e1 = torch.randn(B, 20, device=dev_in)
-            e2 = torch.randn(B, 20, device=dev_in)
+            e1 = torch.randn(B, self._latent, device=dev_in)
+            e2 = torch.randn(B, self._latent, device=dev_in)
             if noisy:
                 eps_sum = torch.randn(B, self._summary_width, device=dev_in)
             eps = torch.stack([e1, e2], dim=1)[None].to(g).contiguous()
@@ -309,9 +327,9 @@ class VarModel:
         """feature_nn -> mean/std time pool with sampled moments (:416-435).  x is used as given (no masking)."""
         # the reference applies the masks in forward(), not here: run the kernel with an empty mask; the MEGNO statistics of
         # fix_megno are appended by forward() (:509-510), not by this method (:416-435)
-        plan = ops.get_plan(0, self.lowest, fix_megno=self.fix_megno)
+        plan = self._plan(zero_mask=0)
         _, _, summ = self._forward_gpu(x, self._w[None], noisy=False, want_debug=True, plan=plan)
-        return summ[:, :40]
+        return summ[:, :2 * self._latent]
 
     def predict_instability(self, summary_stats):
         """regress_nn + soft_clamp (:437-442) on an explicit summary -> (mu [B,1], std [B,1]) on its device."""
@@ -322,12 +340,12 @@ class VarModel:
 
     def add_input_noise(self, x):
         """x + randn_like(x) * exp(input_noise_logvar / 2) (:444-446); forward() fuses this step into the kernel."""
-        lv = self._w[:41].to(x.device)
+        lv = self._w[:self.n_features].to(x.device)
         return x + torch.randn_like(x) * torch.exp(lv[None, None, :] / 2)
 
     def add_summary_noise(self, summary_stats):
         """summary + randn_like(summary) * exp(summary_noise_logvar / 2) (:448-450); forward() fuses this step."""
-        lv = self._w[41:41 + self._summary_width].to(summary_stats.device)
+        lv = self._w[self.n_features:self.n_features + self._summary_width].to(summary_stats.device)
         return summary_stats + torch.randn_like(summary_stats) * torch.exp(lv[None, :] / 2)
 
     def forward(self, x, noisy_val=True):
@@ -422,8 +440,8 @@ class SWAGModel(VarModel):
         idx = torch.zeros(1, dtype=torch.int32, device=g)
         if self.rng == "torch":
             z1, z2 = self._draw_noise()                                  # :830-831
-            e1 = torch.randn(B, 20, device=dev_in)                       # :426
-            e2 = torch.randn(B, 20, device=dev_in)                       # :427
+            e1 = torch.randn(B, self._latent, device=dev_in)             # :426
+            e2 = torch.randn(B, self._latent, device=dev_in)             # :427
             eps = torch.stack([e1, e2], dim=1)[None].to(g).contiguous()
             z1g, z2g = z1.to(g).contiguous(), z2.reshape(1, -1).to(g).contiguous()
             out = ops.multiswag(xg, wa, w2, pd, idx, z1g, z2g, eps, scale=scale, plan=self._plan())

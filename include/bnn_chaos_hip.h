@@ -27,22 +27,31 @@
 extern "C" {
 #endif
 
-#define BNN_ABI_VERSION 2
+/* v3: bnn_arch carries the network depth (any hparams-built network, not only the pretrained ensemble's); bnn_philox_normal_f32 takes
+ * the feature count; bnn_sketch_bins counts the NaN bin (the last hist row); bnn_fragment_table(which = 1) returns the weight-register
+ * table; bnn_arch.reserved became fix_megno; bnn_build_flags() names the build. */
+#define BNN_ABI_VERSION 3
 
 enum bnn_status {
     BNN_OK = 0,
     BNN_ERR_INVALID = -1,     /* NULL pointer / negative size / inconsistent arguments            */
-    BNN_ERR_UNSUPPORTED = -2, /* architecture other than 41->40->40->20 / 40->40->40->2, T%4 != 0 */
+    BNN_ERR_UNSUPPORTED = -2, /* a shape no kernel is built for (widths above 128, a form limited to the v50 network, ...) */
     BNN_ERR_HIP = -3,         /* a HIP runtime call failed (message has the hipError string)      */
     BNN_ERR_NO_DEVICE = -4,   /* no gfx950 device visible                                         */
-    BNN_ERR_RANGE = -5        /* seed index outside the ensemble, K > 32, ...                     */
+    BNN_ERR_RANGE = -5        /* seed index outside the ensemble, K > 256, ...                    */
 };
 
-/* Network description, from the checkpoint's hparams (spock_reg_model.py:343-397). */
+/* Network description, from the checkpoint's hparams (spock_reg_model.py:343-397).
+ * feature_nn = mlp(n_features, latent, hidden, depth_in), regress_nn = mlp(2 latent (+2), 2, hidden, depth_out) with
+ * mlp(in_n, out_n, hidden, layers) (:301-321) = ONE Linear(in_n, out_n) for layers == 0, else Linear(in_n, hidden), ReLU,
+ * layers x [Linear(hidden, hidden), ReLU], Linear(hidden, out_n).
+ * Two engines sit behind every entry point: the pretrained ensemble's network (41, 40, 20, depth 1/1) at
+ * T % 4 == 0, T >= 8 runs on kernels whose weights are register-resident; everything else -- hidden, latent and summary width up to
+ * 128, any depth with at most 16 Linear modules, 41 or 82 features, any T >= 2 -- on the generic engine (weights streamed from LDS). */
 typedef struct bnn_arch {
-    int32_t n_features; /* hparams['time_series_features'] = 41                                  */
-    int32_t hidden;     /* hparams['hidden'] = 40                                                */
-    int32_t latent;     /* hparams['latent'] = 20                                                */
+    int32_t n_features; /* hparams['time_series_features'] x (1 + include_derivatives): 41 or 82 (:346-358) */
+    int32_t hidden;     /* hparams['hidden'] (40 in every pretrained checkpoint)                  */
+    int32_t latent;     /* hparams['latent'] (20)                                                */
     int32_t fix_megno;  /* hparams['fix_megno'] (spock_reg_model.py:360-362): 1 = the summary is 42 wide ([.. | mean_t, std_t of the
                            raw MEGNO column 7], :480-491, :509-510), summary_noise_logvar [42], regress_nn.0 [40,42], d = 7665;
                            the reference zeroes column 7 as well then (:488-491: set bit 7 of zero_mask); the statistics are taken
@@ -51,6 +60,8 @@ typedef struct bnn_arch {
                            (zero_megno/zero_mmr/zero_nan/zero_eplusminus, spock_reg_model.py:452-500) */
     float lowest_std;   /* soft_clamp floor of std: 0.5, or 0.1 with lower_std (:363-365)         */
     float pad;
+    int32_t depth_in;   /* hparams['in']  (1): the `layers` argument of feature_nn's mlp() (:359)  */
+    int32_t depth_out;  /* hparams['out'] (1): the same for regress_nn (:360)                     */
 } bnn_arch;
 
 typedef struct bnn_plan bnn_plan; /* opaque: device-resident operand tables for one bnn_arch */
@@ -58,13 +69,16 @@ typedef struct bnn_plan bnn_plan; /* opaque: device-resident operand tables for 
 int bnn_abi_version(void);
 const char* bnn_last_error(void);
 int bnn_device_count(void); /* number of visible HIP devices, or negative bnn_status */
-int bnn_param_count(const bnn_arch* arch); /* d (7583; 7665 with fix_megno), or negative */
+int bnn_param_count(const bnn_arch* arch); /* d (7583 for the pretrained network; 7665 with fix_megno), or negative */
+const char* bnn_build_flags(void); /* "" for the default build; otherwise the extra compile-time switches (e.g. "BNN_ABLATE=4"): a
+                                      library that reports anything here is a profiling / A-B variant, not the product */
 
 /* Plans own a few KB of device memory; create/destroy allocate and synchronise, nothing else does. */
 int bnn_plan_create(const bnn_arch* arch, bnn_plan** out);
 int bnn_plan_destroy(bnn_plan* plan);
-/* Accumulation order used by the kernels for Linear layer `layer` (0..5): `order` receives up to
- * `cap` entries (input indices; the accumulator starts at the bias).
+/* Accumulation order used by the kernels for Linear layer `layer` (0 .. number of Linear modules - 1, feature_nn's first): `order`
+ * receives up to `cap` entries (input indices; the accumulator starts at the bias).  The generic engine's order is the natural one
+ * (0, 1, 2, ...) for every layer; the v50 kernels permute regress_nn's.
  * `noisy` selects the 41-column variant used by bnn_forward_f32 with eps_in != NULL.
  * Returns the number of entries.  Lets a test pin a CPU model to the same order. */
 int bnn_plan_layer_order(const bnn_plan* plan, int layer, int noisy, int32_t* host_order, int cap);
@@ -82,7 +96,7 @@ int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host
 /* Everything one MultiSWAG evaluation needs besides the ensemble and the noise. */
 typedef struct bnn_grid {
     int64_t B;       /* systems (rows of x)                                                        */
-    int32_t T;       /* timesteps per system (100); T % 4 == 0                                     */
+    int32_t T;       /* timesteps per system (100); any T in [2, 16384]                            */
     int32_t J;       /* weight draws                                                               */
     int32_t nchunks; /* draw e covers chunk e % nchunks of the systems (torch.chunk semantics,
                         chunk size ceil(B/nchunks)) and writes output row e / nchunks.
@@ -91,7 +105,8 @@ typedef struct bnn_grid {
     int32_t systems_per_block; /* 0 = choose; else a multiple of 64                                */
     int32_t noisy;   /* bnn_forward_f32 only: 1 = forward(noisy_val=True) with ALL noise generated in-kernel
                         (eps, eps_in, eps_sum all NULL); explicit eps_in/eps_sum imply noisy regardless          */
-    int32_t reserved;
+    int32_t engine;  /* 0 = choose (the pretrained network at T % 4 == 0, T >= 8: its register-resident kernels; else the generic engine);
+                        1 = the generic engine whatever the shape (cross-checks, measurements)               */
 } bnn_grid;
 
 /* SWAGModel.sample_weights (spock_reg_model.py:815-838), J draws at once.
@@ -105,9 +120,9 @@ int bnn_swag_draw_f32(const bnn_plan* plan, const float* w_avg, const float* w2_
                       void* stream);
 
 /* VarModel.forward (spock_reg_model.py:486-528) for J already-materialised weight vectors.
- *   x [B,T,41] fp32 contiguous; W [J,d]; out [J/nchunks, B, 2] = cat(mu, std).
- *   eps [J/nchunks, B, 2, 20]: the two randn_like draws of compute_summary_stats (:426-427), or NULL
- *   for in-kernel Philox.  eps_in [J/nchunks,B,T,41] (:445) and eps_sum [J/nchunks,B,40] (:449):
+ *   x [B,T,n_features] fp32 contiguous; W [J,d]; out [J/nchunks, B, 2] = cat(mu, std).
+ *   eps [J/nchunks, B, 2, latent]: the two randn_like draws of compute_summary_stats (:426-427), or NULL
+ *   for in-kernel Philox.  eps_in [J/nchunks,B,T,n_features] (:445) and eps_sum [J/nchunks,B,2 latent (+2)] (:449):
  *   both non-NULL = forward(noisy_val=True); both NULL = noisy_val=False / forward_swag_fast.
  *   Optional debug outputs (may be NULL): pre_clamp [J/nchunks,B,2] = regress_nn output,
  *   summary [J/nchunks,B,40] = compute_summary_stats output. */
@@ -136,7 +151,8 @@ int bnn_forward_lowp_f32(const bnn_plan* plan, const bnn_grid* grid, const float
  * arithmetic as bnn_swag_draw_f32, bit for bit), keep them on chip, stream x once, write (mu, std).
  * system_id0 = global index of x row 0 (Philox counters use global ids so results do not depend on
  * how systems are sharded over GPUs).
- * W_workspace: NULL = every workgroup samples its draw in its own prologue (one launch, no scratch memory).
+ * W_workspace: NULL = every workgroup samples its draw in its own prologue (one launch, no scratch memory); only the pretrained
+ * network's kernels have this form (T % 4 == 0, K <= 32): other shapes return BNN_ERR_UNSUPPORTED without a workspace.
  * Non-NULL [J,d] scratch = each draw is sampled ONCE by a draw kernel into the workspace and the forward
  * kernel of the same call picks it up (two launches on `stream`, identical results bit for bit; faster
  * whenever a draw is shared by many workgroups, i.e. B/nchunks above a few hundred systems). */
@@ -195,13 +211,14 @@ int bnn_regress_f32(const bnn_plan* plan, const float* summary, const float* W, 
 int bnn_group_min_f32(const float* vals, int64_t n, int32_t group, float* out, void* stream);
 
 /* The normals the kernels generate when a noise pointer is NULL, written out for inspection:
- *   kind 0: z1 [n_draws, d]   kind 1: z2 [n_draws, K]   kind 2: eps [rows, B, 2, 20]
- *   kind 3: eps_in [rows, B, T = width, 41] (six normals per Philox block)   kind 4: eps_sum [rows, B, 40]
+ *   kind 0: z1 [n_draws, d]   kind 1: z2 [n_draws, K]   kind 2: eps [rows, B, 2, latent = width (0: 20)]
+ *   kind 3: eps_in [rows, B, T = width, n_features (0: 41)] (six normals per Philox block; Philox4x32 with SEVEN rounds for this one
+ *           stream, ten everywhere else)   kind 4: eps_sum [rows, B, width (0: 40)]
  *   kind 5: candidates of the statistics epilogue's truncated-normal draw [rows, B, nsamp = width]
  *   kind 6: survival level of its prior draw [rows, B], uniform on (0, 1]
  *   id0 = draw_id0 (kinds 0,1) or output-row id0 (kinds 2-6); system_id0 only for kinds 2-6. */
 int bnn_philox_normal_f32(int32_t kind, uint64_t philox_seed, int64_t id0, int64_t n_rows, int64_t B,
-                          int64_t system_id0, int32_t width, float* out, void* stream);
+                          int64_t system_id0, int32_t width, int32_t n_features, float* out, void* stream);
 
 /* ---- streaming statistics epilogue: what the evaluation scripts consume, without [J,B,2] in memory -------
  * Per evaluation: (mu, std) -> fast_truncnorm(left, nsamp) (figures/multiswag_5_planet.py:306-370, 388-392; main_figures.py:167-227)

@@ -31,30 +31,36 @@ def test_abi_exports_every_declared_symbol(N):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(N.EXPORTS)
-    assert lib.bnn_abi_version() == 2
+    assert lib.bnn_abi_version() == N.ABI_VERSION == int(re.search(r"#define BNN_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_arch_validation_and_error_strings(N):
     L = N.lib()
-    ok = N.BnnArch(41, 40, 20, 0, V50_MASK, 0.5, 0)
+    ok = N.BnnArch(41, 40, 20, 0, V50_MASK, 0.5, 0, 1, 1)
     assert L.bnn_param_count(C.byref(ok)) == 7583
-    bad = N.BnnArch(41, 32, 20, 0, V50_MASK, 0.5, 0)
-    assert L.bnn_param_count(C.byref(bad)) == N.ERR_UNSUPPORTED
-    assert b"41->40->40->20" in L.bnn_last_error()
+    other = N.BnnArch(41, 32, 20, 0, V50_MASK, 0.5, 0, 1, 1)                     # another width: the generic engine's network
+    assert L.bnn_param_count(C.byref(other)) == 41 + 40 + (32 * 41 + 32) + (32 * 32 + 32) + (20 * 32 + 20) + (32 * 40 + 32) + (32 * 32 + 32) + (2 * 32 + 2)
+    lin = N.BnnArch(82, 40, 8, 1, V50_MASK, 0.5, 0, 0, 0)                         # in = out = 0: one Linear each; 82 features; fix_megno
+    assert L.bnn_param_count(C.byref(lin)) == 82 + 18 + (8 * 82 + 8) + (2 * 18 + 2)
+    for bad in (N.BnnArch(41, 129, 20, 0, V50_MASK, 0.5, 0, 1, 1), N.BnnArch(41, 40, 65, 0, V50_MASK, 0.5, 0, 1, 1),
+                N.BnnArch(40, 40, 20, 0, V50_MASK, 0.5, 0, 1, 1), N.BnnArch(41, 40, 20, 0, V50_MASK, 0.5, 0, 8, 8),
+                N.BnnArch(41, 40, 20, 0, V50_MASK, 0.5, 0, -1, 1), N.BnnArch(41, 128, 20, 0, V50_MASK, 0.5, 0, 3, 1)):
+        assert L.bnn_param_count(C.byref(bad)) == N.ERR_UNSUPPORTED
+        assert len(L.bnn_last_error()) > 20
     assert L.bnn_param_count(None) == N.ERR_INVALID
-    bad = N.BnnArch(41, 40, 20, 0, 1 << 45, 0.5, 0)
+    bad = N.BnnArch(41, 40, 20, 0, 1 << 45, 0.5, 0, 1, 1)
     assert L.bnn_param_count(C.byref(bad)) == N.ERR_INVALID
 
 
 def _order(N, mask, layer, noisy):
     buf = np.zeros(64, np.int32)
-    a = N.BnnArch(41, 40, 20, 0, mask, 0.5, 0)
+    a = N.BnnArch(41, 40, 20, 0, mask, 0.5, 0, 1, 1)
     n = N.check(N.lib().bnn_layer_order(C.byref(a), layer, noisy, buf.ctypes.data, 64))
     return buf[:n].copy()
 
 
 def _table(N, mask, noisy, which):
-    a = N.BnnArch(41, 40, 20, 0, mask, 0.5, 0)
+    a = N.BnnArch(41, 40, 20, 0, mask, 0.5, 0, 1, 1)
     n = N.check(N.lib().bnn_fragment_table(C.byref(a), noisy, which, None, 0))
     t = np.zeros(n, np.int16)
     N.check(N.lib().bnn_fragment_table(C.byref(a), noisy, which, t.ctypes.data, n))
@@ -62,7 +68,7 @@ def _table(N, mask, noisy, which):
 
 
 def _image(N, mask, noisy):
-    a = N.BnnArch(41, 40, 20, 0, mask, 0.5, 0)
+    a = N.BnnArch(41, 40, 20, 0, mask, 0.5, 0, 1, 1)
     n = N.check(N.lib().bnn_fragment_table(C.byref(a), noisy, 1, None, 0))
     t = np.zeros(n, np.int16)
     N.check(N.lib().bnn_fragment_table(C.byref(a), noisy, 1, t.ctypes.data, n))
@@ -151,9 +157,9 @@ def test_fix_megno_layout_tables(N):
     """hparams['fix_megno'] (bnn_arch.fix_megno = 1): d = 7665, regress_nn.0 accumulates 42 inputs in 11 k-steps, every parameter of
     the wider layer sits in exactly one fragment slot, feature_nn's registers hold the same weights two floats further on."""
     L = N.lib()
-    a = N.BnnArch(41, 40, 20, 1, V50_MASK, 0.5, 0)
+    a = N.BnnArch(41, 40, 20, 1, V50_MASK, 0.5, 0, 1, 1)
     assert L.bnn_param_count(C.byref(a)) == 7665
-    bad = N.BnnArch(41, 40, 20, 2, V50_MASK, 0.5, 0)
+    bad = N.BnnArch(41, 40, 20, 2, V50_MASK, 0.5, 0, 1, 1)
     assert L.bnn_param_count(C.byref(bad)) == N.ERR_INVALID
 
     def order(layer):
@@ -233,8 +239,14 @@ def test_constructor_reproduces_reference_side_effects(tmp_path):
     v = torch.arange(d, dtype=torch.float32)
     m.load(v)
     assert torch.equal(m.flatten(), v) and torch.equal(m.state_dict()["regress_nn.4.bias"], v[-2:])
+    # any network the reference builds from hparams (spock_reg_model.py:301-321, 346-362) has the reference's state_dict layout
+    m64 = srm.SWAGModel({**hp, "hidden": 64, "latent": 16, "in": 2, "out": 0, "include_derivatives": True})
+    sd = m64.state_dict()
+    assert [tuple(v.shape) for v in sd.values()] == [(82,), (32,), (64, 82), (64,), (64, 64), (64,), (64, 64), (64,), (16, 64), (16,), (2, 32), (2,)]
+    assert list(sd.keys())[2:] == ["feature_nn.0.weight", "feature_nn.0.bias", "feature_nn.2.weight", "feature_nn.2.bias", "feature_nn.4.weight",
+                                   "feature_nn.4.bias", "feature_nn.6.weight", "feature_nn.6.bias", "regress_nn.weight", "regress_nn.bias"]
     with pytest.raises(NotImplementedError):
-        srm.SWAGModel({**hp, "hidden": 64})
+        srm.SWAGModel({**hp, "hidden": 200})                             # widths above 128: no kernel
 
 
 def test_standard_scaler_matches_reference_constants():
