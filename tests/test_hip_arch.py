@@ -169,7 +169,8 @@ def test_generic_engine_on_the_pretrained_network_equals_its_kernels(ops, swag_s
             a = ops.forward(x, W, philox_seed=5, draw_id0=8, system_id0=99, plan=plan, debug=True, noisy=noisy)
             b = ops.forward(x, W, philox_seed=5, draw_id0=8, system_id0=99, plan=plan, debug=True, noisy=noisy, engine="generic")
             assert torch.equal(a[2], b[2]), (mask, noisy)
-            assert (a[0] - b[0]).abs().max().item() <= 2e-6
+            nbad, mx = close_report(b[0].cpu().numpy(), a[0].cpu().numpy(), rtol=5e-6)   # regress_nn: two summation orders of 40-term sums
+            assert nbad == 0, (mask, noisy, nbad, mx)
 
 
 def test_generic_engine_at_scale_invariances(ops, orc):

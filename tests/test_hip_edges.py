@@ -59,8 +59,13 @@ def test_other_sequence_lengths(T, ops, orc, swag_states):
     plan = ops.get_plan()
     o = orc.multiswag(x, wa, w2, pd, idx, z1, z2, eps, arch=orc.make_arch(T=T), sched=sched(ops, orc, plan))
     assert np.abs(out.cpu().numpy() - o).max() <= 2e-6
+    # T % 4 != 0 (and T < 8): the generic engine, same answer as the oracle on ITS schedule (tests/test_hip_arch.py has the reference fixtures)
+    x10 = synth(B, 10, 3)
+    o10 = ops.multiswag(dev(x10), dev(wa), dev(w2), dev(pd), torch.as_tensor(idx), dev(z1), dev(z2), dev(eps))
+    w10 = orc.multiswag(x10, wa, w2, pd, idx, z1, z2, eps, arch=orc.make_arch(T=10), sched=orc.make_schedule(None, pool_parts=4))
+    assert np.abs(o10.cpu().numpy() - w10).max() <= 2e-6
     with pytest.raises(Exception):
-        ops.multiswag(dev(synth(2, 10, 0)), dev(wa), dev(w2), dev(pd), torch.as_tensor(idx))  # T % 4 != 0
+        ops.multiswag(dev(synth(2, 1, 0)), dev(wa), dev(w2), dev(pd), torch.as_tensor(idx))  # T = 1: torch.std is NaN
 
 
 @pytest.mark.parametrize("K", (2, 7, 20, 32))
@@ -81,7 +86,7 @@ def test_other_swag_ranks(K, ops, orc, swag_states):
     b = ops.forward(dev(x), dev(W), eps=dev(eps))
     assert torch.equal(a, b)
     with pytest.raises(Exception):
-        ops.swag_draw(dev(wa), dev(w2), dev(np.zeros((1, 7583, 33), np.float32)), torch.zeros(1, dtype=torch.int32))
+        ops.swag_draw(dev(wa), dev(w2), dev(np.zeros((1, 7583, 257), np.float32)), torch.zeros(1, dtype=torch.int32))   # K <= 256
 
 
 @pytest.mark.parametrize("flags", [dict(fix_megno2=False, include_mmr=True, include_nan=True, include_eplusminus=True),

@@ -268,10 +268,11 @@ def test_error_codes(ops):
     x = torch.zeros(2, 100, 40, device="cuda")
     with pytest.raises(NotImplementedError):
         ops.forward(x, torch.zeros(1, 7583, device="cuda"))
-    with pytest.raises(N.NativeError):  # T not a multiple of 4
-        ops.forward(torch.zeros(2, 99, 41, device="cuda"), torch.zeros(1, 7583, device="cuda"))
+    with pytest.raises(N.NativeError):  # T = 1
+        ops.forward(torch.zeros(2, 1, 41, device="cuda"), torch.zeros(1, 7583, device="cuda"))
+    assert ops.forward(torch.zeros(2, 99, 41, device="cuda"), torch.zeros(1, 7583, device="cuda")).shape == (1, 2, 2)   # any T >= 2
     with pytest.raises(N.NativeError):
-        N.Plan(0, hidden=32)
+        N.Plan(0, hidden=129)
 
 
 def test_all_thirty_pretrained_seeds(ops, orc):
