@@ -266,7 +266,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 10; 3 for c4, whose step is ~23 s)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 2; 1 for c4)")
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default c3 (configs[2]); with --gpus N > 1 and no --workload the line "
+                    "also carries `named_config`: one step of configs[3]'s per-GPU share (workload c4), the BASELINE 8-GPU configuration")
     ap.add_argument("--systems", type=int, default=0, help="systems per GPU (overrides the workload)")
     ap.add_argument("--samples", type=int, default=0)
     ap.add_argument("--unfused", action="store_true", help="separate ops.swag_draw + ops.forward calls")
@@ -283,6 +284,9 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even at world size 1 (under a launcher): "
                     "exercises the N > 1 code path -- init, collective, event timing -- on a one-GPU box")
     args = ap.parse_args(argv)
+    args.workload_defaulted = args.workload is None
+    if args.workload is None:
+        args.workload = "c3"
     wl = WORKLOADS[args.workload]
     if args.steps is None:
         args.steps = wl.get("steps", 10)
@@ -485,6 +489,38 @@ def main():
     if res_last.shape[0] != expect_rows:
         sys.exit(f"[bench] rank {rank}: gathered {res_last.shape[0]} rows, expected {expect_rows}")
 
+    # A plain `bench.py --gpus N` (what a driver runs) measures configs[2] weak-scaled.  BASELINE.json's own 8-GPU configuration is
+    # configs[3]: one step of its per-GPU share (workload c4: 1.25M systems x 3000 draws -> float64 moments, all-gather) rides along
+    # as `named_config`, timed the same way (barrier + synchronize on both sides, max over ranks), outside the headline's timed region.
+    gather_bytes_per_rank = int(res_last.shape[0] // world * res_last.shape[1] * res_last.element_size())
+    named = None
+    if world > 1 and args.workload_defaulted and not net and os.environ.get("BNN_BENCH_NO_NAMED") != "1":
+        c4 = WORKLOADS["c4"]
+        B4 = int(os.environ.get("BNN_BENCH_NAMED_SYSTEMS", c4["systems"]))   # (the rehearsal on a shared card shrinks it)
+        del x, out
+        res_last = None
+        torch.cuda.empty_cache()
+        lo4, hi4 = shard_bounds(world * B4, world)[rank]
+        x4 = synthetic_x(B4, dev, seed=123 + rank)
+        J4 = c4["seeds"] * c4["samples"]
+        seed4 = (torch.arange(J4, dtype=torch.int32) % c4["seeds"]).to(dev)
+        ops.multiswag_moments(x4[:4096], wa, w2, pd, seed4[:c4["slab"]], philox_seed=99, system_id0=lo4, draws_per_launch=c4["slab"], plan=plan)   # warm
+        fence()
+        t4 = time.perf_counter()
+        mom4 = ops.multiswag_moments(x4, wa, w2, pd, seed4, philox_seed=99, draw_id0=0, system_id0=lo4, draws_per_launch=c4["slab"], plan=plan)
+        g4 = all_gather_moments(mom4, world * B4)
+        fence()
+        dt4 = time.perf_counter() - t4
+        tt = torch.tensor([dt4], dtype=torch.float64, device=dev if on_nccl else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt4 = float(tt.item())
+        assert g4.shape[0] == world * B4
+        named = {"workload": c4["name"], "systems_per_gpu": B4, "draws": J4, "steps": 1, "warmup": 0, "ms_per_step": dt4 * 1e3,
+                 "value": world * B4 * J4 / dt4, "unit": "evals/s", "scaling": "weak",
+                 "frac": world * B4 * J4 * ALG_FLOP_PER_EVAL / dt4 / 1e12 / (world * PEAK_F32_MFMA_TFLOPS),
+                 "note": "BASELINE.json configs[3] (10M systems x 30 seeds x 100 samples over 8 GPUs): ONE step of the per-GPU share through "
+                         "the native slab driver + the all-gather of [systems, 4] float64 moments; whole-job evals/s, max over ranks"}
+
     evals_per_step = world * B * R   # every system under every sample (a chunked draw covers 1/nch of the systems)
     value = evals_per_step * args.steps / dt
     if rank == 0:
@@ -538,7 +574,7 @@ def main():
                        "sharding": (f"whole simulations ({trios} trios each) over {world} rank(s), all-gather of {payload}" if trios > 1 else
                                     f"systems over {world} rank(s), all-gather of {payload}"),
                        "collective": (dist.get_backend() if use_dist else "none"), "degraded": degraded, "ranks_seen": ranks_seen,
-                       "gather_ms": gather_ms, "gather_bytes_per_rank": int(res_last.shape[0] // world * res_last.shape[1] * res_last.element_size()),
+                       "gather_ms": gather_ms, "gather_bytes_per_rank": gather_bytes_per_rank,
                        "kernel_ms_min": min(kern_ms_ranks), "kernel_ms_max": max(kern_ms_ranks),
                        "timing_note": "ms_per_step = wall clock of the whole step, max over ranks; kernel_ms_* = HIP events around the compute "
                                       "launches per rank (min / max over ranks); gather_ms = the all-gather alone, max over ranks"},
@@ -553,6 +589,8 @@ def main():
                                  "no such pass is on file for this workload",
                          "hbm_algorithmic_GBs": ach_gbs, "hbm_frac_of_8TBs": ach_gbs / PEAK_HBM_GBS},
         }
+        if named:
+            res["named_config"] = named
         if lowp:   # priced against the bf16 matrix pipe; issued flops = algorithmic x products; these forms are vector-issue bound
             peak = PEAK_BF16_MFMA_TFLOPS
             iss = exe_tflops * PRODUCTS_OF[args.precision]

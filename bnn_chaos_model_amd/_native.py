@@ -24,7 +24,7 @@ class BnnArch(C.Structure):
 
 class BnnGrid(C.Structure):
     _fields_ = [("B", C.c_int64), ("T", C.c_int32), ("J", C.c_int32), ("nchunks", C.c_int32),
-                ("systems_per_block", C.c_int32), ("noisy", C.c_int32), ("engine", C.c_int32)]
+                ("systems_per_block", C.c_int32), ("noisy", C.c_int32), ("engine", C.c_int32), ("chunk_B", C.c_int64), ("chunk_off", C.c_int64)]
 
 
 class BnnStats(C.Structure):

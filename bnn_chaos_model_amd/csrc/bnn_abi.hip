@@ -682,14 +682,18 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     if (p.draw_id0 % g->nchunks) return fail(BNN_ERR_INVALID, "draw_id0 must be a multiple of nchunks");
     const int NF = pl->arch.n_features;
     p.B = g->B; p.T = g->T; p.ntiles = (g->T + 3) / 4; p.J = g->J; p.nch = g->nchunks;
-    p.csz = (g->B + g->nchunks - 1) / g->nchunks;
+    p.cB = g->chunk_B > 0 ? g->chunk_B : g->B;
+    p.coff = g->chunk_B > 0 ? g->chunk_off : 0;
+    if (p.coff < 0 || p.coff + g->B > p.cB) return fail(BNN_ERR_INVALID, "chunk_off / chunk_B: the shard [chunk_off, chunk_off + B) must lie inside the batch");
+    p.csz = (p.cB + g->nchunks - 1) / g->nchunks;
     p.xcd_order = (g->nchunks > 1 || (double)g->B * g->T * NF * sizeof(float) > 256.0 * 1024 * 1024) ? 1 : 0;
-    p.spc = pick_spc(g, p.csz, p.xcd_order != 0);
+    const int64_t cseg = p.csz < g->B ? p.csz : g->B;   // the longest stretch of one chunk inside this call's rows
+    p.spc = pick_spc(g, cseg, p.xcd_order != 0);
     p.row_id0 = p.draw_id0 / g->nchunks;
     p.tab_f2 = pl->d_f2; p.tab_wr = noisy ? pl->d_f4n : pl->d_f4; p.rcp_tab = pl->d_rcp;
     p.zero_mask = pl->arch.zero_mask;
     p.std_lo = pl->arch.lowest_std; p.std_span = (float)(6.0 - (double)pl->arch.lowest_std);
-    const int64_t nsub = (p.csz + p.spc - 1) / p.spc;
+    const int64_t nsub = (cseg + p.spc - 1) / p.spc;
     const int64_t nblk = nsub * g->J;
     if (nblk > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "grid too large; split the draws");
     static_assert(Lay<true>::NF2 * 64 <= FLAT_LDS, "regress_nn fragments overwrite the flat vector in place");

@@ -175,8 +175,11 @@ __global__ __launch_bounds__(256, 1) void bnn_forward_generic_kernel(const GenPa
     const int64_t sub = wi.sub;
     const int ch = e % p.nch;
     const int64_t r = e / p.nch;  // output row
-    const int64_t seg0 = (int64_t)ch * p.csz;
-    const int64_t seg1 = (seg0 + p.csz < p.B) ? seg0 + p.csz : p.B;
+    // the draw's chunk of systems (torch.chunk over the cB systems of the WHOLE batch, of which this call holds rows [coff, coff + B))
+    const int64_t g0 = (int64_t)ch * p.csz - p.coff, gend = p.cB - p.coff;
+    const int64_t seg0 = g0 > 0 ? g0 : 0;
+    int64_t seg1 = (g0 + p.csz < gend) ? g0 + p.csz : gend;
+    seg1 = seg1 < p.B ? seg1 : p.B;
     const int64_t b0 = seg0 + sub * p.spc;
     const int64_t b1 = (b0 + p.spc < seg1) ? b0 + p.spc : seg1;
     if (b0 >= b1) return;

@@ -33,7 +33,9 @@ struct FwdParams {
     int64_t B;
     int32_t T, ntiles;
     int32_t J, nch;
-    int64_t csz;
+    int64_t csz;  // chunk size = ceil(cB / nch): torch.chunk over the whole batch
+    int64_t cB;   // systems of the whole batch the chunks partition (= B unless the batch is sharded over devices)
+    int64_t coff; // index of this call's row 0 in that batch
     int32_t spc;  // systems per workgroup (multiple of 64)
     int32_t xcd_order;  // 1: XCD k takes the k-th contiguous eighth of the work order (work_item, bnn_common.hip.h)
     int32_t K, S;

@@ -7,7 +7,9 @@ samples [J, B_local, 2] to per-system predictive moments [B_local, 4] locally, a
 xGMI; gloo on CPU in the tests) assembles [B, 4] on every rank.  Results are bit-identical for any world size
 because the in-kernel noise is keyed by global ids.
 
-One process per GPU: launch with torch.distributed.run; rank r uses cuda:LOCAL_RANK.
+One process per GPU: launch with torch.distributed.run; rank r uses cuda:LOCAL_RANK.  The same decomposition from ONE process
+(every visible GPU driven by the caller's process, no launcher): multidevice.py, reached through MultiSwagSharded(devices=...) and
+FeatureRegressor's batched drivers.
 """
 import torch
 import torch.distributed as dist
@@ -76,13 +78,26 @@ def sharded_predictive_moments(local_moments_fn, B, group=None):
 class MultiSwagSharded:
     """Predictive moments of the dense (systems x draws) MultiSWAG grid on this rank's GPU, gathered over ranks."""
 
-    def __init__(self, w_avg, w2_avg, pre_D, zero_mask=None, lowest_std=0.5, group=None, draws_per_launch=256):
+    def __init__(self, w_avg, w2_avg, pre_D, zero_mask=None, lowest_std=0.5, group=None, draws_per_launch=256, devices=None, **arch):
+        """devices=None: one process per GPU (torch.distributed), this rank's current device.  devices="all" / an int / a list:
+        ONE process drives those GPUs (multidevice.DeviceSet): predictive_moments / predictive_quantiles then take the WHOLE x
+        (host or device memory), shard it, and return the assembled table on the first device.
+        **arch: n_features / hidden / latent / depth_in / depth_out / fix_megno of a network other than the pretrained one."""
         from . import ops
         self.ops = ops
         self.state = (w_avg, w2_avg, pre_D)
-        self.plan = ops.get_plan(ops.V50_ZERO_MASK if zero_mask is None else zero_mask, lowest_std)
+        self._mask = ops.V50_ZERO_MASK if zero_mask is None else zero_mask
+        self._lowest, self._arch = lowest_std, arch
+        self.devset = None
+        if devices is not None:
+            from .multidevice import DeviceSet
+            self.devset = DeviceSet(None if devices == "all" else devices)
+        self.plan = None if self.devset else self._plan_on(None)
         self.group = group
         self.draws_per_launch = int(draws_per_launch)
+
+    def _plan_on(self, device):
+        return self.ops.get_plan(self._mask, self._lowest, device=device, **self._arch)
 
     def local_moments(self, x_local, seed_idx, philox_seed, system_id0, scale=0.5):
         """x_local [B_r,T,41] on this rank's GPU; seed_idx [J] (identical on every rank) -> float64 [B_r,4].
@@ -91,7 +106,23 @@ class MultiSwagSharded:
         return self.ops.multiswag_moments(x_local, wa, w2, pd, seed_idx, scale=scale, philox_seed=philox_seed, system_id0=system_id0,
                                           draws_per_launch=self.draws_per_launch, plan=self.plan)
 
+    def _all_devices(self, x, B_total, group, per_shard):
+        """Single-process form: shard the whole x over the device set, run per_shard(x_shard_on_device, state_on_device, plan, lo) on
+        every device, ONE exchange."""
+        ds = self.devset
+        if x.shape[0] != B_total:
+            raise ValueError("with devices=..., x is the WHOLE batch")
+        states = ds.replicate("state", self.state)
+
+        def shard(i, dev, lo, hi):
+            return per_shard(x[lo:hi].detach().to(dev, torch.float32).contiguous(), states[i], self._plan_on(dev), lo)
+
+        return ds.gather_rows(ds.run(B_total, shard, group=group))
+
     def predictive_moments(self, x_local, B_total, seed_idx, philox_seed=0, scale=0.5):
+        if self.devset is not None:
+            return self._all_devices(x_local, B_total, 1, lambda xs, st, plan, lo: self.ops.multiswag_moments(
+                xs, *st, seed_idx, scale=scale, philox_seed=philox_seed, system_id0=lo, draws_per_launch=self.draws_per_launch, plan=plan))
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         rank = dist.get_rank(self.group) if dist.is_initialized() else 0
         lo, hi = shard_bounds(B_total, world)[rank]
@@ -120,6 +151,13 @@ class MultiSwagSharded:
         resampling, min over `trios` consecutive systems: figures/multiswag_5_planet.py:388-428, 484-489) for the dense
         (systems x draws) grid, sharded by simulation: [B_total / trios, len(q) + 1] on every rank after ONE all-gather.
         Neither [J,B,2] nor [J,B] is ever materialised beyond one slab of `draws_per_launch` draws."""
+        if self.devset is not None:
+            def per_shard(xs, st, plan, lo):
+                sk = self.ops.QuantileSketch(xs.shape[0], group=trios, segments=segments, device=xs.device)
+                self.ops.multiswag_bands(xs, *st, seed_idx, sk, st=stats or self.ops.stats_params(device=xs.device), scale=scale,
+                                         philox_seed=philox_seed, system_id0=lo, draws_per_launch=self.draws_per_launch, plan=plan)
+                return torch.cat([sk.percentiles(q), sk.mean().float()[:, None]], 1)
+            return self._all_devices(x_local, B_total, trios, per_shard)
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         rank = dist.get_rank(self.group) if dist.is_initialized() else 0
         lo, hi = shard_bounds(B_total, world, trios)[rank]

@@ -84,8 +84,10 @@ def _f32(t, name):
 ENGINES = {"auto": 0, "generic": 1}
 
 
-def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto"):
-    return N.BnnGrid(int(B), int(T), int(J), int(nchunks), int(spb), int(bool(noisy)), ENGINES[engine])
+def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto", chunk_B=0, chunk_off=0):
+    """chunk_B / chunk_off: the batch is sharded over devices and this call holds rows [chunk_off, chunk_off + B) of its chunk_B
+    systems; the draws' chunks (torch.chunk) partition the whole batch (bnn_grid in include/bnn_chaos_hip.h)."""
+    return N.BnnGrid(int(B), int(T), int(J), int(nchunks), int(spb), int(bool(noisy)), ENGINES[engine], int(chunk_B or 0), int(chunk_off))
 
 
 @_on_device_of(0)
@@ -126,7 +128,7 @@ def half_range_exceeded(x, zero_mask=V50_ZERO_MASK):
 
 @_on_device_of(0)
 def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0, draw_id0=0, system_id0=0, plan=None,
-            debug=False, systems_per_block=0, noisy=False, precision="f32", engine="auto"):
+            debug=False, systems_per_block=0, noisy=False, precision="f32", engine="auto", chunk_B=0, chunk_off=0):
     """VarModel.forward (spock_reg_model.py:486-528) for materialised weight vectors W[J,d] -> out[J/nchunks,B,2].
 
     eps [R,B,2,20] = the two randn_like of compute_summary_stats (:426-427) or None (Philox);
@@ -160,7 +162,7 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     out = torch.empty((R, B, 2), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, SM), dtype=torch.float32, device=x.device) if debug else None
-    g = _grid(B, T, J, nchunks, systems_per_block, noisy, engine)
+    g = _grid(B, T, J, nchunks, systems_per_block, noisy, engine, chunk_B, chunk_off)
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
     if precision != "f32":
@@ -207,7 +209,7 @@ def _workspace(J, d, device):
 @_on_device_of(0)
 def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nchunks=1, scale=0.5, philox_seed=0,
               draw_id0=0, system_id0=0, plan=None, debug=False, systems_per_block=0, out=None, single_launch=None, precision="f32",
-              engine="auto"):
+              engine="auto", chunk_B=0, chunk_off=0):
     """Fused SWAGModel.forward_swag_fast (spock_reg_model.py:878-908) over the MC loop of
     figures/multiswag_5_planet.py:295-298 -> out[J/nchunks, B, 2].
 
@@ -218,7 +220,7 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
     if precision != "f32":  # opt-in reduced precision: exact fp32 draw, then the bf16-pipe forward (same noise streams)
         W = swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1, z2, scale=scale, philox_seed=philox_seed, draw_id0=draw_id0, plan=plan)
         res = forward(x, W, eps=eps, nchunks=nchunks, philox_seed=philox_seed, draw_id0=draw_id0, system_id0=system_id0, plan=plan,
-                      debug=debug, systems_per_block=systems_per_block, precision=precision)
+                      debug=debug, systems_per_block=systems_per_block, precision=precision, chunk_B=chunk_B, chunk_off=chunk_off)
         if out is not None and not debug:
             out.copy_(res)
             return out
@@ -245,13 +247,13 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
         raise ValueError("out has the wrong shape/dtype")
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, plan.summary_width), dtype=torch.float32, device=x.device) if debug else None
-    g = _grid(B, T, J, nchunks, systems_per_block, engine=engine)
+    g = _grid(B, T, J, nchunks, systems_per_block, engine=engine, chunk_B=chunk_B, chunk_off=chunk_off)
     if not fused_draw_available(plan, T, K) or engine == "generic":
         if single_launch:
             raise NotImplementedError("single_launch (in-prologue draw) exists for the pretrained network at T % 4 == 0, K <= 32 only")
         single_launch = False
     if single_launch is None:
-        single_launch = -(-B // max(nchunks, 1)) <= 256
+        single_launch = -(-(chunk_B or B) // max(nchunks, 1)) <= 256
     ws = None if single_launch else _workspace(J, d, x.device)
     N.check(N.lib().bnn_multiswag_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
                                       N.ptr(seed_idx), N.ptr(z1), N.ptr(z2), N.ptr(eps), float(scale), int(philox_seed),
@@ -380,7 +382,7 @@ def stats_draw(musd, st=None, philox_seed=0, row_id0=0, system_id0=0):
 
 @_on_device_of(0)
 def multiswag_stats(x, w_avg, w2_avg, pre_D, seed_idx, st=None, z1=None, z2=None, eps=None, nchunks=1, scale=0.5, philox_seed=0,
-                    draw_id0=0, system_id0=0, plan=None, systems_per_block=0, out=None):
+                    draw_id0=0, system_id0=0, plan=None, systems_per_block=0, out=None, chunk_B=0, chunk_off=0):
     """multiswag with the statistics epilogue fused into the kernel's tail -> t [J/nchunks, B]: (mu, std) never reach memory.
     Bit-identical to stats_draw(multiswag(...), row_id0=draw_id0 // nchunks, system_id0=system_id0)."""
     plan = plan or get_plan()
@@ -403,7 +405,7 @@ def multiswag_stats(x, w_avg, w2_avg, pre_D, seed_idx, st=None, z1=None, z2=None
         out = torch.empty((R, B), dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != (R, B) or out.dtype != torch.float32 or not out.is_contiguous():
         raise ValueError("out has the wrong shape/dtype")
-    g = _grid(B, T, J, nchunks, systems_per_block)
+    g = _grid(B, T, J, nchunks, systems_per_block, chunk_B=chunk_B, chunk_off=chunk_off)
     ws = _workspace(max(J, 1), d, x.device)
     N.check(N.lib().bnn_multiswag_stats_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
                                             N.ptr(seed_idx), N.ptr(z1), N.ptr(z2), N.ptr(eps), float(scale), int(philox_seed),
@@ -486,7 +488,7 @@ def _slab_common(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, draws_per_launch, d
 
 @_on_device_of(0)
 def multiswag_moments(x, w_avg, w2_avg, pre_D, seed_idx, nchunks=1, scale=0.5, philox_seed=0, draw_id0=0, system_id0=0,
-                      draws_per_launch=256, plan=None):
+                      draws_per_launch=256, plan=None, chunk_B=0, chunk_off=0):
     """Predictive moments of the whole grid -> float64 [B,4] (sum mu, sum mu^2, sum std, sum std^2 over the output rows), the
     draws evaluated `draws_per_launch` at a time inside ONE native call (bnn_multiswag_moments_f64): [J,B,2] never exists."""
     plan, x, w_avg, w2_avg, pre_D, S, d, K, seed_idx, J, dpl = _slab_common(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, draws_per_launch, draw_id0, plan)
@@ -494,7 +496,7 @@ def multiswag_moments(x, w_avg, w2_avg, pre_D, seed_idx, nchunks=1, scale=0.5, p
     mom = torch.empty((B, 4), dtype=torch.float64, device=x.device)
     ws = _workspace(dpl, d, x.device)
     outw = torch.empty((dpl // nchunks, B, 2), dtype=torch.float32, device=x.device)
-    g = _grid(B, T, J, nchunks, 0)
+    g = _grid(B, T, J, nchunks, 0, chunk_B=chunk_B, chunk_off=chunk_off)
     N.check(N.lib().bnn_multiswag_moments_f64(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
                                               N.ptr(seed_idx), float(scale), int(philox_seed), int(draw_id0), int(system_id0), dpl,
                                               N.ptr(ws), N.ptr(outw), N.ptr(mom), N.stream_ptr()))
@@ -505,7 +507,7 @@ def multiswag_moments(x, w_avg, w2_avg, pre_D, seed_idx, nchunks=1, scale=0.5, p
 
 @_on_device_of(0)
 def multiswag_bands(x, w_avg, w2_avg, pre_D, seed_idx, sketch, st=None, nchunks=1, scale=0.5, philox_seed=0, draw_id0=0,
-                    system_id0=0, draws_per_launch=256, plan=None):
+                    system_id0=0, draws_per_launch=256, plan=None, chunk_B=0, chunk_off=0):
     """The whole grid streamed into `sketch` (a QuantileSketch over x's systems) inside ONE native call
     (bnn_multiswag_bands_f32): statistics epilogue in the forward tail, min over the sketch's group, histogram update."""
     plan, x, w_avg, w2_avg, pre_D, S, d, K, seed_idx, J, dpl = _slab_common(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, draws_per_launch, draw_id0, plan)
@@ -515,7 +517,7 @@ def multiswag_bands(x, w_avg, w2_avg, pre_D, seed_idx, sketch, st=None, nchunks=
     st = st or stats_params(device=x.device)
     ws = _workspace(dpl, d, x.device)
     tw = torch.empty((dpl // nchunks, B), dtype=torch.float32, device=x.device)
-    g = _grid(B, T, J, nchunks, 0)
+    g = _grid(B, T, J, nchunks, 0, chunk_B=chunk_B, chunk_off=chunk_off)
     N.check(N.lib().bnn_multiswag_bands_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
                                             N.ptr(seed_idx), float(scale), int(philox_seed), int(draw_id0), int(system_id0), dpl,
                                             N.ptr(ws), N.ptr(tw), C.byref(st), sketch.group, C.byref(sketch.spec), N.ptr(sketch.hist),

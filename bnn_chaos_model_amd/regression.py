@@ -13,6 +13,7 @@ import torch
 
 from . import ops
 from . import spock_reg_model
+from .multidevice import DeviceSet
 from .spock_reg_model import _gpu
 
 
@@ -47,6 +48,28 @@ class FeatureRegressor(object):
         self.swag_ensemble = [spock_reg_model.load_swag(fname).cpu() for fname in names]
         self.ssX = spock_reg_model.v50_scaler()  # "Assume fixed scale" (regression.py:47-71)
         self._stacked = None
+        self._device_sets = {}
+        self._cpu_state = None
+
+    # ---- every visible GPU from this one process (multidevice.py) ------------------------------------------------
+    def device_set(self, devices=None):
+        """devices: None = every visible GPU (an unchanged single-process script then uses the whole node); an int n = the first n;
+        a list of indices / torch.devices = exactly those (a device may be named several times: logical shards on one card)."""
+        key = None if devices is None else (devices if isinstance(devices, int) else tuple(str(d) for d in devices))
+        if key not in self._device_sets:
+            self._device_sets[key] = DeviceSet(devices)
+        return self._device_sets[key]
+
+    def _ensemble_cpu(self):
+        if self._cpu_state is None or self._cpu_state[0] != len(self.swag_ensemble):
+            f = lambda name: torch.stack([getattr(m, name).detach().float().cpu() for m in self.swag_ensemble]).contiguous()
+            self._cpu_state = (len(self.swag_ensemble), (f("w_avg"), f("w2_avg"), f("pre_D")))
+        return self._cpu_state[1]
+
+    def _check_X(self, X):
+        nf = self.swag_ensemble[0].n_features if self.swag_ensemble else 41
+        if X.dim() != 3 or X.shape[-1] != nf:
+            raise NotImplementedError(f"X must be [B, T, {nf}]")
 
     # ---- reference API -----------------------------------------------------------------------------------------
     def sample_full_swag(self, X_sample):
@@ -100,32 +123,33 @@ class FeatureRegressor(object):
         """w_avg [S,d], w2_avg [S,d], pre_D [S,d,K] of the whole ensemble, resident on the GPU (29 MB for 30 seeds)."""
         dev = _gpu() if device is None else torch.device(device)
         if self._stacked is None or self._stacked[0].device != dev:
-            f = lambda name: torch.stack([getattr(m, name).detach().float().cpu() for m in self.swag_ensemble]).to(dev).contiguous()
-            self._stacked = (f("w_avg"), f("w2_avg"), f("pre_D"))
+            self._stacked = tuple(t.to(dev).contiguous() for t in self._ensemble_cpu())
         return self._stacked
 
     def sample_full_swag_many(self, X, samples, chunks=1, rng="torch", philox_seed=0, draw_id0=0, system_id0=0,
-                              scale=0.5, out=None, precision="f32"):
-        """The whole MC loop in one launch:
+                              scale=0.5, out=None, precision="f32", devices=None):
+        """The whole MC loop in one launch per device:
 
             torch.cat([torch.cat([self.sample_full_swag(Xpart) for Xpart in torch.chunk(X, chunks)])[None]
                        for _ in range(samples)])          # figures/multiswag_5_planet.py:295-298
 
         -> [samples, B, 2].  rng="torch" consumes numpy's and torch's global generators exactly as that loop does
-        (one randint + randn((1,d)) + randn((K,1)) + 2 randn_like([Bc,20]) per chunk per sample);
+        (one randint + randn((1,d)) + randn((K,1)) + 2 randn_like([Bc,latent]) per chunk per sample);
         rng="philox" draws the seed picks from numpy and everything else in-kernel.
+        devices: None = every visible GPU of this process (the systems are sharded over them, the ensemble and the draws replicated;
+        the chunks stay those of the whole batch, so the result does not depend on the device list: multidevice.py); an int or a
+        list picks devices.
         precision: "f32" (the parity path) or an OPT-IN reduced-precision form of ops.forward ("f16x3": fp32-level error at ~1.7x
         the throughput; "bf16", "f16", ...: approximate) -- DESIGN.md section 4.6.  The IEEE-half forms ("f16", "f16x3") require
         |X| < 65 504 in the live columns: rows beyond that (e.g. the script's constant-4 fill of unstable systems,
         figures/multiswag_5_planet.py:215) get finite but WRONG outputs; this method checks and warns (RuntimeWarning, with the
         number of rows); use a bfloat16 form ("bf16x6": fp32 range and fp32-level error) or "f32" for such inputs."""
-        if X.dim() != 3 or X.shape[-1] != 41:
-            raise NotImplementedError("X must be [B, T, 41]")
-        g = _gpu()
-        wa, w2, pd = self.ensemble_state(g)
-        S, d, K = pd.shape
+        self._check_X(X)
+        ds = self.device_set(devices)
         m0 = self.swag_ensemble[0]
-        plan = ops.get_plan(m0.zero_mask(), m0.lowest)
+        state = ds.replicate("ensemble", self._ensemble_cpu())
+        S, d, K = state[0][2].shape
+        LAT = m0._latent
         B = X.shape[0]
         parts = torch.chunk(torch.arange(B), chunks) if B else []
         nch = len(parts)  # torch.chunk may return fewer chunks than asked
@@ -135,19 +159,20 @@ class FeatureRegressor(object):
         if any(len(pp) != min(csz, B - i * csz) for i, pp in enumerate(parts)):
             raise NotImplementedError("unexpected torch.chunk partition")
         J = samples * nch
-        xg = X.detach().to(g, torch.float32).contiguous()
         if precision in ops.HALF_FORMS:
-            nbad = int(ops.half_range_exceeded(xg, m0.zero_mask()).sum())
+            nbad = int(ops.half_range_exceeded(X.detach().float(), m0.zero_mask()).sum())
             if nbad:
                 import warnings
                 warnings.warn(f"precision={precision!r}: {nbad} of {B} rows hold |x| >= 65504 in a live column; IEEE half saturates there and "
                               "the outputs of those rows are wrong (finite); use 'bf16x6' or 'f32' for them", RuntimeWarning, stacklevel=2)
-        noise_dev = g if self.cuda else torch.device("cpu")
+        g0 = ds.devices[0]
+        noise_dev = g0 if self.cuda else torch.device("cpu")
         seed_idx = np.empty(J, np.int32)
+        z1 = z2 = eps = None
         if rng == "torch":
             z1 = torch.empty((J, d), device=noise_dev)
             z2 = torch.empty((J, K), device=noise_dev)
-            eps = torch.empty((samples, B, 2, 20), device=X.device)
+            eps = torch.empty((samples, B, 2, LAT), device=X.device)
             for e in range(J):
                 s_, c_ = divmod(e, nch)
                 seed_idx[e] = np.random.randint(0, S)                               # regression.py:78
@@ -155,21 +180,35 @@ class FeatureRegressor(object):
                 z2[e] = torch.randn((K, 1), device=noise_dev)[:, 0]                 # :831
                 n = len(parts[c_])
                 lo = c_ * csz
-                eps[s_, lo:lo + n, 0] = torch.randn(n, 20, device=X.device)         # :426
-                eps[s_, lo:lo + n, 1] = torch.randn(n, 20, device=X.device)         # :427
-            res = ops.multiswag(xg, wa, w2, pd, torch.as_tensor(seed_idx), z1.to(g).contiguous(), z2.to(g).contiguous(),
-                                eps.to(g).contiguous(), nchunks=nch, scale=scale, plan=plan, out=out, precision=precision)
+                eps[s_, lo:lo + n, 0] = torch.randn(n, LAT, device=X.device)        # :426
+                eps[s_, lo:lo + n, 1] = torch.randn(n, LAT, device=X.device)        # :427
         elif rng == "philox":
             for e in range(J):
                 seed_idx[e] = np.random.randint(0, S)
-            res = ops.multiswag(xg, wa, w2, pd, torch.as_tensor(seed_idx), nchunks=nch, scale=scale, philox_seed=philox_seed,
-                                draw_id0=draw_id0, system_id0=system_id0, plan=plan, out=out, precision=precision)
         else:
             raise ValueError("rng must be 'torch' or 'philox'")
-        return res if out is not None else res.to(X.device)
+        seed_t = torch.as_tensor(seed_idx)
+
+        def shard(i, dev, lo, hi):
+            wa, w2, pd = state[i]
+            xg = X[lo:hi].detach().to(dev, torch.float32).contiguous()
+            kw = dict(nchunks=nch, scale=scale, plan=m0._plan(device=dev), precision=precision, chunk_B=B, chunk_off=lo)
+            if rng == "torch":
+                return ops.multiswag(xg, wa, w2, pd, seed_t, z1.to(dev).contiguous(), z2.to(dev).contiguous(),
+                                     eps[:, lo:hi].to(dev).contiguous(), **kw)
+            return ops.multiswag(xg, wa, w2, pd, seed_t, philox_seed=philox_seed, draw_id0=draw_id0, system_id0=system_id0 + lo, **kw)
+
+        res = [r for r in ds.run(B, shard) if r is not None]
+        target = out.device if out is not None else X.device
+        nb = torch.device(target).type == "cuda"   # (a non-blocking copy to HOST memory would return before the data has landed)
+        res = res[0].to(target) if len(res) == 1 else torch.cat([r.to(target, non_blocking=nb) for r in res], 1)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     def predictive_bands(self, X, samples, chunks=1, trios=1, q=(50.0, 84.0, 16.0, 97.5, 2.5), philox_seed=0, system_id0=0,
-                         samples_per_launch=64, scale=0.5, stats=None, segments=None):
+                         samples_per_launch=64, scale=0.5, stats=None, segments=None, devices=None):
         """Everything figures/multiswag_5_planet.py does between the features and the `cleaned` table (:295-298, 388-428,
         484-489), streamed: the MC loop (one random ensemble member + one weight draw per chunk per sample), the truncated-normal
         draw, the prior resampling past 9, the min over `trios` consecutive rows and, per simulation, the percentiles `q`
@@ -177,20 +216,34 @@ class FeatureRegressor(object):
         `samples_per_launch` samples: the epilogue runs in the forward kernel's tail, a quantile sketch (ops.QuantileSketch,
         one bin width of error) collects the draws.  Seed picks come from numpy's generator (regression.py:78, one per chunk per
         sample, in the reference's order); all other noise is in-kernel Philox keyed by (philox_seed, sample, row).
+        devices: as in sample_full_swag_many -- None = every visible GPU: WHOLE simulations are sharded over them, each device
+        streams its shard into its own sketch, and ONE exchange assembles the [simulations, len(q) + 1] table on the first device.
         Returns {"percentiles": [B / trios, len(q)], "average": [B / trios]} on the GPU."""
-        if X.dim() != 3 or X.shape[-1] != 41:
-            raise NotImplementedError("X must be [B, T, 41]")
-        g = _gpu()
-        wa, w2, pd = self.ensemble_state(g)
-        S = pd.shape[0]
+        self._check_X(X)
+        if stats is not None and len(self.device_set(devices)) > 1:
+            raise ValueError("an explicit `stats` block lives on one device; leave it None when several devices are used")
+        ds = self.device_set(devices)
         m0 = self.swag_ensemble[0]
-        plan = ops.get_plan(m0.zero_mask(), m0.lowest)
+        state = ds.replicate("ensemble", self._ensemble_cpu())
+        S = state[0][2].shape[0]
         B = X.shape[0]
         nch = len(torch.chunk(torch.arange(B), chunks)) if B else 1
-        xg = X.detach().to(g, torch.float32).contiguous()
-        sk = ops.QuantileSketch(B, group=trios, segments=segments, device=g)
-        st = stats or ops.stats_params(device=g)
-        seed_idx = np.array([np.random.randint(0, S) for _ in range(samples * nch)], np.int32)   # one pick per chunk per sample
-        ops.multiswag_bands(xg, wa, w2, pd, torch.as_tensor(seed_idx), sk, st=st, nchunks=nch, scale=scale, philox_seed=philox_seed,
-                            system_id0=system_id0, draws_per_launch=samples_per_launch * nch, plan=plan)
-        return {"percentiles": sk.percentiles(q), "average": sk.mean().float(), "sketch": sk}
+        seed_idx = torch.as_tensor(np.array([np.random.randint(0, S) for _ in range(samples * nch)], np.int32))   # one pick per chunk per sample
+        sketches = [None] * len(ds)
+
+        def shard(i, dev, lo, hi):
+            wa, w2, pd = state[i]
+            xg = X[lo:hi].detach().to(dev, torch.float32).contiguous()
+            sk = ops.QuantileSketch(hi - lo, group=trios, segments=segments, device=dev)
+            st = stats or ops.stats_params(device=dev)
+            ops.multiswag_bands(xg, wa, w2, pd, seed_idx, sk, st=st, nchunks=nch, scale=scale, philox_seed=philox_seed,
+                                system_id0=system_id0 + lo, draws_per_launch=samples_per_launch * nch, plan=m0._plan(device=dev),
+                                chunk_B=B, chunk_off=lo)
+            sketches[i] = sk
+            return torch.cat([sk.percentiles(q), sk.mean().float()[:, None]], 1)
+
+        table = ds.gather_rows(ds.run(B, shard, group=trios))
+        nq = len(tuple(q))
+        live = [sk for sk in sketches if sk is not None]
+        return {"percentiles": table[:, :nq], "average": table[:, nq], "sketch": live[0] if len(live) == 1 else live,
+                "exchange": ds.last_exchange}

@@ -251,8 +251,9 @@ class VarModel:
         return ops.zero_mask_from_flags(self.fix_megno, self.fix_megno2, self.include_mmr, self.include_nan,
                                         self.include_eplusminus)
 
-    def _plan(self, zero_mask=None):
-        return ops.get_plan(self.zero_mask() if zero_mask is None else zero_mask, self.lowest, fix_megno=self.fix_megno, **self._arch)
+    def _plan(self, zero_mask=None, device=None):
+        return ops.get_plan(self.zero_mask() if zero_mask is None else zero_mask, self.lowest, device=device, fix_megno=self.fix_megno,
+                            **self._arch)
 
     @property
     def _latent(self):

@@ -107,6 +107,10 @@ typedef struct bnn_grid {
                         (eps, eps_in, eps_sum all NULL); explicit eps_in/eps_sum imply noisy regardless          */
     int32_t engine;  /* 0 = choose (the pretrained network at T % 4 == 0, T >= 8: its register-resident kernels; else the generic engine);
                         1 = the generic engine whatever the shape (cross-checks, measurements)               */
+    int64_t chunk_B;   /* nchunks > 1 with the batch sharded over devices: the chunks partition the WHOLE batch of chunk_B systems  */
+    int64_t chunk_off; /* (torch.chunk semantics, chunk size ceil(chunk_B / nchunks)), of which this call holds rows
+                          [chunk_off, chunk_off + B); a draw covers the part of its chunk that lies in the shard.  0, 0 = the call
+                          holds the whole batch.  Results are then bit-identical to the unsharded call with system_id0 = chunk_off. */
 } bnn_grid;
 
 /* SWAGModel.sample_weights (spock_reg_model.py:815-838), J draws at once.

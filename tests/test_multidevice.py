@@ -1,0 +1,95 @@
+"""One process, several GPUs (bnn_chaos_model_amd/multidevice.py): the partition / exchange logic on the CPU, and -- on the one-GPU box --
+several logical shards on the same card, which must reproduce the single-shard result bit for bit (global Philox ids, chunks of the
+whole batch).  Reference call sites: figures/multiswag_5_planet.py:61, 280-298 (a single-process script)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def _cpu_set(n):
+    from bnn_chaos_model_amd.multidevice import DeviceSet
+    ds = object.__new__(DeviceSet)
+    ds.devices, ds._replicas, ds.last_exchange = [torch.device("cpu")] * n, {}, None
+    return ds
+
+
+@pytest.mark.parametrize("B,n,group", [(10, 3, 1), (9, 3, 3), (2, 4, 1), (30, 8, 3), (7, 1, 1)])
+def test_partition_and_exchange_on_cpu(B, n, group):
+    ds = _cpu_set(n)
+    bounds = ds.bounds(B, group)
+    assert bounds[0][0] == 0 and bounds[-1][1] == B and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    assert all((hi - lo) % group == 0 for lo, hi in bounds)
+    rows = torch.arange(B // group, dtype=torch.float64)[:, None] * torch.ones(1, 4, dtype=torch.float64)
+    seen = []
+    def fn(i, dev, lo, hi):
+        seen.append((i, lo, hi))
+        return rows[lo // group: hi // group].clone()
+    parts = ds.run(B, fn, group=group)
+    assert [p is None for p in parts] == [hi == lo for lo, hi in bounds]      # empty shards (more devices than simulations) launch nothing
+    got = ds.gather_rows(parts)
+    assert torch.equal(got, rows) and ds.last_exchange is not None
+    st = ds.replicate("k", (torch.ones(3), torch.arange(4)))
+    assert len(st) == n and all(torch.equal(s[0], torch.ones(3)) for s in st)
+    assert ds.replicate("k", (torch.ones(3),)) is not st
+
+
+@pytest.fixture(scope="module")
+def fr(tmp_path_factory):
+    from bnn_chaos_model_amd import checkpoint
+    from bnn_chaos_model_amd.regression import FeatureRegressor
+    d = tmp_path_factory.mktemp("pretrained_md")
+    for i in (0, 12):
+        z = load_golden(f"swag_v50_{i}.npz")
+        checkpoint.write_swag_file(str(d / f"steps=300000_v50_{i:02d}_output.pkl"), json.loads(str(z["hparams_json"])),
+                                   json.loads(str(z["swa_params_json"])), torch.tensor(z["w_avg"]), torch.tensor(z["w2_avg"]),
+                                   torch.tensor(z["pre_D"]))
+    return FeatureRegressor(cuda=True, filebase=str(d / "*v50*output.pkl"), sort=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rng", ("torch", "philox"))
+def test_logical_shards_reproduce_the_single_shard_result(fr, rng, inputs):
+    """devices=[0, 0, 0]: three shards of a 77-system batch (chunks = 10: ragged chunks that straddle the shard boundaries) on one
+    card == one shard, bit for bit, with the reference's RNG order and with in-kernel Philox; likewise the default (all visible)."""
+    X = torch.tensor(np.tile(inputs["slow"], (3, 1, 1))[:77])
+    outs = {}
+    for name, devs in (("one", [0]), ("three", [0, 0, 0]), ("seven", [0] * 7), ("default", None)):
+        np.random.seed(5); torch.manual_seed(5)
+        outs[name] = fr.sample_full_swag_many(X, samples=4, chunks=10, rng=rng, philox_seed=17, draw_id0=40, system_id0=1000, devices=devs)
+        assert outs[name].shape == (4, 77, 2) and outs[name].device == X.device
+    assert torch.equal(outs["one"], outs["three"]) and torch.equal(outs["one"], outs["seven"]) and torch.equal(outs["one"], outs["default"])
+    # and the single-shard result is the loop of the reference's script (chunk by chunk through sample_full_swag), same seeds
+    if rng == "torch":
+        np.random.seed(5); torch.manual_seed(5)
+        loop = torch.cat([torch.cat([fr.sample_full_swag(Xp) for Xp in torch.chunk(X, 10)])[None] for _ in range(4)])
+        assert torch.equal(loop, outs["one"])
+
+
+@pytest.mark.gpu
+def test_bands_and_moments_over_logical_shards(fr, inputs):
+    from bnn_chaos_model_amd import ops
+    from bnn_chaos_model_amd.distributed import MultiSwagSharded
+    X = torch.tensor(np.tile(inputs["slow"], (4, 1, 1))[:120])          # 40 simulations x 3 trios
+    res = {}
+    for name, devs in (("one", [0]), ("four", [0, 0, 0, 0]), ("many", [0] * 6)):
+        np.random.seed(9)
+        res[name] = fr.predictive_bands(X, samples=64, chunks=10, trios=3, philox_seed=3, system_id0=300, samples_per_launch=16, devices=devs)
+    for name in ("four", "many"):
+        assert torch.equal(res["one"]["percentiles"], res[name]["percentiles"]) and torch.equal(res["one"]["average"], res[name]["average"])
+        assert "peer copies" in res[name]["exchange"]
+    assert res["one"]["percentiles"].shape == (40, 5)
+    # the dense grid through MultiSwagSharded(devices=...): moments and bands, against its own single-device form
+    wa, w2, pd = fr.ensemble_state()
+    seed_idx = torch.arange(24, dtype=torch.int32) % 2
+    xg = X.cuda()
+    single = MultiSwagSharded(wa, w2, pd, draws_per_launch=8)
+    m1 = single.predictive_moments(xg, 120, seed_idx, philox_seed=4)
+    q1 = single.predictive_quantiles(xg, 120, seed_idx, philox_seed=4, trios=3)
+    multi = MultiSwagSharded(wa, w2, pd, draws_per_launch=8, devices=[0, 0, 0])
+    assert torch.equal(m1, multi.predictive_moments(X, 120, seed_idx, philox_seed=4))       # x may live on the host
+    assert torch.equal(q1, multi.predictive_quantiles(xg, 120, seed_idx, philox_seed=4, trios=3))
+    assert MultiSwagSharded(wa, w2, pd, devices="all").predictive_moments(xg, 120, seed_idx, philox_seed=4).shape == (120, 4)

@@ -57,3 +57,19 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert c["gather_ms"] > 0 and 0 < c["kernel_ms_min"] <= c["kernel_ms_max"]
     assert c["gather_bytes_per_rank"] == 1000 * 6 * 4 and "whole simulations" in c["sharding"]
     assert r["value"] == pytest.approx(2 * 3000 * 4 * 2 / (r["ms_per_step"] * 2e-3), rel=1e-6)   # evals of BOTH ranks over the max-rank time
+
+
+def test_plain_multi_gpu_invocation_carries_the_named_config():
+    """`bench.py --gpus 2` with NO --workload (what a driver runs): the headline is configs[2] weak-scaled, and the line also carries
+    `named_config` = one step of BASELINE configs[3]'s per-GPU share (rehearsed here at 8 192 systems per rank, both ranks on cuda:0)."""
+    env = dict(os.environ, BNN_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", BNN_BENCH_NAMED_SYSTEMS="8192")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--systems", "4096", "--samples", "4", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--rendezvous-timeout", "60"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stderr[-2000:])
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and "configs[2]" in r["config"]["workload"]
+    nc = r["named_config"]
+    assert "configs[3]" in nc["workload"] and nc["draws"] == 3000 and nc["systems_per_gpu"] == 8192 and nc["steps"] == 1
+    assert nc["value"] == pytest.approx(2 * 8192 * 3000 / (nc["ms_per_step"] * 1e-3), rel=1e-6)
