@@ -62,8 +62,10 @@ int gen_build(int F, int H, int L, int depth_in, int depth_out, bool megno, GenA
         GenArch t = g;
         t.nwreg = nwreg;
         t.reg_in_lds = reg_in_lds;
-        for (int nw : {4, 2, 1})
+        for (int nw : {8, 4, 2, 1}) {   // eight waves (two per SIMD) only where the kernel fits 256 registers: the narrowest bucket
+            if (nw == 8 && (t.hq > 12 || t.fq != 11)) continue;
             if ((int64_t)(gen_shared_floats(t) + nw * gen_wave_floats(t)) * 4 <= LDS_BYTES) return nw;
+        }
         return 0;
     };
     const int w_all = waves_for(nfeat_regs + nreg_regs, 1), w_feat = waves_for(nfeat_regs, 0);

@@ -47,7 +47,7 @@ struct GenArch {
     int32_t lq, smq;              // latent groups ceil(L / 4), summary quads ceil(SM / 4)
     int32_t nin_blocks;           // Philox blocks of six normals per row of input noise: ceil(F / 6)
     int32_t reg_in_lds;           // 1: regress_nn's weight registers are in the LDS image too; 0: gathered from the flat vector
-    int32_t nwaves;               // waves per workgroup (4, 2 or 1) that the LDS budget allows
+    int32_t nwaves;               // waves per workgroup (8 for the narrowest bucket, else 4; 2 or 1 when the LDS budget forces it)
     int32_t lds_bytes;            // dynamic LDS of the launch
     int32_t off_inlv, off_sumlv;  // input_noise_logvar [F], summary_noise_logvar [SM]
     GenLayer layer[GEN_MAX_LAYERS];
@@ -59,10 +59,9 @@ int gen_build(int n_features, int hidden, int latent, int depth_in, int depth_ou
 
 // Per-wave LDS floats: pool state (mean, M2 per latent group, lane-major), Philox scratch, summaries, MEGNO partitions, and -- when
 // regress_nn's registers are not in the image -- a staging area for one block of them.
-BNN_HD inline int gen_eps_stride(const GenArch& g) { return 4 * ((2 * g.L + 3) / 4); }
-BNN_HD inline int gen_sum_stride(const GenArch& g) { return 4 * g.smq; }
+BNN_HD inline int gen_sum_stride(const GenArch& g) { return 4 * g.smq; }   // (the 2 L pool normals share the summaries' rows: 2 L <= SM)
 BNN_HD inline int gen_wave_floats(const GenArch& g) {
-    return 2 * g.lq * 256 + 16 * gen_eps_stride(g) + 16 * gen_sum_stride(g) + 128 + (g.reg_in_lds ? 0 : g.hq * 64);
+    return 2 * g.lq * 256 + 16 * gen_sum_stride(g) + 128 + (g.reg_in_lds ? 0 : g.hq * 64);
 }
 // Workgroup-shared LDS floats: weight registers (+ one pad register for the read-ahead), biases, noise scales.
 BNN_HD inline int gen_wimg_floats(const GenArch& g) { return (g.nwreg + 1) * 64; }

@@ -38,41 +38,12 @@ DEVINL void gen_load_row(const float* __restrict__ rp, f32x4 (&xr)[FQ]) {
     }
 }
 
-// 4 kk x NG MFMAs per input quad: input 4 kq + kk into neuron group q of the block (bias first, then inputs ascending).
-// The block's weight registers are requested a chunk of up to 16 at a time (one ds_read_b32 each, all of a chunk in flight
-// together) -- 16 rather than all NQI so that the widest bucket keeps 16 registers free.
-template <int NG, int NQI>
-DEVINL void gen_block(f32x4 (&acc)[4], const float* wp, const f32x4 (&in)[NQI], int nkq) {
-    constexpr int CH = NQI < 16 ? NQI : 16;
-    static_while<(NQI + CH - 1) / CH>([&](auto C) {
-        constexpr int k0 = C * CH;
-        if (k0 >= nkq) return false;
-        float wv[CH];
-        static_while<CH>([&](auto J) {
-            constexpr int kq = k0 + J;
-            if (kq >= NQI || kq >= nkq) return false;
-            wv[J] = wp[kq * 64];
-            return true;
-        });
-        static_while<CH>([&](auto J) {
-            constexpr int kq = k0 + J;
-            if (kq >= NQI || kq >= nkq) return false;
-            static_for<16>([&](auto A) {
-                constexpr int a = A, kk = a >> 2, q = a & 3;
-                if constexpr (q < NG) acc[q] = mfma4b<a>(wv[J], in[kq < NQI ? kq : 0][kk], acc[q]);
-            });
-            return true;
-        });
-        return true;
-    });
-}
-
 // nn.ReLU (lim = 0) or identity (lim = INT_MIN) as one integer max on the bit pattern.  The element goes through a scalar
 // parameter first: __builtin_bit_cast applied to a vector element directly reads element 0 (hipcc 7.2; bnn_forward.hip.h has the
 // same note) -- the first version of this routine replicated neuron 4g of every group.
 DEVINL float relu_lim1(float v, int lim) {
     const int b = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, b > lim ? b : lim);
+    return __builtin_bit_cast(float, __builtin_elementwise_max(b, lim));   // v_max_i32 (a compare + select otherwise: three instructions per element with the accumulator read)
 }
 DEVINL f32x4 relu_lim4(f32x4 v, int lim) {
     f32x4 o;
@@ -81,42 +52,96 @@ DEVINL f32x4 relu_lim4(f32x4 v, int lim) {
     return o;
 }
 
+// Register layout of an activation vector (so that every array index is a compile-time constant AND no select is ever needed):
+// a layer writes its FULL output blocks (16 neurons = 4 quads each) to quads 4 nb .. 4 nb + 3 and its LAST block -- whatever its index,
+// which is only known at run time -- to the last four quads of the array.  The next layer therefore reads its first
+// in_nfull = 4 (nblk_prev - 1) input quads from in[0 ..] and the remaining ntail = nkq - in_nfull (<= 4) from in[NQI - 4 ..].  x rows and
+// summaries are laid out naturally (in_nfull = nkq, ntail = 0).  Weight register kq of a block is the LOGICAL input quad kq either way.
+//
+// One output block: 4 kk x NG MFMAs per input quad -- input 4 kq + kk into neuron group q (bias first, then inputs ascending) --
+// accumulating straight into the block's output registers out[BASE .. BASE + 3].  The weight registers are requested a chunk of up to 16
+// at a time (one ds_read_b32 each, all of a chunk in flight together).
+template <int NG, int BASE, int NQI, int NQO>
+DEVINL void gen_block(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], int in_nfull, int ntail, const float* wp, const f32x4* bq, int lim) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[BASE + q] = bq[q];
+    float wt[4];
+    static_while<4>([&](auto J) {   // the tail quads' registers: logical quads in_nfull + j
+        constexpr int j = J;
+        if (j >= ntail) return false;
+        wt[j] = wp[(in_nfull + j) * 64];
+        return true;
+    });
+    constexpr int CH = NQI < 16 ? NQI : 16;
+    static_while<(NQI + CH - 1) / CH>([&](auto C) {
+        constexpr int k0 = C * CH;
+        if (k0 >= in_nfull) return false;
+        float wv[CH];
+        static_while<CH>([&](auto J) {
+            constexpr int kq = k0 + J;
+            if (kq >= NQI || kq >= in_nfull) return false;
+            wv[J] = wp[kq * 64];
+            return true;
+        });
+        static_while<CH>([&](auto J) {
+            constexpr int kq = k0 + J;
+            if (kq >= NQI || kq >= in_nfull) return false;
+            static_for<16>([&](auto A) {
+                constexpr int a = A, kk = a >> 2, q = a & 3;
+                if constexpr (q < NG) out[BASE + q] = mfma4b<a>(wv[J], in[kq < NQI ? kq : 0][kk], out[BASE + q]);
+            });
+            return true;
+        });
+        return true;
+    });
+    static_while<4>([&](auto J) {
+        constexpr int j = J;
+        if (j >= ntail) return false;
+        static_for<16>([&](auto A) {
+            constexpr int a = A, kk = a >> 2, q = a & 3;
+            if constexpr (q < NG) out[BASE + q] = mfma4b<a>(wt[j], in[NQI - 4 + j][kk], out[BASE + q]);
+        });
+        return true;
+    });
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[BASE + q] = relu_lim4(out[BASE + q], lim);
+}
+
 // One Linear (+ ReLU) for the wave's 64 rows; weight register (nb, kq) = LDS image entry [(wreg0 + nb * nkq + kq) * 64 + lane].
+// in_nfull: see the layout note above; the output's is 4 (nblk - 1).
 // TRIM: the last block issues only its live neuron groups (feature_nn: the hot loop); without it the padded groups are multiplied
 // by zero weights (regress_nn: once per 16 systems).
 DEVINL void gen_stage_block(const GenLayer ly, int nb, const float* __restrict__ We, float* stage, int lane);
 template <int NQI, int NQO, bool TRIM, bool STAGED = false>
-DEVINL void gen_layer(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLayer ly, const float* wimg, const float* bimg, int lane,
-                      const float* __restrict__ We = nullptr, float* stage = nullptr) {
-    const int nkq = ly.nkq, nblk = ly.nblk;
+DEVINL void gen_layer(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLayer ly, int in_nfull, const float* wimg, const float* bimg,
+                      int lane, const float* __restrict__ We = nullptr, float* stage = nullptr) {
+    const int nkq = ly.nkq, nblk = ly.nblk, ntail = nkq - in_nfull;
     const int lim = ly.relu ? 0 : (int)0x80000000;
-    for (int nb = 0; nb < nblk; ++nb) {
-        const float* wp = wimg + (size_t)(ly.wreg0 + nb * nkq) * 64 + lane;
+    const f32x4* bq = reinterpret_cast<const f32x4*>(bimg + ly.bias0);
+    auto wsrc = [&](int nb) -> const float* {
         if constexpr (STAGED) {
             if (ly.wreg0 < 0) {   // not in the LDS image: this block's registers come through the wave's staging area
                 __builtin_amdgcn_wave_barrier();
                 gen_stage_block(ly, nb, We, stage, lane);
                 __builtin_amdgcn_wave_barrier();
-                wp = stage + lane;
+                return stage + lane;
             }
         }
-        f32x4 acc[4];
-        const f32x4* bq = reinterpret_cast<const f32x4*>(bimg + ly.bias0 + 16 * nb);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = bq[q];
-        const int ng = (TRIM && nb == nblk - 1) ? ly.ng_last : 4;
-        if (ng == 4) gen_block<4>(acc, wp, in, nkq);
-        else if (ng == 3) gen_block<3>(acc, wp, in, nkq);
-        else if (ng == 2) gen_block<2>(acc, wp, in, nkq);
-        else gen_block<1>(acc, wp, in, nkq);
-        static_for<NQO / 4>([&](auto NB) {
-            constexpr int b = NB;
-            if (nb == b) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) out[4 * b + q] = relu_lim4(acc[q], lim);
-            }
-        });
-    }
+        return wimg + (size_t)(ly.wreg0 + nb * nkq) * 64 + lane;
+    };
+    static_while<NQO / 4 - 1>([&](auto NB) {   // the full blocks, at their natural quads
+        constexpr int nb = NB;
+        if (nb >= nblk - 1) return false;
+        gen_block<4, 4 * nb>(in, out, in_nfull, ntail, wsrc(nb), bq + 4 * nb, lim);
+        return true;
+    });
+    const float* wl = wsrc(nblk - 1);          // the last block, at the array's last four quads
+    const f32x4* bl = bq + 4 * (nblk - 1);
+    const int ng = TRIM ? ly.ng_last : 4;
+    if (ng == 4) gen_block<4, NQO - 4>(in, out, in_nfull, ntail, wl, bl, lim);
+    else if (ng == 3) gen_block<3, NQO - 4>(in, out, in_nfull, ntail, wl, bl, lim);
+    else if (ng == 2) gen_block<2, NQO - 4>(in, out, in_nfull, ntail, wl, bl, lim);
+    else gen_block<1, NQO - 4>(in, out, in_nfull, ntail, wl, bl, lim);
 }
 
 // A regress_nn layer whose registers did not fit the LDS image: block nb's registers are gathered from the flat vector (L2) into the
@@ -151,7 +176,10 @@ DEVINL void gen_merge(const GenMerge mg, float& ma, float& qa, float mb, float q
 }
 
 template <int FQ, int HQ>
-__global__ __launch_bounds__(256, 1) void bnn_forward_generic_kernel(const GenParams P) {
+// The narrowest bucket (41 features) fits 256 registers, so its workgroups are EIGHT waves (two per SIMD sharing one weight image: the partner wave's
+// MFMAs fill this wave's LDS / memory waits -- a single wave per SIMD spent a quarter of its cycles parked in s_waitcnt); the wider
+// buckets need the whole 512-register file and run one wave per SIMD.
+__global__ __launch_bounds__((HQ <= 12 && FQ == 11) ? 512 : 256, 1) void bnn_forward_generic_kernel(const GenParams P) {
     const FwdParams& p = P.f;
     const GenArch& G = *P.g;
     constexpr int NBLK_IN = FQ == 11 ? 7 : 14;   // Philox blocks of six normals per input row (41 / 82 columns)
@@ -228,11 +256,12 @@ __global__ __launch_bounds__(256, 1) void bnn_forward_generic_kernel(const GenPa
     const int T = p.T, ntiles = p.ntiles;
     const float nm1 = (float)(T - 1), nT = (float)T;
     const int64_t rowstride = (int64_t)T * F;
-    const int EPS = gen_eps_stride(G), SMS = gen_sum_stride(G);
+    const int SMS = gen_sum_stride(G);
     float* poolm = wave0 + (size_t)wave * gen_wave_floats(G);   // [lq][64 lanes][4] running means
     float* poolq = poolm + lq * 256;                            // [lq][64][4] running M2
-    float* epsscr = poolq + lq * 256;                           // [16 systems][EPS] pool normals
-    float* sumscr = epsscr + 16 * EPS;                          // [16][SMS] summaries
+    float* sumscr = poolq + lq * 256;                           // [16 systems][SMS] the pool normals (entries n, L + n), overwritten in place by
+                                                                // the summaries: the lane that consumes normal n of a system writes summary n
+    float* epsscr = sumscr;
     float* megscr = sumscr + 16 * SMS;                          // [64 lanes][2] MEGNO partitions
     float* stage = megscr + 128;                                // [hq][64] weight registers of one block (regress_nn layers outside the image)
     f32x4* poolm4 = reinterpret_cast<f32x4*>(poolm);
@@ -259,20 +288,30 @@ __global__ __launch_bounds__(256, 1) void bnn_forward_generic_kernel(const GenPa
         }
         f32x4 a[HQ], b[HQ];
         // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps, state in LDS
-        auto pool = [&](const f32x4 (&y)[HQ], float rcn) {
-            static_while<HQ>([&](auto GI) {
-                constexpr int g = GI;
-                if (g >= lq) return false;
-                f32x4 mean = poolm4[g * 64 + lane], m2 = poolq4[g * 64 + lane];
+        const int lat_nfull = 4 * (G.layer[G.n_feat - 1].nblk - 1);   // latent groups at their natural quads; the rest at the array's tail
+        auto welford = [&](const f32x4 y, int g, float rcn) {
+            f32x4 mean = poolm4[g * 64 + lane], m2 = poolq4[g * 64 + lane];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float dl = y[g][i] - mean[i];
-                    const float mn = fmaf(dl, rcn, mean[i]);
-                    m2[i] = fmaf(dl, y[g][i] - mn, m2[i]);
-                    mean[i] = mn;
-                }
-                poolm4[g * 64 + lane] = mean;
-                poolq4[g * 64 + lane] = m2;
+            for (int i = 0; i < 4; ++i) {
+                const float dl = y[i] - mean[i];
+                const float mn = fmaf(dl, rcn, mean[i]);
+                m2[i] = fmaf(dl, y[i] - mn, m2[i]);
+                mean[i] = mn;
+            }
+            poolm4[g * 64 + lane] = mean;
+            poolq4[g * 64 + lane] = m2;
+        };
+        auto pool = [&](const f32x4 (&y)[HQ], float rcn) {
+            static_while<HQ - 4>([&](auto GI) {
+                constexpr int g = GI;
+                if (g >= lat_nfull) return false;
+                welford(y[g], g, rcn);
+                return true;
+            });
+            static_while<4>([&](auto JI) {
+                constexpr int j = JI;
+                if (lat_nfull + j >= lq) return false;
+                welford(y[HQ - 4 + j], lat_nfull + j, rcn);
                 return true;
             });
         };
@@ -316,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void bnn_forward_generic_kernel(const GenPa
                     }
                 });
             }
-            gen_layer<FQ, HQ, true>(xr, a, G.layer[0], wimg, bimg, lane);
+            gen_layer<FQ, HQ, true>(xr, a, G.layer[0], G.layer[0].nkq, wimg, bimg, lane);
             // x of this tile is dead: fetch the next tile's rows into the same registers
             if constexpr (XPREF) {
                 const int tn = 4 * (it + 1) + ph0;
@@ -326,11 +365,11 @@ __global__ __launch_bounds__(256, 1) void bnn_forward_generic_kernel(const GenPa
             // the remaining Linear modules of feature_nn, ping-pong between the two register arrays
             int l = 1;
             for (; l + 1 < G.n_feat; l += 2) {
-                gen_layer<HQ, HQ, true>(a, b, G.layer[l], wimg, bimg, lane);
-                gen_layer<HQ, HQ, true>(b, a, G.layer[l + 1], wimg, bimg, lane);
+                gen_layer<HQ, HQ, true>(a, b, G.layer[l], 4 * (G.layer[l - 1].nblk - 1), wimg, bimg, lane);
+                gen_layer<HQ, HQ, true>(b, a, G.layer[l + 1], 4 * (G.layer[l].nblk - 1), wimg, bimg, lane);
             }
             if (l < G.n_feat) {
-                gen_layer<HQ, HQ, true>(a, b, G.layer[l], wimg, bimg, lane);
+                gen_layer<HQ, HQ, true>(a, b, G.layer[l], 4 * (G.layer[l - 1].nblk - 1), wimg, bimg, lane);
                 if (tv) pool(b, rcn);   // lanes past T sit the tile out
             } else if (tv) {
                 pool(a, rcn);
@@ -347,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void bnn_forward_generic_kernel(const GenPa
         const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + sysc;
         if (G.megno) { megscr[lane_t * 2] = gmean; megscr[lane_t * 2 + 1] = gm2; }
         if (!p.eps) {   // the system's 2 L pool normals: Philox blocks ph, ph + 4, ... of the quad's four lanes
-            for (int qd = ph; 4 * qd < EPS; qd += 4) *reinterpret_cast<f32x4*>(epsscr + sl * EPS + 4 * qd) = philox_eps4(grow, gsys, qd, p.seed);
+            for (int qd = ph; 2 * qd < L; qd += 4) *reinterpret_cast<f32x4*>(epsscr + sl * SMS + 4 * qd) = philox_eps4(grow, gsys, qd, p.seed);
         }
         __builtin_amdgcn_wave_barrier();   // the pool state and the normals written above are read across lanes below (one wave's LDS
                                            // operations complete in order: no wait is needed, only the compiler must not reorder)
@@ -369,8 +408,8 @@ __global__ __launch_bounds__(256, 1) void bnn_forward_generic_kernel(const GenPa
                 e1 = ep[n];
                 e2 = ep[L + n];
             } else {
-                e1 = epsscr[sl * EPS + n];
-                e2 = epsscr[sl * EPS + L + n];
+                e1 = epsscr[sl * SMS + n];
+                e2 = epsscr[sl * SMS + L + n];
             }
             const float sample_mu = m[0];
             const float sd = sqrtf(q2[0] / nm1);   // torch.std (unbiased)
@@ -437,19 +476,16 @@ __global__ __launch_bounds__(256, 1) void bnn_forward_generic_kernel(const GenPa
             a[kq] = *reinterpret_cast<const f32x4*>(sumscr + sl * SMS + 4 * kq);
             return true;
         });
-        float r0, r1;
+        float r0, r1;   // the two outputs are neurons 0, 1 of the last Linear's only (= last) block
         {
-            int l = G.n_feat;
-            for (; l + 1 < nl; l += 2) {
-                gen_layer<HQ, HQ, false, true>(a, b, G.layer[l], wimg, bimg, lane, We, stage);
-                gen_layer<HQ, HQ, false, true>(b, a, G.layer[l + 1], wimg, bimg, lane, We, stage);
+            int nfull = smq;   // the summary sits at its natural quads
+            for (int l = G.n_feat; l < nl; ++l) {
+                gen_layer<HQ, HQ, false, true>(a, b, G.layer[l], nfull, wimg, bimg, lane, We, stage);
+                nfull = 4 * (G.layer[l].nblk - 1);
+#pragma unroll
+                for (int i = 0; i < HQ; ++i) a[i] = b[i];
             }
-            if (l < nl) {
-                gen_layer<HQ, HQ, false, true>(a, b, G.layer[l], wimg, bimg, lane, We, stage);
-                r0 = b[0][0]; r1 = b[0][1];
-            } else {
-                r0 = a[0][0]; r1 = a[0][1];
-            }
+            r0 = a[HQ - 4][0]; r1 = a[HQ - 4][1];
         }
         if (ph == 0 && valid) {
             const f32x2 ms = soft_clamp2(r0, r1, p.std_lo, p.std_span);
