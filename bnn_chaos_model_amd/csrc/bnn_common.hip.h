@@ -193,6 +193,50 @@ DEVINL f32x2 soft_clamp2(float r0, float r1, float std_lo, float std_span) {
     return o;
 }
 
+// compute_summary_stats for one latent (:420-431), op for op: torch.std (unbiased) from the pooled M2, **2, the two standard errors,
+// the two sampled moments, sqrt(abs(.) + EPSILON).  One routine for the three forward kernels (fp32, reduced precision, generic).
+DEVINL void sampled_moments(float sample_mu, float m2sum, float e1, float e2, float nm1, float nT, float& mu_s, float& sd_s) {
+    const float sd = sqrtf(m2sum / nm1);       // torch.std (unbiased)
+    const float sample_var = sd * sd;          // **2
+    const float std_in_mu = sqrtf(sample_var / nT);
+    const float std_in_var = sqrtf((2.0f * (sample_var * sample_var)) / nm1);
+    mu_s = e1 * std_in_mu + sample_mu;
+    const float var_s = e2 * std_in_var + sample_var;
+    sd_s = sqrtf(fabsf(var_s) + 1e-5f);        // EPSILON (:337)
+}
+
+// regress_nn of the pretrained network (40 (42) -> 40 -> 40 -> 2) for the 16 systems of a wave-batch on v_mfma_f32_16x16x4_f32 (exact
+// fp32): column c = lane & 15 <-> system, lane group g = lane >> 4 <-> k within a k-step.  skeep[ks] = this lane's B operand of k-step ks
+// of regress_nn.0 (kmap_summary; summary noise already added), f2frag = the gathered operand fragments [Lay::NF2][64] in LDS
+// (bnn_tables.cpp).  Returns the accumulator of regress_nn.4: [0], [1] = the two pre-clamp outputs in lanes g = 0.
+template <bool MEGNO>
+DEVINL f32x4 regress16(const float (&skeep)[Lay<MEGNO>::NK4], const float* f2frag, int lane) {
+    using Y = Lay<MEGNO>;
+    const float* f2l = f2frag + lane;
+    auto W2f = [&](int f) { return f2l[f * 64]; };
+    f32x4 a4[3], a5[3], a6;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+        a4[mt] = (f32x4){W2f(Y::F_B4 + mt * 4), W2f(Y::F_B4 + 1 + mt * 4), W2f(Y::F_B4 + 2 + mt * 4), W2f(Y::F_B4 + 3 + mt * 4)};
+#pragma unroll
+    for (int ks = 0; ks < Y::NK4; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(Y::F_L4 + ks * 3 + mt), skeep[ks], a4[mt]);
+    a4[0] = relu4(a4[0]); a4[1] = relu4(a4[1]); a4[2] = relu4<2>(a4[2]);
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+        a5[mt] = (f32x4){W2f(Y::F_B5 + mt * 4), W2f(Y::F_B5 + 1 + mt * 4), W2f(Y::F_B5 + 2 + mt * 4), W2f(Y::F_B5 + 3 + mt * 4)};
+#pragma unroll
+    for (int ks = 0; ks < NKH; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(Y::F_L5 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
+    a5[0] = relu4(a5[0]); a5[1] = relu4(a5[1]); a5[2] = relu4<2>(a5[2]);
+    a6 = (f32x4){W2f(Y::F_B6), W2f(Y::F_B6 + 1), W2f(Y::F_B6 + 2), W2f(Y::F_B6 + 3)};
+#pragma unroll
+    for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(Y::F_L6 + ks), a5[ks >> 2][ks & 3], a6);
+    return a6;
+}
+
 // ------------------------------------------------------------------------------------------------
 // SWAG draw of rows [i0, i0+64) by one wave (SWAGModel.sample_weights, spock_reg_model.py:815-838).
 // pre_D rows are staged through a wave-private LDS slab, MAXK columns at a time (for K <= 32 the read is one contiguous

@@ -442,14 +442,8 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            float sample_mu = mymean[j];
-            float sd = sqrtf(mym2[j] / nm1);   // torch.std (unbiased)
-            float sample_var = sd * sd;        // **2
-            float std_in_mu = sqrtf(sample_var / nT);
-            float std_in_var = sqrtf((2.0f * (sample_var * sample_var)) / nm1);
-            float mu_s = e1[j] * std_in_mu + sample_mu;
-            float var_s = e2[j] * std_in_var + sample_var;
-            float sd_s = sqrtf(fabsf(var_s) + 1e-5f);  // EPSILON (:337)
+            float mu_s, sd_s;
+            sampled_moments(mymean[j], mym2[j], e1[j], e2[j], nm1, nT, mu_s, sd_s);
             sumscr[sl * S2 + 5 * ph + j] = mu_s;
             sumscr[sl * S2 + L + 5 * ph + j] = sd_s;
             if (p.summary && valid) {
@@ -493,28 +487,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                 }
             }
         }
-        const float* f2l = f2frag + lane;
-        auto W2f = [&](int f) { return f2l[f * 64]; };
-        f32x4 a4[3], a5[3], a6;
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt)
-            a4[mt] = (f32x4){W2f(Y::F_B4 + mt * 4), W2f(Y::F_B4 + 1 + mt * 4), W2f(Y::F_B4 + 2 + mt * 4), W2f(Y::F_B4 + 3 + mt * 4)};
-#pragma unroll
-        for (int ks = 0; ks < Y::NK4; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(Y::F_L4 + ks * 3 + mt), skeep[ks], a4[mt]);
-        a4[0] = relu4(a4[0]); a4[1] = relu4(a4[1]); a4[2] = relu4<2>(a4[2]);
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt)
-            a5[mt] = (f32x4){W2f(Y::F_B5 + mt * 4), W2f(Y::F_B5 + 1 + mt * 4), W2f(Y::F_B5 + 2 + mt * 4), W2f(Y::F_B5 + 3 + mt * 4)};
-#pragma unroll
-        for (int ks = 0; ks < NKH; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(Y::F_L5 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
-        a5[0] = relu4(a5[0]); a5[1] = relu4(a5[1]); a5[2] = relu4<2>(a5[2]);
-        a6 = (f32x4){W2f(Y::F_B6), W2f(Y::F_B6 + 1), W2f(Y::F_B6 + 2), W2f(Y::F_B6 + 3)};
-#pragma unroll
-        for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(Y::F_L6 + ks), a5[ks >> 2][ks & 3], a6);
+        const f32x4 a6 = regress16<MEGNO>(skeep, f2frag, lane);
         if (g == 0 && validb) {
             // predict_instability + soft_clamp (:295-296, :437-442)
             const float r0 = a6[0], r1 = a6[1];

@@ -411,14 +411,8 @@ __global__ __launch_bounds__((HQ <= 12 && FQ == 11) ? 512 : 256, 1) void bnn_for
                 e1 = epsscr[sl * SMS + n];
                 e2 = epsscr[sl * SMS + L + n];
             }
-            const float sample_mu = m[0];
-            const float sd = sqrtf(q2[0] / nm1);   // torch.std (unbiased)
-            const float sample_var = sd * sd;      // **2
-            const float std_in_mu = sqrtf(sample_var / nT);
-            const float std_in_var = sqrtf((2.0f * (sample_var * sample_var)) / nm1);
-            const float mu_s = e1 * std_in_mu + sample_mu;
-            const float var_s = e2 * std_in_var + sample_var;
-            const float sd_s = sqrtf(fabsf(var_s) + 1e-5f);  // EPSILON (:337)
+            float mu_s, sd_s;
+            sampled_moments(m[0], q2[0], e1, e2, nm1, nT, mu_s, sd_s);
             sumscr[sl * SMS + n] = mu_s;
             sumscr[sl * SMS + L + n] = sd_s;
             if (p.summary && valid) {

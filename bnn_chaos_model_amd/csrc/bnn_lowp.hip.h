@@ -472,13 +472,8 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
                 } else {
                     e1 = epsscr[slot * S2 + n]; e2 = epsscr[slot * S2 + L + n];
                 }
-                float sd = sqrtf(msum / nm1);
-                float sample_var = sd * sd;
-                float std_in_mu = sqrtf(sample_var / nT);
-                float std_in_var = sqrtf((2.0f * (sample_var * sample_var)) / nm1);
-                float mu_s = e1 * std_in_mu + sample_mu;
-                float var_s = e2 * std_in_var + sample_var;
-                float sd_s = sqrtf(fabsf(var_s) + 1e-5f);
+                float mu_s, sd_s;
+                sampled_moments(sample_mu, msum, e1, e2, nm1, nT, mu_s, sd_s);
                 sumscr[slot * S2 + n] = mu_s;
                 sumscr[slot * S2 + L + n] = sd_s;
                 if (p.summary && valid) {
@@ -496,26 +491,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
         float skeep[10];
 #pragma unroll
         for (int ks = 0; ks < 10; ++ks) skeep[ks] = sumscr[c * S2 + kmap_summary(ks, g)];
-        const float* f2l = f2frag + lane;
-        auto W2f = [&](int f) { return f2l[f * 64]; };
-        f32x4 a4[3], a5[3], a6;
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt) a4[mt] = (f32x4){W2f(70 + mt * 4), W2f(71 + mt * 4), W2f(72 + mt * 4), W2f(73 + mt * 4)};
-#pragma unroll
-        for (int ks = 0; ks < 10; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(ks * 3 + mt), skeep[ks], a4[mt]);
-        a4[0] = relu4(a4[0]); a4[1] = relu4(a4[1]); a4[2] = relu4<2>(a4[2]);
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt) a5[mt] = (f32x4){W2f(82 + mt * 4), W2f(83 + mt * 4), W2f(84 + mt * 4), W2f(85 + mt * 4)};
-#pragma unroll
-        for (int ks = 0; ks < NKH; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(30 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
-        a5[0] = relu4(a5[0]); a5[1] = relu4(a5[1]); a5[2] = relu4<2>(a5[2]);
-        a6 = (f32x4){W2f(94), W2f(95), W2f(96), W2f(97)};
-#pragma unroll
-        for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(60 + ks), a5[ks >> 2][ks & 3], a6);
+        const f32x4 a6 = regress16<false>(skeep, f2frag, lane);   // the one routine of the fp32 kernel (bnn_common.hip.h)
         if (g == 0 && validb) {
             const f32x2 ms = soft_clamp2(a6[0], a6[1], p.std_lo, p.std_span);
             const int64_t o = (r * p.B + sysb) * 2;

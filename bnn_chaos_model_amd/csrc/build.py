@@ -72,23 +72,30 @@ def build(force=False, verbose=False, extra=(), out=None):
     except OSError:
         same_flags = False
     if not same_flags:
+        # objects compiled under other flags are not reusable: drop them, and write the stamp only AFTER every unit has compiled (a failed
+        # or interrupted build must not leave a stamp that vouches for a mix of old and new objects)
         force = True
-        with open(stamp_file, "w") as f:
-            f.write(flags_stamp)
+        for name in os.listdir(objdir):
+            if name.endswith(".o") or name == "FLAGS":
+                os.remove(os.path.join(objdir, name))
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         if not force and out is None and os.path.exists(obj) and os.path.getmtime(obj) > max(_mtime(src), hdr_t):
             return obj
-        cmd = [cc] + CFLAGS + UNIT_FLAGS.get(src, []) + list(extra) + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
+        cmd = [cc] + CFLAGS + UNIT_FLAGS.get(src, []) + list(extra) + build_flags_define + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=HERE)
         return obj
 
+    # a build with extra switches names itself: bnn_build_flags() returns them, bench.py writes them into its JSON line
+    build_flags_define = ['-DBNN_BUILD_FLAGS="%s"' % " ".join(a[2:] if a.startswith("-D") else a for a in extra)] if extra else []
     workers = min(len(SRCS), max(1, (os.cpu_count() or 2)))
     with ThreadPoolExecutor(workers) as ex:
         objs = list(ex.map(compile_one, SRCS))
+    with open(stamp_file, "w") as f:
+        f.write(flags_stamp)
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", so + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -172,7 +172,8 @@ class VarModel:
         self.include_nan = hparams["include_nan"]
         self.include_eplusminus = hparams.get("include_eplusminus", True)
         self._summary_kl = 0.0
-        self._cur_summary = None
+        self._last_forward = None
+        self._cur_summary_cache = None
         self.ssX = None
         self.ssy = None
         self.training = True
@@ -181,6 +182,18 @@ class VarModel:
         self.rng = "torch"
         self.philox_seed = 0
         self._philox_calls = 0
+
+    # forward()'s side effect `self._cur_summary = summary_stats` (:512): the kernels do not write the summary unless asked, so it is
+    # produced on demand by re-running the last forward with its debug output (same weights, same noise).  `latents` (:433) and
+    # `_summary_kl` (:515-520) are read by the out-of-scope feature_importance.py / the training loss only and stay None / 0.
+    @property
+    def _cur_summary(self):
+        if self._cur_summary_cache is None and self._last_forward is not None:
+            xg, Wg, eps, eps_in, eps_sum, noisy, did, plan = self._last_forward
+            _, _, summ = ops.forward(xg, Wg, eps=eps, eps_in=eps_in, eps_sum=eps_sum, philox_seed=self.philox_seed, draw_id0=did, plan=plan,
+                                     debug=True, noisy=noisy)
+            self._cur_summary_cache = summ[0]
+        return self._cur_summary_cache
 
     # ---- nn.Module-like conveniences used by the evaluation scripts --------------------------------------------
     @property
@@ -251,6 +264,16 @@ class VarModel:
         return ops.zero_mask_from_flags(self.fix_megno, self.fix_megno2, self.include_mmr, self.include_nan,
                                         self.include_eplusminus)
 
+    def _op_args(self):
+        """(zero_mask, lowest_std, net) as the torch.ops.bnn_chaos.* entry points take them (torch_ops.py)."""
+        a = self._arch
+        return self.zero_mask(), float(self.lowest), [a["n_features"], a["hidden"], a["latent"], a["depth_in"], a["depth_out"], int(self.fix_megno)]
+
+    @staticmethod
+    def _tops():
+        from . import torch_ops  # noqa: F401  (registers torch.ops.bnn_chaos.*)
+        return torch.ops.bnn_chaos
+
     def _plan(self, zero_mask=None, device=None):
         return ops.get_plan(self.zero_mask() if zero_mask is None else zero_mask, self.lowest, device=device, fix_megno=self.fix_megno,
                             **self._arch)
@@ -294,7 +317,7 @@ class VarModel:
     def zero_eplusminus(self, x):
         x = x.clone(); x[..., self.eplusminus_location] = 0; return x
 
-    def _forward_gpu(self, x, W, noisy, want_debug=False, plan=None):
+    def _forward_gpu(self, x, W, noisy, want_debug=False, plan=None, record=False):
         """x [B,T,41] on any device, W [1,d] -> (out[B,2] on x.device, pre, summ)."""
         self._check_x(x)
         plan = plan or self._plan()
@@ -315,12 +338,22 @@ class VarModel:
             if noisy:
                 eps_in = eps_in[None].to(g).contiguous()
                 eps_sum = eps_sum[None].to(g).contiguous()
-            res = ops.forward(xg, W.to(g), eps=eps, eps_in=eps_in, eps_sum=eps_sum, plan=plan, debug=want_debug)
+            did = 0
         else:
-            res = ops.forward(xg, W.to(g), philox_seed=self.philox_seed, draw_id0=self._next_philox_id(),
-                              plan=plan, debug=want_debug, noisy=noisy)
-        if want_debug:
-            return tuple(r[0].to(dev_in) for r in res)
+            did = self._next_philox_id()
+        Wg = W.to(g)
+        if record:   # what the lazily evaluated side effect (_cur_summary, :512) needs to re-run this forward with its debug outputs
+            self._last_forward = (xg, Wg, eps, eps_in, eps_sum, noisy, did, plan)
+            self._cur_summary_cache = None
+        if want_debug or plan is not self._plan():   # debug outputs / a plan other than the model's own (compute_summary_stats): direct
+            res = ops.forward(xg, Wg, eps=eps, eps_in=eps_in, eps_sum=eps_sum, philox_seed=self.philox_seed, draw_id0=did, plan=plan,
+                              debug=want_debug, noisy=noisy)
+            if want_debug:
+                return tuple(r[0].to(dev_in) for r in res)
+            return res[0].to(dev_in)
+        mask, lowest, net = self._op_args()
+        with torch.cuda.device(g):
+            res = self._tops().forward(xg, Wg, eps, eps_in, eps_sum, 1, bool(noisy), int(self.philox_seed), int(did), 0, mask, lowest, net)
         return res[0].to(dev_in)
 
     # ---- reference API -----------------------------------------------------------------------------------------
@@ -353,7 +386,7 @@ class VarModel:
         """VarModel.forward (:486-528) with the currently loaded weights -> cat(mu, std) [B,2] on x.device."""
         if self.random_sample:
             raise NotImplementedError("random_sample (training-time augmentation) is not part of the inference path")
-        return self._forward_gpu(x, self._w[None], noisy=bool(noisy_val))
+        return self._forward_gpu(x, self._w[None], noisy=bool(noisy_val), record=True)
 
     def sample(self, x, samples=10):
         """VarModel.sample (:530-545): mean over `samples` noisy forwards of mu + N(0,1)*std -> float64 ndarray [B].
@@ -417,13 +450,15 @@ class SWAGModel(VarModel):
         wa, w2, pd = self._state_gpu()
         g = wa.device
         idx = torch.zeros(1, dtype=torch.int32, device=g)
-        if self.rng == "torch":
-            z1, z2 = self._draw_noise()
-            W = ops.swag_draw(wa, w2, pd, idx, z1.to(g).contiguous(), z2.reshape(1, -1).to(g).contiguous(), scale=scale,
-                              plan=self._plan())
-        else:
-            W = ops.swag_draw(wa, w2, pd, idx, scale=scale, philox_seed=self.philox_seed, draw_id0=self._next_philox_id(),
-                              plan=self._plan())
+        mask, lowest, net = self._op_args()
+        with torch.cuda.device(g):
+            if self.rng == "torch":
+                z1, z2 = self._draw_noise()
+                W = self._tops().swag_draw(wa, w2, pd, idx, z1.to(g).contiguous(), z2.reshape(1, -1).to(g).contiguous(), float(scale), 0, 0,
+                                           mask, lowest, net)
+            else:
+                W = self._tops().swag_draw(wa, w2, pd, idx, None, None, float(scale), int(self.philox_seed), int(self._next_philox_id()),
+                                           mask, lowest, net)
         self.load(W[0])
 
     def forward_swag(self, x, scale=0.5):
@@ -445,14 +480,20 @@ class SWAGModel(VarModel):
             e2 = torch.randn(B, self._latent, device=dev_in)             # :427
             eps = torch.stack([e1, e2], dim=1)[None].to(g).contiguous()
             z1g, z2g = z1.to(g).contiguous(), z2.reshape(1, -1).to(g).contiguous()
-            out = ops.multiswag(xg, wa, w2, pd, idx, z1g, z2g, eps, scale=scale, plan=self._plan())
+            mask, lowest, net = self._op_args()
+            with torch.cuda.device(g):
+                out = self._tops().multiswag(xg, wa, w2, pd, idx, z1g, z2g, eps, 1, float(scale), 0, 0, 0, mask, lowest, net)
             # the reference leaves the sampled weights loaded in the module (:838)
             plan = self._plan()
             self._pending_draw = lambda: ops.swag_draw(wa, w2, pd, idx, z1g, z2g, scale=scale, plan=plan)[0]
         else:
             did, seed, plan = self._next_philox_id(), self.philox_seed, self._plan()
-            out = ops.multiswag(xg, wa, w2, pd, idx, scale=scale, philox_seed=seed, draw_id0=did, plan=plan)
+            mask, lowest, net = self._op_args()
+            with torch.cuda.device(g):
+                out = self._tops().multiswag(xg, wa, w2, pd, idx, None, None, None, 1, float(scale), int(seed), int(did), 0, mask, lowest, net)
             self._pending_draw = lambda: ops.swag_draw(wa, w2, pd, idx, scale=scale, philox_seed=seed, draw_id0=did, plan=plan)[0]
+        self._last_forward = None          # (_cur_summary belongs to forward(); forward_swag_fast does not set it, :878-908)
+        self._cur_summary_cache = None
         return out[0].to(dev_in)
 
 

@@ -1,12 +1,14 @@
 """PyTorch custom-op registration of the hot-path entry points (torch.ops.bnn_chaos.*): swag_draw, forward, multiswag,
 multiswag_moments, multiswag_stats.
 
-BASELINE.json's north_star asks for "PyTorch-ROCm custom ops": these are thin torch.library wrappers over
+BASELINE.json's north_star asks for "PyTorch-ROCm custom ops": these are torch.library wrappers over
 bnn_chaos_model_amd.ops (ctypes -> C ABI -> HIP kernels) with shape-only fake implementations, so the ops can be
 called from torch code, traced by torch.export / captured in HIP graphs by the caller, and show up by name in profiles.
-Importing this module registers them; nothing else in the package depends on it.
+The module surface routes through them: VarModel.forward, SWAGModel.sample_weights and SWAGModel.forward_swag_fast
+(spock_reg_model.py) call torch.ops.bnn_chaos.forward / swag_draw / multiswag.  The network (`net` = [n_features, hidden, latent,
+depth_in, depth_out, fix_megno]; None = the pretrained ensemble's), its column mask and its clamp floor select the plan.
 """
-from typing import Optional
+from typing import List, Optional
 
 import torch
 
@@ -15,43 +17,54 @@ from . import ops
 LIB = "bnn_chaos"
 
 
+def _plan(zero_mask, lowest_std, net):
+    if net is None:
+        return ops.get_plan(zero_mask, lowest_std)
+    return ops.get_plan(zero_mask, lowest_std, fix_megno=bool(net[5]), n_features=net[0], hidden=net[1], latent=net[2], depth_in=net[3],
+                        depth_out=net[4])
+
+
 @torch.library.custom_op(f"{LIB}::swag_draw", mutates_args=())
 def swag_draw(w_avg: torch.Tensor, w2_avg: torch.Tensor, pre_D: torch.Tensor, seed_idx: torch.Tensor,
-              z1: Optional[torch.Tensor], z2: Optional[torch.Tensor], scale: float, philox_seed: int, draw_id0: int) -> torch.Tensor:
+              z1: Optional[torch.Tensor], z2: Optional[torch.Tensor], scale: float, philox_seed: int, draw_id0: int,
+              zero_mask: int = ops.V50_ZERO_MASK, lowest_std: float = 0.5, net: Optional[List[int]] = None) -> torch.Tensor:
     """SWAGModel.sample_weights for J draws (spock_reg_model.py:815-838) -> W[J,d]."""
-    return ops.swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1, z2, scale=scale, philox_seed=philox_seed, draw_id0=draw_id0)
+    return ops.swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1, z2, scale=scale, philox_seed=philox_seed, draw_id0=draw_id0,
+                         plan=_plan(zero_mask, lowest_std, net))
 
 
 @swag_draw.register_fake
-def _(w_avg, w2_avg, pre_D, seed_idx, z1, z2, scale, philox_seed, draw_id0):
+def _(w_avg, w2_avg, pre_D, seed_idx, z1, z2, scale, philox_seed, draw_id0, zero_mask=ops.V50_ZERO_MASK, lowest_std=0.5, net=None):
     return w_avg.new_empty((seed_idx.numel(), w_avg.shape[1]))
 
 
 @torch.library.custom_op(f"{LIB}::forward", mutates_args=())
 def forward(x: torch.Tensor, W: torch.Tensor, eps: Optional[torch.Tensor], eps_in: Optional[torch.Tensor],
             eps_sum: Optional[torch.Tensor], nchunks: int, noisy: bool, philox_seed: int, draw_id0: int,
-            system_id0: int) -> torch.Tensor:
+            system_id0: int, zero_mask: int = ops.V50_ZERO_MASK, lowest_std: float = 0.5, net: Optional[List[int]] = None) -> torch.Tensor:
     """VarModel.forward (spock_reg_model.py:486-528) for materialised weights -> [J/nchunks, B, 2]."""
     return ops.forward(x, W, eps, eps_in, eps_sum, nchunks=nchunks, noisy=noisy, philox_seed=philox_seed, draw_id0=draw_id0,
-                       system_id0=system_id0)
+                       system_id0=system_id0, plan=_plan(zero_mask, lowest_std, net))
 
 
 @forward.register_fake
-def _(x, W, eps, eps_in, eps_sum, nchunks, noisy, philox_seed, draw_id0, system_id0):
+def _(x, W, eps, eps_in, eps_sum, nchunks, noisy, philox_seed, draw_id0, system_id0, zero_mask=ops.V50_ZERO_MASK, lowest_std=0.5, net=None):
     return x.new_empty((W.shape[0] // nchunks, x.shape[0], 2))
 
 
 @torch.library.custom_op(f"{LIB}::multiswag", mutates_args=())
 def multiswag(x: torch.Tensor, w_avg: torch.Tensor, w2_avg: torch.Tensor, pre_D: torch.Tensor, seed_idx: torch.Tensor,
               z1: Optional[torch.Tensor], z2: Optional[torch.Tensor], eps: Optional[torch.Tensor], nchunks: int, scale: float,
-              philox_seed: int, draw_id0: int, system_id0: int) -> torch.Tensor:
+              philox_seed: int, draw_id0: int, system_id0: int, zero_mask: int = ops.V50_ZERO_MASK, lowest_std: float = 0.5,
+              net: Optional[List[int]] = None) -> torch.Tensor:
     """Fused forward_swag_fast over the MC loop (spock_reg_model.py:878-908, figures/multiswag_5_planet.py:295-298)."""
     return ops.multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1, z2, eps, nchunks=nchunks, scale=scale, philox_seed=philox_seed,
-                         draw_id0=draw_id0, system_id0=system_id0)
+                         draw_id0=draw_id0, system_id0=system_id0, plan=_plan(zero_mask, lowest_std, net))
 
 
 @multiswag.register_fake
-def _(x, w_avg, w2_avg, pre_D, seed_idx, z1, z2, eps, nchunks, scale, philox_seed, draw_id0, system_id0):
+def _(x, w_avg, w2_avg, pre_D, seed_idx, z1, z2, eps, nchunks, scale, philox_seed, draw_id0, system_id0, zero_mask=ops.V50_ZERO_MASK,
+      lowest_std=0.5, net=None):
     return x.new_empty((seed_idx.numel() // nchunks, x.shape[0], 2))
 
 

@@ -226,6 +226,12 @@ def test_surface_accepts_checkpoints_of_other_shapes(tmp_path, ops):
             o = m(x, noisy_val=noisy)
             nbad, mx = close_report(o.numpy(), z[f"forward_noisy{int(noisy)}_out"])
             assert nbad == 0, (name, noisy, nbad, mx)
+            # forward()'s side effect self._cur_summary (:512: the summary before the summary noise), produced on demand
+            ref = z[f"forward_noisy{int(noisy)}_summary"]
+            cs = m._cur_summary
+            assert cs.shape == ref.shape
+            nbad, mx = close_report(cs.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+            assert nbad == 0, (name, noisy, nbad, mx)
         np.random.seed(0); torch.manual_seed(0)
         s = m.sample(x, samples=3)
         assert s.shape == (x.shape[0],) and np.isfinite(s).all()

@@ -413,3 +413,33 @@ def test_sharded_bands_gather_gloo(n_sims, world):
         assert p.exitcode == 0
     want = np.stack([np.arange(n_sims, dtype=np.float32) * 10 + k for k in range(6)], 1)
     assert np.array_equal(got, want)
+
+
+def test_headline_kernels_use_no_scratch(N):
+    """The register-resident forward forms sit at 236-256 VGPRs under __launch_bounds__(256, 2): a compiler update or a small edit would
+    tip them into scratch silently.  Read the built library's code-object notes (scripts/resusage.py): the quiet and noisy forms of the
+    pretrained network (31 / 41 columns, workspace and in-prologue draw, statistics tail) and the reduced-precision forms must use
+    0 bytes of scratch and spill no VGPR; the fix_megno noisy form is known to spill 3 and is only bounded."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import resusage
+    ks = resusage.kernels(N.SO_PATH)
+    fwd = [k for k in ks if k["name"].startswith("bnn::bnn_forward_kernel<")]
+    assert len(fwd) >= 13
+    for k in fwd:
+        args = [a.strip() for a in k["name"].split("<", 1)[1].rstrip(">").split(",")]   # KIN, FUSED, NOISY, STATS, MEGNO, XNOISE
+        megno_noisy = args[2] == "true" and args[4] == "true"
+        assert k["vgpr"] <= 256 and k["agpr"] == 0, k
+        if megno_noisy:
+            assert k["scratch"] <= 32, k
+        else:
+            assert k["scratch"] == 0 and k["vgpr_spills"] == 0, k
+    lowp = [k for k in ks if "bnn_forward_lowp_kernel" in k["name"]]
+    assert len(lowp) == 5 and all(k["scratch"] == 0 and k["vgpr_spills"] == 0 for k in lowp)
+    gen = {k["name"]: k for k in ks if "bnn_forward_generic_kernel" in k["name"]}
+    assert len(gen) == 8
+    # the generic engine: no scratch in the 41-feature buckets except the eight-wave narrow one (a handful of spills outside the MFMA chains)
+    for name, k in gen.items():
+        if name.endswith("<11, 12>"):
+            assert k["vgpr"] <= 256 and k["scratch"] <= 160, k
+        elif name.startswith("bnn::bnn_forward_generic_kernel<11"):
+            assert k["scratch"] == 0, k
