@@ -63,7 +63,7 @@ int gen_build(int F, int H, int L, int depth_in, int depth_out, bool megno, GenA
         t.nwreg = nwreg;
         t.reg_in_lds = reg_in_lds;
         for (int nw : {8, 4, 2, 1}) {   // eight waves (two per SIMD) only where the kernel fits 256 registers: the narrowest bucket
-            if (nw == 8 && (t.hq > 12 || t.fq != 11)) continue;
+            if (nw == 8 && (t.hq > GEN_W8_HQ || t.fq != 11)) continue;
             if ((int64_t)(gen_shared_floats(t) + nw * gen_wave_floats(t)) * 4 <= LDS_BYTES) return nw;
         }
         return 0;

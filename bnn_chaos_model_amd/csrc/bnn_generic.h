@@ -18,6 +18,7 @@
 
 namespace bnn {
 
+constexpr int GEN_W8_HQ = 16;   // widest activation bucket (41-feature forms) that also has an eight-wave form, compiled for 256 registers
 constexpr int GEN_MAX_LAYERS = 16;   // Linear modules of feature_nn and regress_nn together
 constexpr int GEN_MAX_WIDTH = 128;   // hidden, latent and summary width (2 latent + 2) supported by the register buckets
 

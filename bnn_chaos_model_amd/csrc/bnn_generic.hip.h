@@ -175,11 +175,13 @@ DEVINL void gen_merge(const GenMerge mg, float& ma, float& qa, float mb, float q
     }
 }
 
-template <int FQ, int HQ>
-// The narrowest bucket (41 features) fits 256 registers, so its workgroups are EIGHT waves (two per SIMD sharing one weight image: the partner wave's
-// MFMAs fill this wave's LDS / memory waits -- a single wave per SIMD spent a quarter of its cycles parked in s_waitcnt); the wider
-// buckets need the whole 512-register file and run one wave per SIMD.
-__global__ __launch_bounds__((HQ <= 12 && FQ == 11) ? 512 : 256, 1) void bnn_forward_generic_kernel(const GenParams P) {
+// W8: the form compiled for 256 registers and launched with EIGHT waves per workgroup (two per SIMD sharing one weight image: the
+// partner wave's MFMAs fill this wave's LDS / memory waits -- a single wave per SIMD spent a quarter of its cycles parked in
+// s_waitcnt).  It exists for the 41-feature buckets of 12 and 16 quads and is chosen by the host when eight waves' LDS fits
+// (same-box A/B on a hidden-64 / latent-16 network: +13 %; where only four waves fit, the 256-register form's spills cost 5 %, so
+// those shapes run the 512-register form at one wave per SIMD, as the wider buckets always do).
+template <int FQ, int HQ, bool W8>
+__global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(const GenParams P) {
     const FwdParams& p = P.f;
     const GenArch& G = *P.g;
     constexpr int NBLK_IN = FQ == 11 ? 7 : 14;   // Philox blocks of six normals per input row (41 / 82 columns)
@@ -280,7 +282,7 @@ __global__ __launch_bounds__((HQ <= 12 && FQ == 11) ? 512 : 256, 1) void bnn_for
         // XPREF: the next tile's rows are fetched right behind layer 1 of the current one (a tile of work to land).  The widest
         // bucket has no registers to hold them across the other layers (two 128-register activation arrays): it loads at the top of
         // the tile and waits (about 1 us of a tile of 20 us or more at those widths).
-        constexpr bool XPREF = HQ < 32;
+        constexpr bool XPREF = HQ < 32 && !(W8 && HQ > 12);   // (the eight-wave form of the 16-quad bucket has no registers for it either)
         f32x4 xr[FQ];
         if constexpr (XPREF) {
             gen_load_row<FQ>(sysp + (int64_t)(ph0 < T ? ph0 : T - 1) * F, xr);
@@ -495,16 +497,16 @@ __global__ __launch_bounds__((HQ <= 12 && FQ == 11) ? 512 : 256, 1) void bnn_for
     }
 }
 
-template <int FQ, int HQ>
+template <int FQ, int HQ, bool W8>
 inline hipError_t launch_generic_form(unsigned nblk, hipStream_t st, const GenParams& P, int nwaves, size_t lds_bytes) {
     static bool attr_set[MAX_DEVICES];  // the attribute belongs to the (function, device) pair
     const int slot = current_device_slot();
     if (!attr_set[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_generic_kernel<FQ, HQ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_generic_kernel<FQ, HQ, W8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr_set[slot] = true;
     }
-    hipLaunchKernelGGL((bnn_forward_generic_kernel<FQ, HQ>), dim3(nblk), dim3(64 * nwaves), lds_bytes, st, P);
+    hipLaunchKernelGGL((bnn_forward_generic_kernel<FQ, HQ, W8>), dim3(nblk), dim3(64 * nwaves), lds_bytes, st, P);
     return hipGetLastError();
 }
 

@@ -6,7 +6,7 @@
 //   bnn_fwd_noisy.hip   forward kernel, forward(noisy_val=True)
 //   bnn_fwd_megno.hip   forward kernel forms for hparams['fix_megno'] = True (42-wide summary, d = 7665)
 //   bnn_fwd_lowp.hip    reduced-precision forward kernels (bf16 / half matrix pipe; opt-in, configs[4])
-//   bnn_fwd_generic.hip generic forward engine: the network built from hparams (any hidden / latent / depth, 41 | 82 features), any T
+//   bnn_fwd_generic.hip, bnn_fwd_generic82.hip   generic forward engine: the network built from hparams (any hidden / latent / depth; 41 resp. 82 features), any T
 //   bnn_generic.cpp     host: descriptor of that engine (layers, LDS image, register bucket)
 //   bnn_abi.hip         extern "C" entry points of include/bnn_chaos_hip.h + the small kernels (SWAG draw, moments, regress_nn,
 //                       statistics epilogue, feature packing, Philox fills)

@@ -436,10 +436,10 @@ def test_headline_kernels_use_no_scratch(N):
     lowp = [k for k in ks if "bnn_forward_lowp_kernel" in k["name"]]
     assert len(lowp) == 5 and all(k["scratch"] == 0 and k["vgpr_spills"] == 0 for k in lowp)
     gen = {k["name"]: k for k in ks if "bnn_forward_generic_kernel" in k["name"]}
-    assert len(gen) == 8
-    # the generic engine: no scratch in the 41-feature buckets except the eight-wave narrow one (a handful of spills outside the MFMA chains)
+    assert len(gen) == 10
+    # the generic engine: no scratch in the 41-feature one-wave-per-SIMD forms; the eight-wave (256-register) forms spill a bounded amount
     for name, k in gen.items():
-        if name.endswith("<11, 12>"):
-            assert k["vgpr"] <= 256 and k["scratch"] <= 160, k
+        if name.endswith("true>"):
+            assert k["vgpr"] <= 256 and k["agpr"] == 0 and k["scratch"] <= 320, k
         elif name.startswith("bnn::bnn_forward_generic_kernel<11"):
             assert k["scratch"] == 0, k
