@@ -195,11 +195,28 @@ DEVINL f32x2 soft_clamp2(float r0, float r1, float std_lo, float std_span) {
 
 // compute_summary_stats for one latent (:420-431), op for op: torch.std (unbiased) from the pooled M2, **2, the two standard errors,
 // the two sampled moments, sqrt(abs(.) + EPSILON).  One routine for the three forward kernels (fp32, reduced precision, generic).
+// BNN_DIVFAST (A/B builds ONLY; profiles/r04_ab_variants.txt): the three divisions by the wave-uniform constants T - 1 and T as the
+// 3-instruction sequence q = x r, e = fma(-q, n, x), q + e r with r = RN(1 / n) instead of the IEEE divide expansion -- to MEASURE what
+// the lever is worth (round-3 verdict, item 5a).  Not the product: the sequence is correctly rounded for most but not provably all
+// operands, and the parity path divides as the oracle does.
+#ifndef BNN_DIVFAST
+#define BNN_DIVFAST 0
+#endif
+DEVINL float div_by(float x, float n) {
+#if BNN_DIVFAST
+    const float rn = 1.0f / n;                 // wave-uniform: hoisted out of every loop by the compiler
+    const float q = x * rn;
+    const float e = fmaf(-q, n, x);
+    return fmaf(e, rn, q);
+#else
+    return x / n;
+#endif
+}
 DEVINL void sampled_moments(float sample_mu, float m2sum, float e1, float e2, float nm1, float nT, float& mu_s, float& sd_s) {
-    const float sd = sqrtf(m2sum / nm1);       // torch.std (unbiased)
-    const float sample_var = sd * sd;          // **2
-    const float std_in_mu = sqrtf(sample_var / nT);
-    const float std_in_var = sqrtf((2.0f * (sample_var * sample_var)) / nm1);
+    const float sd = sqrtf(div_by(m2sum, nm1));  // torch.std (unbiased)
+    const float sample_var = sd * sd;            // **2
+    const float std_in_mu = sqrtf(div_by(sample_var, nT));
+    const float std_in_var = sqrtf(div_by(2.0f * (sample_var * sample_var), nm1));
     mu_s = e1 * std_in_mu + sample_mu;
     const float var_s = e2 * std_in_var + sample_var;
     sd_s = sqrtf(fabsf(var_s) + 1e-5f);        // EPSILON (:337)
