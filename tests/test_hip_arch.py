@@ -205,7 +205,7 @@ def test_surface_accepts_checkpoints_of_other_shapes(tmp_path, ops):
     """load_swag on checkpoints whose hparams describe other networks -> the module API replays the reference run seed for seed
     (forward_swag_fast :878-908, forward :486-528); state_dict keys / shapes are the reference's."""
     from bnn_chaos_model_amd import checkpoint, spock_reg_model as srm
-    for name in ("h64l16", "deep22", "lin00", "deriv82", "h33l7"):
+    for name in ("h64l16", "deep22", "lin00", "deriv82", "h33l7", "k40", "h48megno"):
         z = load_golden(f"case_arch_{name}.npz")
         hp = hparams_of(z)
         p = tmp_path / f"{name}_output.pkl"

@@ -93,3 +93,39 @@ def test_bands_and_moments_over_logical_shards(fr, inputs):
     assert torch.equal(m1, multi.predictive_moments(X, 120, seed_idx, philox_seed=4))       # x may live on the host
     assert torch.equal(q1, multi.predictive_quantiles(xg, 120, seed_idx, philox_seed=4, trios=3))
     assert MultiSwagSharded(wa, w2, pd, devices="all").predictive_moments(xg, 120, seed_idx, philox_seed=4).shape == (120, 4)
+
+
+@pytest.mark.gpu
+def test_another_network_through_the_batched_drivers(tmp_path):
+    """An ensemble of two checkpoints of ANOTHER network (hidden 64, latent 16: the generic engine) through FeatureRegressor's batched
+    drivers: the one-launch MC loop equals the script's chunk-by-chunk loop bit for bit (reference RNG order), logical shards on one
+    card equal the single shard (chunks of the whole batch inside the generic kernel), and the streamed bands run."""
+    from bnn_chaos_model_amd import checkpoint
+    from bnn_chaos_model_amd.regression import FeatureRegressor
+    z = load_golden("case_arch_h64l16.npz")
+    hp = json.loads(str(z["hparams_json"]))
+    for k, v in list(hp.items()):
+        if isinstance(v, str) and v in ("True", "False"):
+            hp[k] = v == "True"
+    rng = np.random.default_rng(2)
+    for i in range(2):
+        jit = (1.0 + 0.01 * rng.standard_normal(z["w_avg"].shape)).astype(np.float32)
+        checkpoint.write_swag_file(str(tmp_path / f"net64_{i}_output.pkl"), hp, json.loads(str(z["swa_params_json"])),
+                                   torch.tensor(z["w_avg"] * jit), torch.tensor(z["w2_avg"] * jit * jit), torch.tensor(z["pre_D"] * jit[:, None]))
+    fr = FeatureRegressor(cuda=True, filebase=str(tmp_path / "net64_*_output.pkl"), sort=True)
+    assert len(fr.swag_ensemble) == 2 and fr.swag_ensemble[0].hparams["hidden"] == 64
+    X = torch.tensor(np.tile(z["x"], (3, 1, 1))[:45])
+    np.random.seed(4); torch.manual_seed(4)
+    one = fr.sample_full_swag_many(X, samples=3, chunks=10, devices=[0])
+    np.random.seed(4); torch.manual_seed(4)
+    three = fr.sample_full_swag_many(X, samples=3, chunks=10, devices=[0, 0, 0])
+    np.random.seed(4); torch.manual_seed(4)
+    loop = torch.cat([torch.cat([fr.sample_full_swag(Xp) for Xp in torch.chunk(X, 10)])[None] for _ in range(3)])
+    assert torch.equal(one, three) and torch.equal(one, loop)
+    np.random.seed(5)
+    a = fr.predictive_bands(X, samples=32, chunks=5, trios=3, philox_seed=8, samples_per_launch=8, devices=[0])
+    np.random.seed(5)
+    b = fr.predictive_bands(X, samples=32, chunks=5, trios=3, philox_seed=8, samples_per_launch=8, devices=[0, 0])
+    assert torch.equal(a["percentiles"], b["percentiles"]) and a["percentiles"].shape == (15, 5)
+    with pytest.raises(NotImplementedError):
+        fr.sample_full_swag_many(X[:, :, :40], samples=1)
