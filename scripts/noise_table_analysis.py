@@ -54,8 +54,25 @@ def main():
     P("Decision: Box-Muller stays.  The form that would pay is a cheaper BLOCK generator (the Philox rounds are 47 % of the generator's")
     P("cycles), which is a statistical-quality trade (fewer than the 7 rounds Salmon et al. report as Crush-resistant, or 16-bit uniforms)")
     P("that this path does not make.")
-    txt = "\n".join(out) + "\n"
+    # the generator as BUILT: the tile loop's instruction classes from the library's code object (once per 64-row tile, so these are the
+    # per-tile dynamic counts behind SQ_INSTS_VALU - SQ_INSTS_MFMA of profiles/r04_pmc_summary_noisy.json)
     import os
+    import subprocess
+    import sys
+    here0 = os.path.dirname(os.path.abspath(__file__))
+    h = subprocess.run([sys.executable, os.path.join(here0, "loop_histogram.py"), "bnn_forward_kernelILi41ELb0ELb1ELb0ELb0ELb0EE"],
+                       capture_output=True, text=True).stdout
+    if h.strip():
+        P("")
+        P("The noisy forward's tile loop as built (scripts/loop_histogram.py on libbnn_chaos_hip.so):")
+        for l in h.rstrip().split("\n"):
+            P("  " + l)
+        P("  -> 668 non-MFMA vector instructions = 836 issue slots (the 85 + 83 two-slot ones counted twice) = 3 344 cycles next to the 8 080 of")
+        P("     the 1 010 MFMAs: a ceiling of 70.7 % matrix-pipe occupancy for this loop; measured 67.5 % (r04_issue_accounting.json).")
+        P("     The uniform-knot table would take out the 83 transcendentals, 21 sub, 21 mul and 21 packed multiplies (229 slots) and put in")
+        P("     41 and + 41 fma + 41 ds_read issues (123 slots): 106 slots = 424 cycles per tile, 3.7 % -- the estimate above from the")
+        P("     instruction list agrees with the count from the binary.")
+    txt = "\n".join(out) + "\n"
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(here, "profiles", "r04_noise_table_analysis.txt"), "w") as f:
         f.write(txt)
