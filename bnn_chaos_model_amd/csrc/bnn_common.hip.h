@@ -123,8 +123,16 @@ DEVINL f32x4 philox_eps4(int64_t row, int64_t sys, int quad, uint64_t seed) { re
 // eps_in[row][sys][t][col]: block = t*7 + col/6, normal col%6 of the block.
 constexpr int NIN_PER_BLOCK = 6, NIN_BLOCKS = 7;  // 7 blocks x 6 >= 41 columns
 constexpr int NIN_ROUNDS = 7;
-DEVINL float unit21(uint32_t aligned) {  // bits [22:2] of `aligned` are the 21-bit field; +half a step so that f is never 1 or 2
-    return __builtin_bit_cast(float, (aligned & 0x007FFFFCu) | 0x3F800002u);
+// The and-or is ONE v_and_or_b32 only if at most one of its two constants comes from the scalar side (gfx950 VALU instructions take
+// one scalar / literal operand): the OR constant is therefore kept in a VGPR the compiler cannot see through -- left to itself it
+// emits v_and_b32 + v_or_b32 with two literals, 42 extra vector instructions per 64-row tile of the noisy forward.
+DEVINL uint32_t unit21_orc() {
+    uint32_t c = 0x3F800002u;
+    asm("" : "+v"(c));   // (not volatile: one copy per kernel is enough, the compiler may hoist and share it)
+    return c;
+}
+DEVINL float unit21(uint32_t aligned, uint32_t orc) {  // bits [22:2] of `aligned` are the 21-bit field; +half a step so that f is never 1 or 2
+    return __builtin_bit_cast(float, (aligned & 0x007FFFFCu) | orc);
 }
 DEVINL f32x2 box_muller21(float f_radius, float f_angle) {
     const float u1 = 2.0f - f_radius;
@@ -134,13 +142,14 @@ DEVINL f32x2 box_muller21(float f_radius, float f_angle) {
 }
 DEVINL void philox_normal6(uint4 ctr, uint64_t seed, float (&n)[6]) {
     const uint4 r = philox4x32<NIN_ROUNDS>(ctr, make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    const uint32_t orc = unit21_orc();
     // fields (bit offsets in the 128-bit block x:y:z:w, little end first): 0, 21, 42, 63, 84, 105 -- each moved to bits [22:2]
-    const float f0 = unit21(r.x << 2);
-    const float f1 = unit21(__builtin_amdgcn_alignbit(r.y, r.x, 19));
-    const float f2 = unit21(r.y >> 8);
-    const float f3 = unit21(__builtin_amdgcn_alignbit(r.z, r.y, 29));
-    const float f4 = unit21(__builtin_amdgcn_alignbit(r.w, r.z, 18));
-    const float f5 = unit21(r.w >> 7);
+    const float f0 = unit21(r.x << 2, orc);
+    const float f1 = unit21(__builtin_amdgcn_alignbit(r.y, r.x, 19), orc);
+    const float f2 = unit21(r.y >> 8, orc);
+    const float f3 = unit21(__builtin_amdgcn_alignbit(r.z, r.y, 29), orc);
+    const float f4 = unit21(__builtin_amdgcn_alignbit(r.w, r.z, 18), orc);
+    const float f5 = unit21(r.w >> 7, orc);
     const f32x2 a = box_muller21(f0, f1), b = box_muller21(f2, f3), c = box_muller21(f4, f5);
     n[0] = a.x; n[1] = a.y; n[2] = b.x; n[3] = b.y; n[4] = c.x; n[5] = c.y;
 }

@@ -141,11 +141,11 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     if (tid < 2 * H + L) wl[tid] = flat[tid < H ? Y::B1 + tid : tid < 2 * H ? Y::B2 + (tid - H) : Y::B3 + (tid - 2 * H)];
     if constexpr (NOISY) {  // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
         if (tid < F + Y::SM) nsc[tid] = expf(flat[Y::INLV + tid] / 2.0f);
-        if (tid < 56) {     // the same input scales per noise block, and all-ones / zero bit masks for kept / zeroed columns
+        if (tid < 56) {     // the same input scales per noise block, and 1.0 / 0.0 keep-factors for kept / zeroed columns
             const int col = NIN_PER_BLOCK * (tid >> 3) + (tid & 7);
             const bool live = (tid & 7) < NIN_PER_BLOCK && col < F;
             nsc[96 + tid] = live ? expf(flat[Y::INLV + col] / 2.0f) : 0.0f;
-            nsc[96 + 56 + tid] = __builtin_bit_cast(float, (live && !((p.zero_mask >> col) & 1ull)) ? 0xFFFFFFFFu : 0u);
+            nsc[96 + 56 + tid] = (live && !((p.zero_mask >> col) & 1ull)) ? 1.0f : 0.0f;
         }
     }
     {   // regress_nn operands replace the flat vector in place: gather to registers, barrier, write.  All table entries are
@@ -255,28 +255,26 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                         philox_in6(p.row_id0 + r, p.sys_id0 + sysc0, tblk + blk, p.seed, n6);
                     }
                     const f32x4* nb = reinterpret_cast<const f32x4*>(nsc + 96 + 8 * blk);
-                    const f32x4 s0 = nb[0], s1 = nb[1], k0 = nb[14], k1 = nb[15];  // scales, keep-masks (56 floats further on)
+                    const f32x4 s0 = nb[0], s1 = nb[1], k0 = nb[14], k1 = nb[15];  // scales, keep-factors (56 floats further on)
                     // (indexed access only: __builtin_bit_cast of a swizzle member such as k0.y was miscompiled by hipcc 7.2 -- every
                     // column got k0.x's mask)
                     float scs[6], kpf[6];
 #pragma unroll
                     for (int j = 0; j < 6; ++j) { scs[j] = j < 4 ? s0[j] : s1[j - 4]; kpf[j] = j < 4 ? k0[j] : k1[j - 4]; }
 #pragma unroll
-                    for (int j = 0; j < 6; j += 2) {   // column pairs: two v_and, then ONE v_pk_mul_f32 and ONE v_pk_add_f32
-                        const int col = 6 * blk + j;
-                        if (col + 1 < KIN) {
-                            f32x2 xm;
-                            xm.x = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, xv[col]) & __builtin_bit_cast(uint32_t, kpf[j]));
-                            xm.y = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, xv[col + 1]) & __builtin_bit_cast(uint32_t, kpf[j + 1]));
+                    for (int j = 0; j < 6; j += 2) {   // column pairs: ONE v_pk_mul_f32 (randn * exp(logvar / 2)) and ONE v_pk_fma_f32
+                        const int col = 6 * blk + j;   // x * keep + noise with keep = 1.0 | 0.0: x * 1.0 and x * 0.0 are exact, so the fma rounds once,
+                        if (col + 1 < KIN) {           // exactly where the reference's x + noise does (:445) -- and the two v_and of a bit-mask form are gone
+                            const f32x2 xp = {xv[col], xv[col + 1]};
+                            const f32x2 kp = {kpf[j], kpf[j + 1]};
                             f32x2 nz = {n6[j], n6[j + 1]};
                             const f32x2 sc = {scs[j], scs[j + 1]};
-                            nz = nz * sc;                 // randn * exp(logvar / 2): a multiply ...
-                            const f32x2 xs = xm + nz;     // ... then an add (:445)
+                            nz = nz * sc;                                             // a multiply ...
+                            const f32x2 xs = __builtin_elementwise_fma(xp, kp, nz);   // ... then the add
                             xv[col] = xs.x;
                             xv[col + 1] = xs.y;
                         } else if (col < KIN) {           // the last column stands alone (KIN is odd)
-                            const float xm = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, xv[col]) & __builtin_bit_cast(uint32_t, kpf[j]));
-                            xv[col] = xm + n6[j] * scs[j];
+                            xv[col] = fmaf(xv[col], kpf[j], n6[j] * scs[j]);
                         }
                     }
                 };

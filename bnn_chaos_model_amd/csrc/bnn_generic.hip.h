@@ -189,7 +189,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wimg = lds;
     float* bimg = wimg + gen_wimg_floats(G);
-    float* nsc = bimg + G.nbias;   // exp(input_noise_logvar / 2) [4 * fq] | exp(summary_noise_logvar / 2) [4 * smq] | per noise block [8] scales | [8] keep-masks
+    float* nsc = bimg + G.nbias;   // exp(input_noise_logvar / 2) [4 * fq] | exp(summary_noise_logvar / 2) [4 * smq] | per noise block [8] scales | [8] keep-factors (1.0 | 0.0)
     float* nsc_sum = nsc + 4 * FQ;
     float* nsc_blk = nsc_sum + 4 * G.smq;
     float* wave0 = nsc + gen_nsc_floats(G);
@@ -245,11 +245,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
         if (P.noisy) {   // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
             for (int j = tid; j < 4 * FQ; j += blockDim.x) nsc[j] = j < F ? expf(We[G.off_inlv + j] / 2.0f) : 0.0f;
             for (int j = tid; j < 4 * smq; j += blockDim.x) nsc_sum[j] = j < SM ? expf(We[G.off_sumlv + j] / 2.0f) : 0.0f;
-            for (int j = tid; j < 8 * NBLK_IN; j += blockDim.x) {   // the input scales per noise block, and keep-masks of the unmasked columns
+            for (int j = tid; j < 8 * NBLK_IN; j += blockDim.x) {   // the input scales per noise block, and keep-factors of the unmasked columns
                 const int col = NIN_PER_BLOCK * (j >> 3) + (j & 7);
                 const bool live = (j & 7) < NIN_PER_BLOCK && col < F;
                 nsc_blk[j] = live ? expf(We[G.off_inlv + col] / 2.0f) : 0.0f;
-                nsc_blk[8 * NBLK_IN + j] = __builtin_bit_cast(float, (live && !(col < 64 && ((p.zero_mask >> col) & 1ull))) ? 0xFFFFFFFFu : 0u);
+                nsc_blk[8 * NBLK_IN + j] = (live && !(col < 64 && ((p.zero_mask >> col) & 1ull))) ? 1.0f : 0.0f;
             }
         }
     }
@@ -349,10 +349,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
                         const int col = 6 * blk + j;
                         if (col < FCOLS) {
                             const float sc = j < 4 ? s0[j] : s1[j - 4], kp = j < 4 ? k0[j] : k1[j - 4];
-                            const float xv = xr[col >> 2][col & 3];   // (through scalars: see relu_lim1)
-                            const float xm = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, xv) & __builtin_bit_cast(uint32_t, kp));
-                            const float nz = n6[j] * sc;          // randn * exp(logvar / 2): a multiply ...
-                            xr[col >> 2][col & 3] = xm + nz;      // ... then an add (:445)
+                            const float nz = n6[j] * sc;                                     // randn * exp(logvar / 2): a multiply ...
+                            xr[col >> 2][col & 3] = fmaf(xr[col >> 2][col & 3], kp, nz);     // ... then the add (:445): x * keep (1.0 | 0.0, exact) + noise
                         }
                     }
                 });

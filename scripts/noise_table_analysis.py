@@ -67,8 +67,12 @@ def main():
         P("The noisy forward's tile loop as built (scripts/loop_histogram.py on libbnn_chaos_hip.so):")
         for l in h.rstrip().split("\n"):
             P("  " + l)
-        P("  -> 668 non-MFMA vector instructions = 836 issue slots (the 85 + 83 two-slot ones counted twice) = 3 344 cycles next to the 8 080 of")
-        P("     the 1 010 MFMAs: a ceiling of 70.7 % matrix-pipe occupancy for this loop; measured 67.5 % (r04_issue_accounting.json).")
+        P("  -> the non-MFMA vector instructions, the 85 + 83 two-slot ones counted twice, are the issue slots the generator, the ReLUs and the")
+        P("     pool take next to the 8 080 cycles of the 1 010 MFMAs.  At the start of round 4 the loop held 668 of them (836 slots, 3 344")
+        P("     cycles: a ceiling of 70.7 % matrix-pipe occupancy; measured 67.5 %, r04_issue_accounting.json); two trims that change no bit")
+        P("     took 82 out -- ONE v_and_or_b32 per uniform field (the OR constant kept in a VGPR: two literals cannot share an instruction on")
+        P("     gfx950) and x * keep + noise as one v_pk_fma_f32 with keep = 1.0 | 0.0 instead of two bit-mask v_and + v_pk_add_f32 per column")
+        P("     pair -- same-box A/B 23.42 -> 23.03 ms per 3e6 evaluations (r04_ab_variants.txt): 1.28e8 -> 1.30e8 evals/s.")
         P("     The uniform-knot table would take out the 83 transcendentals, 21 sub, 21 mul and 21 packed multiplies (229 slots) and put in")
         P("     41 and + 41 fma + 41 ds_read issues (123 slots): 106 slots = 424 cycles per tile, 3.7 % -- the estimate above from the")
         P("     instruction list agrees with the count from the binary.")
