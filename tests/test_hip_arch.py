@@ -251,3 +251,46 @@ def test_limits_are_errors_not_wrong_answers(ops):
         ops.forward(x, torch.zeros(1, plan.d, device="cuda"), plan=plan)        # T = 1: torch.std is NaN
     with pytest.raises(Exception):
         ops.forward(torch.zeros(4, 8, 41, device="cuda"), torch.zeros(1, plan.d, device="cuda"), plan=plan, precision="bf16")
+
+
+def test_random_architecture_sweep_against_the_oracle(ops, orc):
+    """Seeded random networks (widths 1..128, depths 0..3, 41 / 82 features, fix_megno, random column masks, T in [2, 45]) with random
+    weights: the generic engine's summary and pre-clamp outputs equal the oracle's on its schedule bit for bit, quiet; the noisy forward
+    agrees to the rounding of expf.  Covers every register bucket, the eight-, four-, two- and one-wave LDS budgets and the staged
+    regress_nn path."""
+    rng = np.random.default_rng(20260410)
+    seen = set()
+    for trial in range(14):
+        F = 82 if trial % 5 == 4 else 41
+        H = int(rng.choice([1, 3, 8, 17, 40, 48, 49, 64, 77, 96, 100, 128]))
+        L = int(rng.choice([1, 2, 5, 16, 20, 31, 48, 63]))
+        din, dout = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+        megno = bool(rng.integers(0, 2))
+        mask = int(rng.integers(0, 1 << 41)) | ((1 << 7) if megno else 0)
+        if trial == 0:
+            H, L, din, dout, megno, mask = 128, 48, 1, 2, False, 0     # the LDS budget leaves one or two waves; regress_nn staged from L2
+        T = int(rng.integers(2, 46))
+        try:
+            plan = ops.get_plan(mask, 0.5, fix_megno=megno, n_features=F, hidden=H, latent=L, depth_in=din, depth_out=dout)
+        except Exception as e:      # outside the LDS budget: an error, never a wrong answer
+            assert "LDS" in str(e) or "UNSUPPORTED" in str(e).upper() or "fit" in str(e), e
+            continue
+        arch = orc.make_arch(T=T, zero_mask=mask, n_features=F, hidden=H, latent=L, fix_megno=megno, depth_in=din, depth_out=dout)
+        assert plan.d == orc.param_count(arch)
+        B = 21
+        x = (rng.standard_normal((B, 1, F)) + 0.2 * rng.standard_normal((B, T, F))).astype(np.float32)
+        w = (rng.standard_normal(plan.d) * (0.6 / np.sqrt(max(H, 8)))).astype(np.float32)
+        eps = rng.standard_normal((1, B, 2, L)).astype(np.float32)
+        out, pre, summ = ops.forward(dev(x), dev(w[None]), eps=dev(eps), plan=plan, debug=True, engine="generic")
+        o, ex = orc.forward(x, w, eps[0, :, 0], eps[0, :, 1], arch=arch, sched=orc.make_schedule(None, pool_parts=4), extras=True)
+        assert np.array_equal(summ[0].cpu().numpy(), ex["summary"]), (trial, F, H, L, din, dout, megno, T)
+        assert np.array_equal(pre[0].cpu().numpy(), ex["pre_clamp"]), (trial, F, H, L, din, dout, megno, T)
+        assert np.abs(out[0].cpu().numpy() - o).max() <= 2e-6
+        e_in = rng.standard_normal((1, B, T, F)).astype(np.float32)
+        e_sum = rng.standard_normal((1, B, plan.summary_width)).astype(np.float32)
+        on = ops.forward(dev(x), dev(w[None]), eps=dev(eps), eps_in=dev(e_in), eps_sum=dev(e_sum), plan=plan, engine="generic")[0].cpu().numpy()
+        wn = orc.forward(x, w, eps[0, :, 0], eps[0, :, 1], eps_in=e_in[0], eps_sum=e_sum[0], arch=arch, sched=orc.make_schedule(None, pool_parts=4))
+        nbad, mx = close_report(on, wn, rtol=5e-6, atol=5e-6)
+        assert nbad == 0, (trial, nbad, mx)
+        seen.add((F, H, L, din, dout))
+    assert len(seen) >= 10
