@@ -9,8 +9,10 @@ result is bit-identical for any device list, including the same device named sev
 
 The exchange: `torch.cuda.nccl.all_gather` (RCCL over xGMI, the single-process form: one communicator per device inside this
 process) when the devices are distinct and RCCL accepts them; otherwise peer copies onto the first device.  `last_exchange` says
-which ran.
+which ran; BNN_MULTIDEVICE_EXCHANGE=copies forces the copies (the payload is a few floats per simulation either way).
 """
+import os
+
 import torch
 
 from .distributed import shard_bounds
@@ -81,7 +83,9 @@ class DeviceSet:
             self.last_exchange = "none (one shard)"
             return parts[0]
         devs = [p.device for p in parts]
-        if len(set(devs)) == len(devs):
+        if os.environ.get("BNN_MULTIDEVICE_EXCHANGE", "rccl") == "copies":
+            self.last_exchange = "peer copies (BNN_MULTIDEVICE_EXCHANGE=copies)"
+        elif len(set(devs)) == len(devs):
             try:
                 res = _rccl_all_gather(parts)
                 self.last_exchange = "rccl all_gather (torch.cuda.nccl, one process)"
