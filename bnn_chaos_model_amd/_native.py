@@ -84,6 +84,7 @@ def lib():
                                     C.c_uint64, C.c_int64, _vp, _vp]
     L.bnn_forward_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64,
                                   _vp, _vp, _vp, _vp]
+    L.bnn_feature_nn_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp]
     L.bnn_forward_lowp_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, C.c_int32,
                                        _vp, _vp, _vp, _vp]
     L.bnn_multiswag_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp,
@@ -121,7 +122,7 @@ EXPORTS = ("bnn_abi_version", "bnn_last_error", "bnn_device_count", "bnn_param_c
            "bnn_plan_destroy", "bnn_plan_layer_order", "bnn_layer_order", "bnn_fragment_table", "bnn_swag_draw_f32", "bnn_forward_f32", "bnn_multiswag_f32",
            "bnn_moments_f64", "bnn_truncnorm_f32", "bnn_prior_resample_f32", "bnn_regress_f32", "bnn_group_min_f32", "bnn_quantiles_f32", "bnn_feature_pack_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32",
            "bnn_prior_table_f32", "bnn_stats_draw_f32", "bnn_multiswag_stats_f32", "bnn_sketch_bins", "bnn_sketch_update_u32",
-           "bnn_sketch_quantiles_f32", "bnn_forward_lowp_f32", "bnn_multiswag_moments_f64", "bnn_multiswag_bands_f32")
+           "bnn_sketch_quantiles_f32", "bnn_forward_lowp_f32", "bnn_multiswag_moments_f64", "bnn_multiswag_bands_f32", "bnn_feature_nn_f32")
 
 
 def check(rc):

@@ -722,7 +722,7 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     if (generic && lowp) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels are built for the pretrained network at T % 4 == 0 only");
     if (generic && fused) return fail(BNN_ERR_UNSUPPORTED, "the in-prologue draw (W_workspace = NULL) exists for the pretrained network at T % 4 == 0 only: pass a [J, d] workspace");
     if (g->B == 0 || g->J == 0) return 0;
-    if (!p.x || !(p.out || p.sink)) return fail(BNN_ERR_INVALID, "x/out is NULL");
+    if (!p.x || !(p.out || p.sink || p.latents)) return fail(BNN_ERR_INVALID, "x/out is NULL");
     if (p.draw_id0 % g->nchunks) return fail(BNN_ERR_INVALID, "draw_id0 must be a multiple of nchunks");
     const int NF = pl->arch.n_features;
     p.B = g->B; p.T = g->T; p.ntiles = (g->T + 3) / 4; p.J = g->J; p.nch = g->nchunks;
@@ -811,6 +811,22 @@ int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, 
     p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
     p.out = out; p.pre_clamp = pre_clamp; p.summary = summary;
     return launch_forward(plan, grid, p, false, noisy, stream);
+}
+
+int bnn_feature_nn_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps_in, uint64_t philox_seed,
+                       int64_t draw_id0, int64_t system_id0, float* latents, void* stream) {
+    if (!plan || !grid) return fail(BNN_ERR_INVALID, "plan/grid is NULL");
+    if (grid->B == 0 || grid->J == 0) return 0;
+    if (!W || !latents) return fail(BNN_ERR_INVALID, "W/latents is NULL");
+    // the generic engine with its latents output switched on and no (mu, std) output: the pool and the tail run on in-kernel normals and
+    // their results are dropped (the latents do not depend on them)
+    bnn_grid g = *grid;
+    g.engine = 1;
+    FwdParams p{};
+    p.x = x; p.W = W; p.eps_in = eps_in;
+    p.seed = philox_seed; p.draw_id0 = draw_id0; p.sys_id0 = system_id0;
+    p.latents = latents;
+    return launch_forward(plan, &g, p, false, eps_in != nullptr || grid->noisy, stream);
 }
 
 int bnn_forward_lowp_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps, uint64_t philox_seed,

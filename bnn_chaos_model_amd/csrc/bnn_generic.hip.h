@@ -303,17 +303,26 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
             poolm4[g * 64 + lane] = mean;
             poolq4[g * 64 + lane] = m2;
         };
+        float* latrow = nullptr;   // this lane's row of the latents output (debug / side-effect output, bnn_feature_nn_f32)
+        auto welford_out = [&](const f32x4 y, int g, float rcn) {
+            welford(y, g, rcn);
+            if (latrow) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 * g + i < L) latrow[4 * g + i] = y[i];
+            }
+        };
         auto pool = [&](const f32x4 (&y)[HQ], float rcn) {
             static_while<HQ - 4>([&](auto GI) {
                 constexpr int g = GI;
                 if (g >= lat_nfull) return false;
-                welford(y[g], g, rcn);
+                welford_out(y[g], g, rcn);
                 return true;
             });
             static_while<4>([&](auto JI) {
                 constexpr int j = JI;
                 if (lat_nfull + j >= lq) return false;
-                welford(y[HQ - 4 + j], lat_nfull + j, rcn);
+                welford_out(y[HQ - 4 + j], lat_nfull + j, rcn);
                 return true;
             });
         };
@@ -323,6 +332,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
             const bool tv = t < T;
             const int tc = tv ? t : T - 1;
             const float rcn = p.rcp_tab[it];
+            latrow = (p.latents && valid0 && tv) ? p.latents + (((r * p.B + sys0) * T) + t) * (int64_t)L : nullptr;
             if constexpr (!XPREF) gen_load_row<FQ>(sysp + (int64_t)tc * F, xr);
             if (G.megno && tv) {   // summarize_megno (:480-484): the RAW column, before the masks and before any noise
                 const float xm = xr[MEGNO_COL >> 2][MEGNO_COL & 3];
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
             const f32x2 ms = soft_clamp2(r0, r1, p.std_lo, p.std_span);
             if (p.sink) {
                 p.sink[r * p.B + sys] = stats_draw(p.st, ms.x, ms.y, grow, p.sys_id0 + sys, p.seed);
-            } else {
+            } else if (p.out) {   // (null for a latents-only call, bnn_feature_nn_f32)
                 const int64_t o = (r * p.B + sys) * 2;
                 *reinterpret_cast<f32x2*>(p.out + o) = ms;
                 if (p.pre_clamp) *reinterpret_cast<f32x2*>(p.pre_clamp + o) = (f32x2){r0, r1};

@@ -55,6 +55,8 @@ struct FwdParams {
     float* out;
     float* pre_clamp;
     float* summary;
+    float* latents;   // [R,B,T,latent] feature_nn's output per timestep (compute_summary_stats' side effect self.latents, :433), or null;
+                      // written by the generic engine only (bnn_feature_nn_f32)
     const int16_t* tab_f2;
     const int16_t* tab_wr;  // feature_nn weight-register gather table [WR<KIN>::NR][64] (bnn_layout.h)
     const float* rcp_tab;   // [i] = 1/(i+1), correctly rounded

@@ -177,6 +177,26 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     return (out, pre, summ) if debug else out
 
 
+@_on_device_of(0)
+def feature_latents(x, W, eps_in=None, noisy=False, philox_seed=0, draw_id0=0, system_id0=0, plan=None):
+    """feature_nn alone -> the per-timestep latents [J, B, T, latent] that compute_summary_stats leaves in self.latents
+    (spock_reg_model.py:417, 433): masks applied, optional input noise (explicit eps_in [J,B,T,F], or noisy=True for in-kernel Philox)."""
+    plan = plan or get_plan()
+    x, W, eps_in = _f32(x, "x"), _f32(W, "W"), _f32(eps_in, "eps_in")
+    _check_x(x, plan)
+    B, T, NF = x.shape
+    if W.dim() != 2 or W.shape[1] != plan.d:
+        raise ValueError(f"W must be [J,{plan.d}]")
+    J = W.shape[0]
+    if eps_in is not None and tuple(eps_in.shape) != (J, B, T, NF):
+        raise ValueError(f"eps_in must be [{J},{B},{T},{NF}]")
+    lat = torch.empty((J, B, T, plan.latent), dtype=torch.float32, device=x.device)
+    g = _grid(B, T, J, 1, 0, noisy)
+    N.check(N.lib().bnn_feature_nn_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(W), N.ptr(eps_in), int(philox_seed), int(draw_id0), int(system_id0),
+                                       N.ptr(lat), N.stream_ptr()))
+    return lat
+
+
 def _check_grid(J, nchunks, draw_id0):
     if nchunks < 1 or J % nchunks:
         raise ValueError("the number of draws must be a multiple of nchunks")

@@ -158,7 +158,7 @@ class VarModel:
         self._pending_draw = None
         self._w = torch.cat([v.detach().reshape(-1) for v in sd.values()]).float().contiguous()  # flat vector [d]
 
-        self.latents = None
+        self._latents_cache, self._last_latents_args = None, None
         self.megno_location = 7
         self.mmr_location = [3, 6]
         self.nan_location = [38, 39, 40]
@@ -195,6 +195,21 @@ class VarModel:
             self._cur_summary_cache = summ[0]
         return self._cur_summary_cache
 
+    @property
+    def latents(self):
+        """compute_summary_stats' side effect `self.latents = feature_nn(x)` [B,T,latent] (:417, :433) of the last forward / of the
+        last compute_summary_stats call, produced on demand (same weights, same masks, same input noise)."""
+        if self._latents_cache is None and self._last_latents_args is not None:
+            xg, Wg, eps_in, noisy, did, plan = self._last_latents_args
+            if callable(Wg):   # after forward_swag_fast: the weights its fused kernel drew (materialised on demand, like flatten())
+                Wg = Wg()[None].to(xg.device)
+            self._latents_cache = ops.feature_latents(xg, Wg, eps_in=eps_in, noisy=noisy, philox_seed=self.philox_seed, draw_id0=did, plan=plan)[0]
+        return self._latents_cache
+
+    @latents.setter
+    def latents(self, v):
+        self._latents_cache, self._last_latents_args = v, None
+
     # ---- nn.Module-like conveniences used by the evaluation scripts --------------------------------------------
     @property
     def device(self):
@@ -211,6 +226,9 @@ class VarModel:
 
     @_w.setter
     def _w(self, v):
+        la = getattr(self, "_last_latents_args", None)
+        if la is not None and callable(la[1]) and self._latents_cache is None:   # latents of the weights being replaced: evaluate now
+            _ = self.latents
         self._pending_draw = None
         self._w_store = v
 
@@ -345,6 +363,8 @@ class VarModel:
         if record:   # what the lazily evaluated side effect (_cur_summary, :512) needs to re-run this forward with its debug outputs
             self._last_forward = (xg, Wg, eps, eps_in, eps_sum, noisy, did, plan)
             self._cur_summary_cache = None
+        self._last_latents_args = (xg, Wg, eps_in, noisy, did, plan)   # self.latents (:433): set by every compute_summary_stats
+        self._latents_cache = None
         if want_debug or plan is not self._plan():   # debug outputs / a plan other than the model's own (compute_summary_stats): direct
             res = ops.forward(xg, Wg, eps=eps, eps_in=eps_in, eps_sum=eps_sum, philox_seed=self.philox_seed, draw_id0=did, plan=plan,
                               debug=want_debug, noisy=noisy)
@@ -494,6 +514,8 @@ class SWAGModel(VarModel):
             self._pending_draw = lambda: ops.swag_draw(wa, w2, pd, idx, scale=scale, philox_seed=seed, draw_id0=did, plan=plan)[0]
         self._last_forward = None          # (_cur_summary belongs to forward(); forward_swag_fast does not set it, :878-908)
         self._cur_summary_cache = None
+        self._last_latents_args = (xg, self.flatten, None, False, 0, plan)   # its compute_summary_stats call (:893) sets self.latents
+        self._latents_cache = None
         return out[0].to(dev_in)
 
 

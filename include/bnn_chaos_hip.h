@@ -134,6 +134,13 @@ int bnn_forward_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, 
                     const float* eps_in, const float* eps_sum, uint64_t philox_seed, int64_t draw_id0,
                     int64_t system_id0, float* out, float* pre_clamp, float* summary, void* stream);
 
+/* feature_nn alone: the per-timestep latents that compute_summary_stats leaves in self.latents (spock_reg_model.py:417, 433), for
+ * inspection (the out-of-scope figures/feature_importance.py reads them).  Same arguments as bnn_forward_f32 (masks, optional input
+ * noise: eps_in explicit, or grid.noisy with in-kernel Philox); latents [J/nchunks, B, T, latent].  Runs on the generic engine for every
+ * network, so its numbers are the natural-order ones (bit-identical to the oracle's `latents`). */
+int bnn_feature_nn_f32(const bnn_plan* plan, const bnn_grid* grid, const float* x, const float* W, const float* eps_in,
+                       uint64_t philox_seed, int64_t draw_id0, int64_t system_id0, float* latents, void* stream);
+
 /* OPT-IN reduced-precision forward for the precision sweep of BASELINE.json configs[4] (the reference's 5-planet script casts to
  * fp32 at figures/multiswag_5_planet.py:287; a bf16 cast there is what this measures).  feature_nn runs on the bf16 matrix pipe
  * with fp32 accumulation; pool, sampled moments and regress_nn stay exact fp32; same arguments and Philox streams as

@@ -45,6 +45,11 @@ def orc():
     return oracle
 
 
+def orc_mod():
+    from oracle import oracle
+    return oracle
+
+
 def plan_and_arch(ops, orc, z, T=100):
     hp = hparams_of(z)
     mask = ops.zero_mask_from_flags(hp.get("fix_megno", False), hp.get("fix_megno2", False), hp["include_mmr"], hp["include_nan"],
@@ -83,6 +88,14 @@ def test_forward_vs_reference_and_oracle(name, ops, orc):
             assert np.array_equal(summ[0].cpu().numpy(), ex["summary"]), name
             assert np.array_equal(pre[0].cpu().numpy(), ex["pre_clamp"]), name
         assert np.abs(out[0].cpu().numpy() - o).max() <= 2e-6      # tanhf: libm vs device
+        # the self.latents side effect (:417, :433): feature_nn per time step, bit for bit (and the forward beside it is unchanged)
+        lat = ops.feature_latents(x, W, eps_in=dev(t[0][None]) if noisy else None, plan=plan)
+        assert lat.shape == (1, B, x.shape[1], plan.latent)
+        if noisy:   # (expf of the input-noise scale: an ulp between libm and the device)
+            nbad, mx = close_report(lat[0].cpu().numpy(), ex["latents"], rtol=2e-6, atol=2e-6 * max(1.0, float(np.abs(ex["latents"]).max())))
+            assert nbad == 0, (name, nbad, mx)
+        else:
+            assert np.array_equal(lat[0].cpu().numpy(), ex["latents"]), name
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -221,6 +234,11 @@ def test_surface_accepts_checkpoints_of_other_shapes(tmp_path, ops):
         nbad, mx = close_report(out.numpy(), z["swagfast_out"])
         assert nbad == 0, (name, nbad, mx)
         assert np.abs(m.flatten().numpy() - z["swagfast_w"]).max() <= 2e-6        # the sampled weights stay loaded (:838)
+        _, arch = plan_and_arch(ops, orc_mod(), z)
+        zero = np.zeros((x.shape[0], hp["latent"]), np.float32)
+        sched = orc_mod().make_schedule(None, pool_parts=4)
+        _, ex = orc_mod().forward(z["x"], m.flatten().numpy(), zero, zero, arch=arch, sched=sched, extras=True)
+        assert np.array_equal(m.latents.cpu().numpy(), ex["latents"]), name        # ... and so do the latents of that call (:433)
         for noisy in (False, True):
             torch.manual_seed(hp["seed"] + 3 + int(noisy))
             o = m(x, noisy_val=noisy)
@@ -232,11 +250,38 @@ def test_surface_accepts_checkpoints_of_other_shapes(tmp_path, ops):
             assert cs.shape == ref.shape
             nbad, mx = close_report(cs.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
             assert nbad == 0, (name, noisy, nbad, mx)
+            # compute_summary_stats' side effect self.latents (:433), on demand as well: feature_nn of THIS call (same input noise)
+            t = tp(z, f"forward_noisy{int(noisy)}_tape")
+            _, ex = orc_mod().forward(z["x"], m.flatten().numpy(), zero, zero, eps_in=t[0] if noisy else None, eps_sum=None, arch=arch,
+                                      sched=sched, extras=True)
+            nbad, mx = close_report(m.latents.cpu().numpy(), ex["latents"], rtol=2e-6, atol=2e-6 * max(1.0, float(np.abs(ex["latents"]).max())))
+            assert nbad == 0 and (noisy or np.array_equal(m.latents.cpu().numpy(), ex["latents"])), (name, noisy, nbad, mx)
         np.random.seed(0); torch.manual_seed(0)
         s = m.sample(x, samples=3)
         assert s.shape == (x.shape[0],) and np.isfinite(s).all()
         with pytest.raises(NotImplementedError):
             m(x[:, :, :-1])
+
+
+def test_latents_on_the_pretrained_network(ops, orc, swag_states, inputs):
+    """feature_nn alone on the pretrained network (T = 100 and a ragged T) == the oracle's per-step latents bit for bit; in-kernel
+    Philox input noise == the explicit-tensor form."""
+    wa, w2, pd = (dev(swag_states[0][k][None]) for k in ("w_avg", "w2_avg", "pre_D"))
+    plan = ops.get_plan()
+    W = ops.swag_draw(wa, w2, pd, torch.zeros(2, dtype=torch.int32), philox_seed=5, plan=plan)
+    for T in (100, 37):
+        xh = np.ascontiguousarray(inputs["slow"][:, :T])
+        x = dev(xh)
+        B = x.shape[0]
+        lat = ops.feature_latents(x, W, plan=plan)
+        zero = np.zeros((B, 20), np.float32)
+        for j in range(2):
+            _, ex = orc.forward(xh, W[j].cpu().numpy(), zero, zero, arch=orc.make_arch(T=T), sched=orc.make_schedule(None, pool_parts=4), extras=True)
+            assert np.array_equal(lat[j].cpu().numpy(), ex["latents"])
+        e_in = ops.philox_normal(3, 77, 4, 2, width=T, B=B, system_id0=9, n_features=41)
+        a = ops.feature_latents(x, W, noisy=True, philox_seed=77, draw_id0=4, system_id0=9, plan=plan)
+        b = ops.feature_latents(x, W, eps_in=e_in, plan=plan)
+        assert torch.equal(a, b) and not torch.equal(a, lat)
 
 
 def test_limits_are_errors_not_wrong_answers(ops):
