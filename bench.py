@@ -274,7 +274,9 @@ def parse(argv=None):
     ap.add_argument("--single-launch", action="store_true", help="in-kernel draw in every workgroup prologue (no workspace)")
     ap.add_argument("--spb", type=int, default=0, help="systems per workgroup (0 = auto)")
     ap.add_argument("--precision", default="f32", choices=sorted(DTYPE_OF), help="opt-in reduced-precision forward (workload c5 / c3 / c2)")
-    ap.add_argument("--engine", default="auto", choices=("auto", "generic"), help="generic: force the generic forward engine (LDS-streamed weights)")
+    ap.add_argument("--engine", default="auto", choices=("auto", "generic", "spec"),
+                    help="generic: force the generic forward engine (LDS-streamed weights); spec: its run-time-compiled form for this network (specialize.py)")
+    ap.add_argument("--spec-w8", default="auto", choices=("auto", "0", "1"), help="--engine spec: eight waves at 256 registers (1), four at 512 (0), builder's choice")
     ap.add_argument("--net", default="", help="hidden,latent,in,out[,features]: another hparams-built network on a synthetic ensemble (generic engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-systems", type=int, default=8192, help="systems of the batch the CPU baselines are timed on")
@@ -390,6 +392,10 @@ def main():
             sys.exit("--net applies to the dense fp32 workloads (c3, c2, noisy, tiny)")
     NF = net["n_features"] if net else 41
     plan = ops.get_plan(**net) if net else ops.get_plan()
+    if args.engine == "spec":   # compile this network's own form of the generic engine (cached on disk) before anything is timed
+        t0 = time.time()
+        ops.specialize(plan, noisy=(noisy,), w8={"auto": None, "0": False, "1": True}[args.spec_w8])
+        spec_compile_s = time.time() - t0
     x = synthetic_x(B, dev, seed=123 + rank, F=NF)    # this rank's shard
     wa, w2, pd = synthetic_net_ensemble(S, plan.d, 30, dev) if net else synthetic_ensemble(S, dev)   # replicated ensemble (29 MB)
     if nch == 1:
@@ -526,7 +532,7 @@ def main():
     if rank == 0:
         evals_per_launch = B * R
         kin = 41 if noisy else 31
-        generic = bool(net) or args.engine == "generic"
+        generic = bool(net) or args.engine != "auto"
         alg_flop, exe_flop, alg_bytes = ALG_FLOP_PER_EVAL, EXEC_FLOP_PER_EVAL[kin], ALG_BYTES_PER_EVAL
         if net:   # another network: the same two counts from its shapes (the v50 mask leaves 31 of the first 41 columns live)
             a5 = (NF, net["hidden"], net["latent"], net["depth_in"], net["depth_out"])
@@ -556,7 +562,8 @@ def main():
                   f"bnn_multiswag_moments_f64: {slab} draws per launch (draw + forward + moments kernels), {J // slab} launches per step" if slab else
                   ("multiswag, in-kernel draw per workgroup" if args.single_launch else "multiswag, draw-once workspace + forward"))
         if generic:
-            kernel = ("bnn_forward_generic_kernel (weight registers streamed from an LDS image; draw-once workspace)" +
+            kernel = (("bnn_spec_forward: the generic engine compiled at run time for this network (specialize.py, %.1f s incl. cache lookup; w8 %s)" % (spec_compile_s, args.spec_w8)
+                       if args.engine == "spec" else "bnn_forward_generic_kernel (weight registers streamed from an LDS image; draw-once workspace)") +
                       (f", network hidden={net['hidden']} latent={net['latent']} in={net['depth_in']} out={net['depth_out']} features={NF}" if net else
                        ", the pretrained network forced onto the generic engine"))
         if lowp:

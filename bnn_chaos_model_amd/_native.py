@@ -84,6 +84,9 @@ def lib():
                                     C.c_uint64, C.c_int64, _vp, _vp]
     L.bnn_forward_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64,
                                   _vp, _vp, _vp, _vp]
+    L.bnn_spec_source.argtypes = [C.POINTER(BnnArch), C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
+    L.bnn_plan_attach_spec.argtypes = [_vp, C.c_int32, C.c_int32, _vp, C.c_size_t]
+    L.bnn_plan_spec_attached.argtypes = [_vp, C.c_int32]
     L.bnn_feature_nn_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp]
     L.bnn_forward_lowp_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, C.c_int32,
                                        _vp, _vp, _vp, _vp]
@@ -122,7 +125,8 @@ EXPORTS = ("bnn_abi_version", "bnn_last_error", "bnn_device_count", "bnn_param_c
            "bnn_plan_destroy", "bnn_plan_layer_order", "bnn_layer_order", "bnn_fragment_table", "bnn_swag_draw_f32", "bnn_forward_f32", "bnn_multiswag_f32",
            "bnn_moments_f64", "bnn_truncnorm_f32", "bnn_prior_resample_f32", "bnn_regress_f32", "bnn_group_min_f32", "bnn_quantiles_f32", "bnn_feature_pack_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32",
            "bnn_prior_table_f32", "bnn_stats_draw_f32", "bnn_multiswag_stats_f32", "bnn_sketch_bins", "bnn_sketch_update_u32",
-           "bnn_sketch_quantiles_f32", "bnn_forward_lowp_f32", "bnn_multiswag_moments_f64", "bnn_multiswag_bands_f32", "bnn_feature_nn_f32")
+           "bnn_sketch_quantiles_f32", "bnn_forward_lowp_f32", "bnn_multiswag_moments_f64", "bnn_multiswag_bands_f32", "bnn_feature_nn_f32", "bnn_spec_source", "bnn_plan_attach_spec",
+           "bnn_plan_spec_attached")
 
 
 def check(rc):
@@ -161,6 +165,21 @@ class Plan:
         h = _vp()
         check(lib().bnn_plan_create(C.byref(self.arch), C.byref(h)))
         self.handle = h
+
+    def spec_source(self, noisy=False, w8=None):
+        """HIP source of this network's specialised form of the generic engine (bnn_spec_source; needs no device)."""
+        w = -1 if w8 is None else int(bool(w8))
+        n = check(lib().bnn_spec_source(C.byref(self.arch), w, int(bool(noisy)), None, 0))
+        buf = C.create_string_buffer(n + 1)
+        check(lib().bnn_spec_source(C.byref(self.arch), w, int(bool(noisy)), buf, n + 1))
+        return buf.value.decode()
+
+    def attach_spec(self, image, noisy=False, w8=None):
+        """Load a compiled specialised form (code object bytes) into the plan; the current device must be the plan's."""
+        check(lib().bnn_plan_attach_spec(self.handle, int(bool(noisy)), -1 if w8 is None else int(bool(w8)), image, len(image)))
+
+    def spec_attached(self, noisy=False):
+        return bool(check(lib().bnn_plan_spec_attached(self.handle, int(bool(noisy)))))
 
     def layer_order(self, layer, noisy=False):
         import numpy as np

@@ -543,6 +543,10 @@ struct bnn_plan {
     float* d_rcp = nullptr;    // [RCP_N] 1/(i+1)
     GenArch gen;               // generic engine: every plan has one (the v50 network falls back to it for T % 4 != 0 or T < 8)
     GenArch* d_gen = nullptr;
+    // specialised forms of the generic engine, compiled at run time for this network (bnn_spec_source / bnn_plan_attach_spec): [noisy]
+    GenArch spec_gen[2];
+    hipModule_t spec_mod[2] = {nullptr, nullptr};
+    hipFunction_t spec_fn[2] = {nullptr, nullptr};
     int device = 0;
 };
 
@@ -631,8 +635,52 @@ int bnn_plan_destroy(bnn_plan* pl) {
     if (pl->d_f4n) (void)hipFree(pl->d_f4n);
     if (pl->d_rcp) (void)hipFree(pl->d_rcp);
     if (pl->d_gen) (void)hipFree(pl->d_gen);
+    for (int i = 0; i < 2; ++i)
+        if (pl->spec_mod[i]) (void)hipModuleUnload(pl->spec_mod[i]);
     delete pl;
     return 0;
+}
+
+int bnn_spec_source(const bnn_arch* arch, int32_t w8, int32_t noisy, char* buf, size_t cap) {
+    int rc = check_arch(arch);
+    if (rc) return rc;
+    GenArch g;
+    const char* why = "";
+    if (gen_build_spec(arch->n_features, arch->hidden, arch->latent, arch->depth_in, arch->depth_out, arch->fix_megno != 0, w8, &g, &why))
+        return fail(BNN_ERR_UNSUPPORTED, why);
+    return gen_spec_source(g, noisy, buf, cap);
+}
+
+int bnn_plan_attach_spec(bnn_plan* pl, int32_t noisy, int32_t w8, const void* image, size_t bytes) {
+    if (!pl || !image || !bytes) return fail(BNN_ERR_INVALID, "plan/image is NULL");
+    if (noisy != 0 && noisy != 1) return fail(BNN_ERR_INVALID, "noisy must be 0 or 1");
+    GenArch g;
+    const char* why = "";
+    const bnn_arch* a = &pl->arch;
+    if (gen_build_spec(a->n_features, a->hidden, a->latent, a->depth_in, a->depth_out, a->fix_megno != 0, w8, &g, &why))
+        return fail(BNN_ERR_UNSUPPORTED, why);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != pl->device) return fail(BNN_ERR_INVALID, "the plan lives on another device than the current one");
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    hipError_t e = hipModuleLoadData(&mod, image);
+    if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("hipModuleLoadData: ") + hipGetErrorString(e));
+    e = hipModuleGetFunction(&fn, mod, "bnn_spec_forward");
+    if (e != hipSuccess) {
+        (void)hipModuleUnload(mod);
+        return fail(BNN_ERR_HIP, std::string("the code object has no kernel bnn_spec_forward: ") + hipGetErrorString(e));
+    }
+    if (pl->spec_mod[noisy]) (void)hipModuleUnload(pl->spec_mod[noisy]);
+    pl->spec_mod[noisy] = mod;
+    pl->spec_fn[noisy] = fn;
+    pl->spec_gen[noisy] = g;
+    return 0;
+}
+
+int bnn_plan_spec_attached(const bnn_plan* pl, int32_t noisy) {
+    if (!pl || (noisy != 0 && noisy != 1)) return fail(BNN_ERR_INVALID, "plan is NULL / noisy must be 0 or 1");
+    return pl->spec_fn[noisy] ? 1 : 0;
 }
 
 // natural order of the generic engine: the live inputs ascending (layer 0 drops the masked columns unless `noisy`)
@@ -717,8 +765,11 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     if (g->T < 2 || (g->T + 3) / 4 > RCP_N) return fail(BNN_ERR_UNSUPPORTED, "T must be in [2, 16384] (torch.std of a single timestep is NaN)");
     if (g->systems_per_block < 0 || (g->systems_per_block % 64)) return fail(BNN_ERR_INVALID, "systems_per_block must be a multiple of 64");
     // the pretrained network's kernels take whole tiles of 4 timesteps and at least two of them; everything else is the generic engine's
-    if (g->engine != 0 && g->engine != 1) return fail(BNN_ERR_INVALID, "grid.engine must be 0 (choose) or 1 (generic)");
-    const bool generic = !pl->v50net || (g->T % 4) != 0 || g->T < 8 || g->engine == 1;
+    if (g->engine < 0 || g->engine > 2) return fail(BNN_ERR_INVALID, "grid.engine must be 0 (choose), 1 (generic) or 2 (specialised)");
+    const bool generic = !pl->v50net || (g->T % 4) != 0 || g->T < 8 || g->engine != 0;
+    // the network's own compiled form of the generic engine, when one is attached (engine 2 insists on it)
+    const bool spec = generic && g->engine != 1 && pl->spec_fn[noisy ? 1 : 0] != nullptr;
+    if (g->engine == 2 && !spec) return fail(BNN_ERR_UNSUPPORTED, "grid.engine = 2: no specialised form is attached to this plan (bnn_plan_attach_spec)");
     if (generic && lowp) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels are built for the pretrained network at T % 4 == 0 only");
     if (generic && fused) return fail(BNN_ERR_UNSUPPORTED, "the in-prologue draw (W_workspace = NULL) exists for the pretrained network at T % 4 == 0 only: pass a [J, d] workspace");
     if (g->B == 0 || g->J == 0) return 0;
@@ -753,6 +804,13 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
         P.m23 = gen_merge_consts(cnt[2], cnt[3]);
         P.m0123 = gen_merge_consts(cnt[0] + cnt[1], cnt[2] + cnt[3]);
         P.noisy = noisy ? 1 : 0;
+        if (spec) {
+            size_t psz = sizeof(P);
+            void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &P, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz, HIP_LAUNCH_PARAM_END};
+            e = hipModuleLaunchKernel(pl->spec_fn[noisy ? 1 : 0], (unsigned)nblk, 1, 1, 64u * pl->spec_gen[noisy ? 1 : 0].nwaves, 1, 1, 0, st, nullptr, cfg);
+            if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("specialised forward kernel launch: ") + hipGetErrorString(e));
+            return 0;
+        }
         e = launch_fwd_generic(pl->gen, (unsigned)nblk, st, P);
         if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("generic forward kernel launch: ") + hipGetErrorString(e));
         return 0;

@@ -3,6 +3,9 @@
 #include "bnn_generic.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
 
 namespace bnn {
 
@@ -13,10 +16,11 @@ constexpr int HQ_BUCKETS[] = {12, 16, 24, 32};
 int mlp_nlin(int layers) { return layers == 0 ? 1 : layers + 2; }   // mlp() (spock_reg_model.py:301-321)
 }  // namespace
 
-int gen_build(int F, int H, int L, int depth_in, int depth_out, bool megno, GenArch* out, const char** why) {
+static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool megno, bool spec, int w8, GenArch* out, const char** why) {
     static const char* msg_f = "n_features must be 41 or 82 (time_series_features x (1 + include_derivatives))";
     static const char* msg_w = "hidden and latent must be in [1, 128] and the summary width 2 latent (+ 2) at most 128";
     static const char* msg_d = "depth `in` / `out` must be >= 0 with at most 16 Linear modules in the two MLPs together";
+    static const char* msg_8 = "eight waves' pool state does not fit LDS next to this network's weight image";
     static const char* msg_l = "feature_nn's weights do not fit the 160 KB of LDS (roughly F*H + in*H*H + H*L <= 36 000 floats)";
     if (F != 41 && F != 82) { *why = msg_f; return -2; }
     const int SM = 2 * L + (megno ? 2 : 0);
@@ -52,9 +56,13 @@ int gen_build(int F, int H, int L, int depth_in, int depth_out, bool megno, GenA
     g.d = off;
     g.nbias = bias0;
     g.hq = 0;
-    for (int b : HQ_BUCKETS)
-        if (!g.hq && need <= b) g.hq = b;
-    if (!g.hq) { *why = msg_w; return -2; }
+    if (spec) {
+        g.hq = 4 * ((need + 3) / 4);   // exact: the widest layer's blocks
+    } else {
+        for (int b : HQ_BUCKETS)
+            if (!g.hq && need <= b) g.hq = b;
+    }
+    if (!g.hq || g.hq > 32) { *why = msg_w; return -2; }
     // LDS: feature_nn's registers must be resident; regress_nn's are if that costs no waves
     int nfeat_regs = 0, nreg_regs = 0;
     for (int l = 0; l < nl; ++l) (l < g.n_feat ? nfeat_regs : nreg_regs) += g.layer[l].nblk * g.layer[l].nkq;
@@ -63,13 +71,15 @@ int gen_build(int F, int H, int L, int depth_in, int depth_out, bool megno, GenA
         t.nwreg = nwreg;
         t.reg_in_lds = reg_in_lds;
         for (int nw : {8, 4, 2, 1}) {   // eight waves (two per SIMD) only where the kernel fits 256 registers: the narrowest bucket
-            if (nw == 8 && (t.hq > GEN_W8_HQ || t.fq != 11)) continue;
+            if (nw == 8 && (spec ? w8 == 0 : false)) continue;
+            if (nw == 8 && (spec ? w8 < 0 : true) && (t.hq > GEN_W8_HQ || t.fq != 11)) continue;
+            if (nw != 8 && spec && w8 == 1) continue;
             if ((int64_t)(gen_shared_floats(t) + nw * gen_wave_floats(t)) * 4 <= LDS_BYTES) return nw;
         }
         return 0;
     };
     const int w_all = waves_for(nfeat_regs + nreg_regs, 1), w_feat = waves_for(nfeat_regs, 0);
-    if (!w_feat) { *why = msg_l; return -2; }
+    if (!w_feat) { *why = (spec && w8 == 1) ? msg_8 : msg_l; return -2; }
     g.reg_in_lds = (w_all >= w_feat) ? 1 : 0;
     g.nwaves = g.reg_in_lds ? w_all : w_feat;
     g.nwreg = nfeat_regs + (g.reg_in_lds ? nreg_regs : 0);
@@ -79,6 +89,39 @@ int gen_build(int F, int H, int L, int depth_in, int depth_out, bool megno, GenA
     g.lds_bytes = (gen_shared_floats(g) + g.nwaves * gen_wave_floats(g)) * 4;
     *out = g;
     return 0;
+}
+
+int gen_build(int F, int H, int L, int depth_in, int depth_out, bool megno, GenArch* out, const char** why) {
+    return gen_build_impl(F, H, L, depth_in, depth_out, megno, false, -1, out, why);
+}
+
+int gen_build_spec(int F, int H, int L, int depth_in, int depth_out, bool megno, int w8, GenArch* out, const char** why) {
+    return gen_build_impl(F, H, L, depth_in, depth_out, megno, true, w8, out, why);
+}
+
+int gen_spec_source(const GenArch& g, int noisy, char* buf, size_t cap) {
+    std::string s;
+    char t[256];
+    auto add = [&](const char* fmt, auto... a) { snprintf(t, sizeof t, fmt, a...); s += t; };
+    s += "// generated by bnn_spec_source (bnn_generic.cpp): the generic forward engine compiled for ONE network -- every shape a constant\n";
+    s += "#include \"bnn_generic.hip.h\"\n\nnamespace bnn {\nstruct SpecArch {\n    static DEVINL GenArch get(const GenParams&) {\n        constexpr GenArch value = {\n";
+    add("            %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d,\n            {\n", g.F, g.H, g.L, g.SM, g.d, g.megno, g.n_feat,
+        g.n_reg, g.nwreg, g.nbias, g.fq, g.hq, g.lq, g.smq, g.nin_blocks, g.reg_in_lds, g.nwaves, g.lds_bytes, g.off_inlv, g.off_sumlv);
+    for (int l = 0; l < g.n_feat + g.n_reg; ++l) {
+        const GenLayer& y = g.layer[l];
+        add("                {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d},\n", y.K, y.N, y.nkq, y.nblk, y.ng_last, y.off_w, y.off_b, y.wreg0, y.bias0, y.relu);
+    }
+    s += "            }};\n        return value;\n    }\n};\n}  // namespace bnn\n\n";
+    const bool w8 = g.nwaves == 8;
+    add("extern \"C\" __global__ __launch_bounds__(%d, 1) void bnn_spec_forward(const bnn::GenParams P) {\n", w8 ? 512 : 256);
+    add("    __shared__ __attribute__((aligned(16))) float lds[%d];\n", g.lds_bytes / 4);
+    add("    bnn::generic_body<%d, %d, %s, bnn::SpecArch, %d>(P, lds);\n}\n", g.fq, g.hq, w8 ? "true" : "false", noisy ? 1 : 0);
+    if (buf && cap) {
+        const size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return (int)s.size();
 }
 
 }  // namespace bnn

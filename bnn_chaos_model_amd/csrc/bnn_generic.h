@@ -12,6 +12,7 @@
 // MFMA a of the register multiplies input 4 kq + kk into neuron group 4 nb + q; per output the accumulation order is bias, then
 // the inputs ascending: the oracle's natural order, and bit for bit the v50 kernel's for feature_nn.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include "bnn_layout.h"
@@ -57,6 +58,15 @@ struct GenArch {
 // Host: build the descriptor.  Returns 0, or a negative code with *why set (unsupported width / depth, LDS budget).
 //   depth_in / depth_out = hparams['in'] / hparams['out'] (the `layers` argument of mlp()).
 int gen_build(int n_features, int hidden, int latent, int depth_in, int depth_out, bool megno, GenArch* out, const char** why);
+
+// Host: the descriptor of the network's SPECIALISED form (compiled at run time for this one network, bnn_spec_source): the activation
+// arrays are sized exactly (hq = 4 x the widest layer's blocks) instead of by bucket; w8 = 1 asks for the eight-wave / 256-register
+// form (refused when eight waves' LDS does not fit), 0 for four waves (or fewer) at 512 registers, -1 lets the builder choose.
+int gen_build_spec(int n_features, int hidden, int latent, int depth_in, int depth_out, bool megno, int w8, GenArch* out, const char** why);
+
+// Host: the HIP source of that form -- `static constexpr GenArch` + one extern "C" kernel `bnn_spec_forward` around generic_body.
+// Returns the length of the text (without the terminator); writes at most cap bytes.
+int gen_spec_source(const GenArch& g, int noisy, char* buf, size_t cap);
 
 // Per-wave LDS floats: pool state (mean, M2 per latent group, lane-major), Philox scratch, summaries, MEGNO partitions, and -- when
 // regress_nn's registers are not in the image -- a staging area for one block of them.

@@ -175,18 +175,27 @@ DEVINL void gen_merge(const GenMerge mg, float& ma, float& qa, float mb, float q
     }
 }
 
+// Where the kernel reads the network's shapes from.  ArchRuntime: the descriptor in global memory (scalar loads: the ahead-of-time
+// buckets, any network).  A policy whose get() returns a constexpr GenArch by value (written by bnn_spec_source, compiled at run time for ONE
+// network: specialize.py) turns every early exit, trip count and image offset below into a constant: the layer loops unroll into one
+// straight-line tile body that the compiler schedules as a whole, like the pretrained network's own kernel.
+struct ArchRuntime {
+    static DEVINL const GenArch& get(const GenParams& P) { return *P.g; }
+};
+
 // W8: the form compiled for 256 registers and launched with EIGHT waves per workgroup (two per SIMD sharing one weight image: the
 // partner wave's MFMAs fill this wave's LDS / memory waits -- a single wave per SIMD spent a quarter of its cycles parked in
 // s_waitcnt).  It exists for the 41-feature buckets of 12 and 16 quads and is chosen by the host when eight waves' LDS fits
 // (same-box A/B on a hidden-64 / latent-16 network: +13 %; where only four waves fit, the 256-register form's spills cost 5 %, so
 // those shapes run the 512-register form at one wave per SIMD, as the wider buckets always do).
-template <int FQ, int HQ, bool W8>
-__global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(const GenParams P) {
+// NOISY: -1 = read noisy (one kernel serves forward(noisy_val=False) and (True)); 0 / 1 = fixed at compile time (specialised forms).
+template <int FQ, int HQ, bool W8, class AS, int NOISY>
+DEVINL void generic_body(const GenParams& P, float* lds) {
     const FwdParams& p = P.f;
-    const GenArch& G = *P.g;
+    const GenArch& G = AS::get(P);   // (a temporary of constants in the specialised forms: its lifetime is the reference's)
+    const bool noisy = NOISY < 0 ? P.noisy != 0 : NOISY != 0;
     constexpr int NBLK_IN = FQ == 11 ? 7 : 14;   // Philox blocks of six normals per input row (41 / 82 columns)
     constexpr int FCOLS = FQ == 11 ? 41 : 82;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wimg = lds;
     float* bimg = wimg + gen_wimg_floats(G);
     float* nsc = bimg + G.nbias;   // exp(input_noise_logvar / 2) [4 * fq] | exp(summary_noise_logvar / 2) [4 * smq] | per noise block [8] scales | [8] keep-factors (1.0 | 0.0)
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
             const int neuron = 16 * nb + 4 * q + i, k = 4 * kq + kk;
             // zero_megno / zero_mmr / zero_nan / zero_eplusminus (:452-500) as zero weights on the masked input columns; the noisy
             // forward keeps them (masked columns carry pure noise)
-            const bool masked = li == 0 && !P.noisy && k < 64 && ((p.zero_mask >> k) & 1ull);
+            const bool masked = li == 0 && !noisy && k < 64 && ((p.zero_mask >> k) & 1ull);
             const bool live = neuron < ly.N && k < ly.K && !masked;
             const float v = We[live ? ly.off_w + neuron * ly.K + k : 0];
             wimg[R * 64 + lane] = live ? v : 0.0f;
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
             const int n = j - G.layer[li].bias0;
             bimg[j] = n < G.layer[li].N ? We[G.layer[li].off_b + n] : 0.0f;
         }
-        if (P.noisy) {   // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
+        if (noisy) {   // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
             for (int j = tid; j < 4 * FQ; j += blockDim.x) nsc[j] = j < F ? expf(We[G.off_inlv + j] / 2.0f) : 0.0f;
             for (int j = tid; j < 4 * smq; j += blockDim.x) nsc_sum[j] = j < SM ? expf(We[G.off_sumlv + j] / 2.0f) : 0.0f;
             for (int j = tid; j < 8 * NBLK_IN; j += blockDim.x) {   // the input scales per noise block, and keep-factors of the unmasked columns
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
                 gm2 = fmaf(dl, xm - mn, gm2);
                 gmean = mn;
             }
-            if (P.noisy) {   // masks, then add_input_noise (:486-506): masked columns become pure noise
+            if (noisy) {   // masks, then add_input_noise (:486-506): masked columns become pure noise
                 const float* er = p.eps_in ? p.eps_in + ((r * p.B + sysc0) * T + tc) * (int64_t)F : nullptr;
                 static_for<NBLK_IN>([&](auto BLK) {
                     constexpr int blk = BLK;
@@ -451,7 +460,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
             for (int n = SM; n < SMS; ++n) sumscr[sl * SMS + n] = 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
-        if (P.noisy) {   // add_summary_noise (:448-450), on the LDS copy: lane ph takes summary quads ph, ph + 4, ...
+        if (noisy) {   // add_summary_noise (:448-450), on the LDS copy: lane ph takes summary quads ph, ph + 4, ...
             const float* es = p.eps_sum ? p.eps_sum + (r * p.B + sysc) * SM : nullptr;
             for (int kq = ph; kq < smq; kq += 4) {
                 f32x4 nz;
@@ -503,6 +512,12 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
         }
         __builtin_amdgcn_wave_barrier();  // scratch is reused by the next wave-batch
     }
+}
+
+template <int FQ, int HQ, bool W8>
+__global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(const GenParams P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    generic_body<FQ, HQ, W8, ArchRuntime, -1>(P, lds);
 }
 
 template <int FQ, int HQ, bool W8>

@@ -62,6 +62,22 @@ def get_plan(zero_mask=V50_ZERO_MASK, lowest_std=0.5, device=None, fix_megno=Fal
     return _plans[key]
 
 
+def specialize(plan=None, noisy=(False, True), w8=None, verbose=False):
+    """Compile this plan's network into its own form of the generic engine (specialize.py: ~10 s of hipcc per form, cached on disk)
+    and attach it; bit-identical results, the pretrained network's schedule quality for any hparams-built network."""
+    from . import specialize as S
+    plan = plan or get_plan()
+    with torch.cuda.device(plan_device(plan)):
+        return S.specialize(plan, noisy=noisy, w8=w8, verbose=verbose)
+
+
+def plan_device(plan):
+    for k, v in _plans.items():
+        if v is plan:
+            return k[0]
+    return torch.cuda.current_device()
+
+
 def _check_x(x, plan):
     if x.dim() != 3 or x.shape[2] != plan.n_features:
         raise NotImplementedError(f"x must be [B, T, {plan.n_features}]")  # figures/spock/regression.py:210-211
@@ -81,7 +97,7 @@ def _f32(t, name):
     return t.contiguous()
 
 
-ENGINES = {"auto": 0, "generic": 1}
+ENGINES = {"auto": 0, "generic": 1, "spec": 2}
 
 
 def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto", chunk_B=0, chunk_off=0):
@@ -137,7 +153,8 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     precision: "f32" (default: the parity path) or the OPT-IN reduced-precision forms "bf16" / "bf16x3" / "bf16x6" / "f16" /
     "f16x3" (feature_nn on the bf16 / half matrix pipe; BASELINE configs[4] sweep; v50 mask, quiet forward only).
     engine: "auto" = the pretrained network at T % 4 == 0, T >= 8 runs on its register-resident kernels, every other shape on the
-    generic engine; "generic" forces the generic engine (cross-checks, measurements).
+    generic engine (in the network's run-time-compiled form once `specialize(plan)` has attached one); "generic" forces the generic
+    engine's ahead-of-time form (cross-checks, measurements); "spec" insists on the specialised form.
     PRECONDITION of "f16" / "f16x3": |x| < 65 504 in the live columns (half_range_exceeded(x) names the rows that violate it;
     their outputs are finite but wrong).  This op never synchronises, so it does not check; the FeatureRegressor surface does."""
     plan = plan or get_plan()
@@ -268,7 +285,7 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, plan.summary_width), dtype=torch.float32, device=x.device) if debug else None
     g = _grid(B, T, J, nchunks, systems_per_block, engine=engine, chunk_B=chunk_B, chunk_off=chunk_off)
-    if not fused_draw_available(plan, T, K) or engine == "generic":
+    if not fused_draw_available(plan, T, K) or engine != "auto":
         if single_launch:
             raise NotImplementedError("single_launch (in-prologue draw) exists for the pretrained network at T % 4 == 0, K <= 32 only")
         single_launch = False

@@ -248,6 +248,13 @@ class VarModel:
         self.training = False
         return self
 
+    def specialize(self, noisy=(False, True), w8=None):
+        """Not in the reference (PyTorch needs no such step): compile this model's network into its own form of the generic forward
+        engine (specialize.py: ~10 s of hipcc per form, cached on disk) -- bit-identical outputs, the schedule of a kernel written
+        for these shapes.  The pretrained ensemble's network at T % 4 == 0 keeps its own kernels either way."""
+        ops.specialize(self._plan(), noisy=noisy, w8=w8)
+        return self
+
     def train(self, mode=True):
         self.training = mode
         return self

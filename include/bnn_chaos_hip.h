@@ -21,6 +21,7 @@
 #ifndef BNN_CHAOS_HIP_H
 #define BNN_CHAOS_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -76,6 +77,17 @@ const char* bnn_build_flags(void); /* "" for the default build; otherwise the ex
 /* Plans own a few KB of device memory; create/destroy allocate and synchronise, nothing else does. */
 int bnn_plan_create(const bnn_arch* arch, bnn_plan** out);
 int bnn_plan_destroy(bnn_plan* plan);
+
+/* Specialised forms of the generic engine: the same kernel source compiled for ONE network, every shape a
+ * compile-time constant.  bnn_spec_source writes the HIP source text (needs no device; returns its length, or a negative status;
+ * compile it with hipcc --genco --offload-arch=gfx950 -I<csrc> and the library's own flags: bnn_chaos_model_amd/specialize.py does);
+ * bnn_plan_attach_spec loads the resulting code object into the plan (current device = the plan's); from then on the generic route
+ * of every entry point launches it for that `noisy` form.  w8: 1 = eight waves at 256 registers, 0 = at most four at 512,
+ * -1 = the builder's choice -- the same value must be given to both calls.  Results are bit-identical to the ahead-of-time form's
+ * (same accumulation order); what changes is the schedule. */
+int bnn_spec_source(const bnn_arch* arch, int32_t w8, int32_t noisy, char* buf, size_t cap);
+int bnn_plan_attach_spec(bnn_plan* plan, int32_t noisy, int32_t w8, const void* image, size_t bytes);
+int bnn_plan_spec_attached(const bnn_plan* plan, int32_t noisy); /* 1 / 0 */
 /* Accumulation order used by the kernels for Linear layer `layer` (0 .. number of Linear modules - 1, feature_nn's first): `order`
  * receives up to `cap` entries (input indices; the accumulator starts at the bias).  The generic engine's order is the natural one
  * (0, 1, 2, ...) for every layer; the v50 kernels permute regress_nn's.
@@ -105,8 +117,10 @@ typedef struct bnn_grid {
     int32_t systems_per_block; /* 0 = choose; else a multiple of 64                                */
     int32_t noisy;   /* bnn_forward_f32 only: 1 = forward(noisy_val=True) with ALL noise generated in-kernel
                         (eps, eps_in, eps_sum all NULL); explicit eps_in/eps_sum imply noisy regardless          */
-    int32_t engine;  /* 0 = choose (the pretrained network at T % 4 == 0, T >= 8: its register-resident kernels; else the generic engine);
-                        1 = the generic engine whatever the shape (cross-checks, measurements)               */
+    int32_t engine;  /* 0 = choose (the pretrained network at T % 4 == 0, T >= 8: its register-resident kernels; else the generic engine,
+                            in the network's specialised form when one is attached to the plan);
+                        1 = the generic engine's ahead-of-time form whatever the shape (cross-checks, measurements);
+                        2 = the specialised form (error when none is attached)                                   */
     int64_t chunk_B;   /* nchunks > 1 with the batch sharded over devices: the chunks partition the WHOLE batch of chunk_B systems  */
     int64_t chunk_off; /* (torch.chunk semantics, chunk size ceil(chunk_B / nchunks)), of which this call holds rows
                           [chunk_off, chunk_off + B); a draw covers the part of its chunk that lies in the shard.  0, 0 = the call

@@ -1,0 +1,104 @@
+"""Run-time specialised forms of the generic forward engine (specialize.py): the same kernel source compiled
+for ONE network with every shape a constant.  Same accumulation order, same arithmetic as the ahead-of-time form -> BIT-IDENTICAL
+outputs (mu, std, pre-clamp, summary, latents-free) on every network of the fixture set, quiet and noisy, at ragged T, with the
+statistics tail, and through the surface.  Needs an MI355X and hipcc (the ROCm image has it)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import close_report, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bnn_chaos_model_amd import ops as o
+    return o
+
+
+def _plan(ops, hidden, latent, din, dout, nf=41, megno=False, mask=None):
+    mask = ops.V50_ZERO_MASK if mask is None else mask
+    if megno:
+        mask |= 1 << 7
+    return ops.get_plan(mask, 0.5, fix_megno=megno, n_features=nf, hidden=hidden, latent=latent, depth_in=din, depth_out=dout)
+
+
+NETS = [(40, 20, 1, 1, 41, False), (64, 16, 1, 1, 41, False), (20, 10, 1, 1, 41, False), (33, 7, 1, 1, 41, False), (40, 20, 2, 2, 41, False),
+        (30, 12, 0, 0, 41, False), (40, 20, 1, 1, 82, False), (48, 24, 1, 1, 41, True), (100, 30, 1, 1, 41, False)]
+
+
+@pytest.mark.parametrize("net", NETS, ids=lambda n: "h%dl%d_%d%d_f%d%s" % (n[0], n[1], n[2], n[3], n[4], "_megno" if n[5] else ""))
+def test_specialised_form_is_bit_identical_to_the_generic_engine(net, ops):
+    H, L, din, dout, NF, megno = net
+    plan = _plan(ops, H, L, din, dout, NF, megno)
+    ops.specialize(plan)
+    assert plan.spec_attached(False) and plan.spec_attached(True)
+    g = torch.Generator(device="cuda").manual_seed(H * 1000 + L)
+    R = 3
+    W = torch.randn(R, plan.d, generator=g, device="cuda") * 0.25
+    for T, B in ((100, 70), (37, 33), (2, 5)):
+        x = torch.randn(B, T, NF, generator=g, device="cuda")
+        for noisy in (False, True):
+            kw = dict(philox_seed=11, draw_id0=3, system_id0=17, plan=plan, noisy=noisy, debug=True)
+            a = ops.forward(x, W, engine="generic", **kw)
+            b = ops.forward(x, W, engine="spec", **kw)
+            c = ops.forward(x, W, **kw)                       # "auto" takes the specialised form once attached ...
+            for u, v, w in zip(a, b, c):
+                assert torch.equal(u, v) and (torch.equal(u, w) or (plan.v50net and T % 4 == 0 and T >= 8)), (net, T, noisy)   # (... except where the pretrained network's own kernels run)
+            assert torch.isfinite(a[0]).all()
+    # chunked draws + the fused statistics tail
+    x = torch.randn(130, 100, NF, generator=g, device="cuda")
+    W6 = torch.randn(6, plan.d, generator=g, device="cuda") * 0.25
+    a = ops.forward(x, W6, nchunks=3, philox_seed=5, plan=plan, engine="generic")
+    b = ops.forward(x, W6, nchunks=3, philox_seed=5, plan=plan, engine="spec")
+    assert torch.equal(a, b)
+
+
+def test_both_wave_forms_and_errors(ops):
+    plan = _plan(ops, 56, 14, 1, 1)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    W = torch.randn(2, plan.d, generator=g, device="cuda") * 0.25
+    x = torch.randn(50, 100, 41, generator=g, device="cuda")
+    from bnn_chaos_model_amd import _native as N
+    with pytest.raises(N.NativeError):
+        ops.forward(x, W, plan=plan, engine="spec")           # nothing attached yet: an error, not a silent fallback
+    ref = ops.forward(x, W, philox_seed=2, plan=plan, engine="generic")
+    for w8 in (False, True):
+        ops.specialize(plan, noisy=(False,), w8=w8)
+        assert torch.equal(ops.forward(x, W, philox_seed=2, plan=plan, engine="spec"), ref), w8
+    with pytest.raises(N.NativeError):
+        ops.forward(x, W, plan=plan, engine="spec", noisy=True)   # only the quiet form was attached
+    big = _plan(ops, 128, 32, 1, 1)
+    with pytest.raises(N.NativeError):
+        ops.specialize(big, noisy=(False,), w8=True)              # eight waves' pool state does not fit next to that image
+
+
+def test_surface_specialize(tmp_path, ops):
+    """load_swag(...).specialize(): forward_swag_fast / forward replay the reference's fixture through the specialised form."""
+    from bnn_chaos_model_amd import checkpoint, spock_reg_model as srm
+    z = load_golden("case_arch_h64l16.npz")
+    hp = json.loads(str(z["hparams_json"]))
+    for k, v in list(hp.items()):
+        if isinstance(v, str) and v in ("True", "False"):
+            hp[k] = v == "True"
+    p = tmp_path / "h64_output.pkl"
+    checkpoint.write_swag_file(str(p), hp, json.loads(str(z["swa_params_json"])), torch.tensor(z["w_avg"]), torch.tensor(z["w2_avg"]), torch.tensor(z["pre_D"]))
+    m = srm.load_swag(str(p)).eval().specialize()
+    x = torch.tensor(z["x"])
+    torch.manual_seed(hp["seed"] + 2)
+    out = m.forward_swag_fast(x, scale=0.5)
+    nbad, mx = close_report(out.numpy(), z["swagfast_out"])
+    assert nbad == 0, (nbad, mx)
+    for noisy in (False, True):
+        torch.manual_seed(hp["seed"] + 3 + int(noisy))
+        o = m(x, noisy_val=noisy)
+        nbad, mx = close_report(o.numpy(), z[f"forward_noisy{int(noisy)}_out"])
+        assert nbad == 0, (noisy, nbad, mx)
+    assert m._plan().spec_attached(False) and m._plan().spec_attached(True)
