@@ -84,7 +84,7 @@ def lib():
                                     C.c_uint64, C.c_int64, _vp, _vp]
     L.bnn_forward_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64,
                                   _vp, _vp, _vp, _vp]
-    L.bnn_spec_source.argtypes = [C.POINTER(BnnArch), C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
+    L.bnn_spec_source.argtypes = [C.POINTER(BnnArch), C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
     L.bnn_plan_attach_spec.argtypes = [_vp, C.c_int32, C.c_int32, _vp, C.c_size_t]
     L.bnn_plan_spec_attached.argtypes = [_vp, C.c_int32]
     L.bnn_feature_nn_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp]
@@ -148,6 +148,18 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+SPEC_POOL_REGS = 1
+SPEC_BLOCK_MAJOR = 2
+
+
+def spec_source(arch, noisy=False, w8=None, flags=0):
+    w = -1 if w8 is None else int(bool(w8))
+    n = check(lib().bnn_spec_source(C.byref(arch), w, int(bool(noisy)), int(flags), None, 0))
+    buf = C.create_string_buffer(n + 1)
+    check(lib().bnn_spec_source(C.byref(arch), w, int(bool(noisy)), int(flags), buf, n + 1))
+    return buf.value.decode()
+
+
 class Plan:
     """Owns a bnn_plan (device operand tables) for one architecture / column mask.
     depth_in / depth_out = hparams['in'] / hparams['out'] (the `layers` argument of the reference's mlp(), spock_reg_model.py:301-321)."""
@@ -166,13 +178,9 @@ class Plan:
         check(lib().bnn_plan_create(C.byref(self.arch), C.byref(h)))
         self.handle = h
 
-    def spec_source(self, noisy=False, w8=None):
+    def spec_source(self, noisy=False, w8=None, flags=0):
         """HIP source of this network's specialised form of the generic engine (bnn_spec_source; needs no device)."""
-        w = -1 if w8 is None else int(bool(w8))
-        n = check(lib().bnn_spec_source(C.byref(self.arch), w, int(bool(noisy)), None, 0))
-        buf = C.create_string_buffer(n + 1)
-        check(lib().bnn_spec_source(C.byref(self.arch), w, int(bool(noisy)), buf, n + 1))
-        return buf.value.decode()
+        return spec_source(self.arch, noisy, w8, flags)
 
     def attach_spec(self, image, noisy=False, w8=None):
         """Load a compiled specialised form (code object bytes) into the plan; the current device must be the plan's."""

@@ -641,14 +641,15 @@ int bnn_plan_destroy(bnn_plan* pl) {
     return 0;
 }
 
-int bnn_spec_source(const bnn_arch* arch, int32_t w8, int32_t noisy, char* buf, size_t cap) {
+int bnn_spec_source(const bnn_arch* arch, int32_t w8, int32_t noisy, int32_t flags, char* buf, size_t cap) {
     int rc = check_arch(arch);
     if (rc) return rc;
     GenArch g;
     const char* why = "";
     if (gen_build_spec(arch->n_features, arch->hidden, arch->latent, arch->depth_in, arch->depth_out, arch->fix_megno != 0, w8, &g, &why))
         return fail(BNN_ERR_UNSUPPORTED, why);
-    return gen_spec_source(g, noisy, buf, cap);
+    if (flags & ~(BNN_SPEC_POOL_REGS | BNN_SPEC_BLOCK_MAJOR)) return fail(BNN_ERR_INVALID, "unknown specialisation flag");
+    return gen_spec_source(g, noisy, (flags & BNN_SPEC_POOL_REGS) ? 1 : 0, (flags & BNN_SPEC_BLOCK_MAJOR) ? 1 : 0, buf, cap);
 }
 
 int bnn_plan_attach_spec(bnn_plan* pl, int32_t noisy, int32_t w8, const void* image, size_t bytes) {

@@ -99,12 +99,17 @@ int gen_build_spec(int F, int H, int L, int depth_in, int depth_out, bool megno,
     return gen_build_impl(F, H, L, depth_in, depth_out, megno, true, w8, out, why);
 }
 
-int gen_spec_source(const GenArch& g, int noisy, char* buf, size_t cap) {
+int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, char* buf, size_t cap) {
     std::string s;
     char t[256];
     auto add = [&](const char* fmt, auto... a) { snprintf(t, sizeof t, fmt, a...); s += t; };
     s += "// generated by bnn_spec_source (bnn_generic.cpp): the generic forward engine compiled for ONE network -- every shape a constant\n";
-    s += "#include \"bnn_generic.hip.h\"\n\nnamespace bnn {\nstruct SpecArch {\n    static DEVINL GenArch get(const GenParams&) {\n        constexpr GenArch value = {\n";
+    s += "#include \"bnn_generic.hip.h\"\n\nnamespace bnn {\nstruct SpecArch {\n";
+    add("    static constexpr bool kq_major = %s;\n", block_major ? "false" : "true");
+    add("    static constexpr int n_feat = %d, n_reg = %d;\n", g.n_feat, g.n_reg);
+    add("    static constexpr int pool_lq = %d, lat_nfull = %d;   // Welford state of the pool in registers (0: in LDS)\n", pool_regs ? g.lq : 0,
+        4 * (g.layer[g.n_feat - 1].nblk - 1));
+    s += "    static DEVINL GenArch get(const GenParams&) {\n        constexpr GenArch value = {\n";
     add("            %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d,\n            {\n", g.F, g.H, g.L, g.SM, g.d, g.megno, g.n_feat,
         g.n_reg, g.nwreg, g.nbias, g.fq, g.hq, g.lq, g.smq, g.nin_blocks, g.reg_in_lds, g.nwaves, g.lds_bytes, g.off_inlv, g.off_sumlv);
     for (int l = 0; l < g.n_feat + g.n_reg; ++l) {

@@ -66,7 +66,7 @@ int gen_build_spec(int n_features, int hidden, int latent, int depth_in, int dep
 
 // Host: the HIP source of that form -- `static constexpr GenArch` + one extern "C" kernel `bnn_spec_forward` around generic_body.
 // Returns the length of the text (without the terminator); writes at most cap bytes.
-int gen_spec_source(const GenArch& g, int noisy, char* buf, size_t cap);
+int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, char* buf, size_t cap);
 
 // Per-wave LDS floats: pool state (mean, M2 per latent group, lane-major), Philox scratch, summaries, MEGNO partitions, and -- when
 // regress_nn's registers are not in the image -- a staging area for one block of them.

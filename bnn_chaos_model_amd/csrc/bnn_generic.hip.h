@@ -144,6 +144,106 @@ DEVINL void gen_layer(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLayer 
     else gen_block<1, NQO - 4>(in, out, in_nfull, ntail, wl, bl, lim);
 }
 
+// The same Linear, INPUT-QUAD-MAJOR (the specialised forms: every count below is a compile-time constant there, the early exits fold
+// away and a layer is one straight-line run of MFMAs).  Step kq multiplies input quad kq into EVERY output block -- per output the
+// order is still bias, then inputs ascending -- so that
+//   * a step's 4 kk x (4 (nblk - 1) + ng_last) MFMAs interleave all of the layer's accumulator chains: consecutive MFMAs on one
+//     accumulator are a whole row of neuron groups apart (the block-major order leaves the last block's 1-3 chains back to back,
+//     an s_nop each), and
+//   * the weight registers are consumed in image order (register (kq, nb) = entry kq * nblk + nb of the layer: AS::kq_major images)
+//     one step AHEAD: step kq + 1's nblk registers are requested before step kq's MFMAs are issued, the first step's by the previous
+//     layer (w0), and the tail steps' at the top of the layer -- no MFMA waits on an LDS read issued just above it.
+// A scheduling barrier behind each request keeps the compiler from sinking the reads back down to their first use (it does,
+// to shorten live ranges: the first specialised build waited lgkmcnt(0) in front of every 32 MFMAs).
+#ifndef BNN_GEN_SCHED_MASK
+#define BNN_GEN_SCHED_MASK 0
+#endif
+template <int NQI, int NQO, bool TRIM, int NQN = NQO>
+DEVINL void gen_layer_kq(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLayer ly, int in_nfull, const float* wimg, const float* bimg, int lane,
+                         float (&w0)[NQO / 4], bool have_w0, const GenLayer* next) {
+    constexpr int NB = NQO / 4;
+    const int nkq = ly.nkq, nblk = ly.nblk, ntail = nkq - in_nfull;
+    const int lim = ly.relu ? 0 : (int)0x80000000;
+    const int ng = TRIM ? ly.ng_last : 4;
+    const f32x4* bq = reinterpret_cast<const f32x4*>(bimg + ly.bias0);
+    const float* wp = wimg + (size_t)ly.wreg0 * 64 + lane;
+    auto load = [&](float (&w)[NB], const float* s, int nb_) {   // one step's registers: blocks 0 .. nb_ - 2 at their slots, the last at slot NB - 1
+        static_while<NB - 1>([&](auto NBI) {
+            constexpr int nb = NBI;
+            if (nb >= nb_ - 1) return false;
+            w[nb] = s[nb * 64];
+            return true;
+        });
+        w[NB - 1] = s[(nb_ - 1) * 64];
+    };
+    float wt[4][NB], w[2][NB];
+    static_while<4>([&](auto J) {   // the tail steps (logical quads in_nfull + j): a whole layer to land
+        constexpr int j = J;
+        if (j >= ntail) return false;
+        load(wt[j], wp + (size_t)(in_nfull + j) * nblk * 64, nblk);
+        return true;
+    });
+    if (!have_w0) load(w0, wp, nblk);
+    static_while<NB - 1>([&](auto NBI) {
+        constexpr int nb = NBI;
+        if (nb >= nblk - 1) return false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[4 * nb + q] = bq[4 * nb + q];
+        return true;
+    });
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[NQO - 4 + q] = bq[4 * (nblk - 1) + q];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) w[0][nb] = w0[nb];
+    auto step = [&](const float (&wr)[NB], const f32x4 xin) {
+        static_for<4>([&](auto KK) {
+            constexpr int kk = KK;
+            static_while<NB - 1>([&](auto NBI) {
+                constexpr int nb = NBI;
+                if (nb >= nblk - 1) return false;
+                static_for<4>([&](auto Q) {
+                    constexpr int q = Q;
+                    out[4 * nb + q] = mfma4b<4 * kk + q>(wr[nb], xin[kk], out[4 * nb + q]);
+                });
+                return true;
+            });
+            static_for<4>([&](auto Q) {
+                constexpr int q = Q;
+                if (q < ng) out[NQO - 4 + q] = mfma4b<4 * kk + q>(wr[NB - 1], xin[kk], out[NQO - 4 + q]);
+            });
+        });
+    };
+    const bool pre_next = next != nullptr;
+    static_while<NQI>([&](auto S) {
+        constexpr int s_ = S;
+        if (s_ >= in_nfull) return false;
+        if (s_ + 1 < in_nfull) load(w[(s_ + 1) & 1], wp + (size_t)(s_ + 1) * nblk * 64, nblk);
+        else if (pre_next && ntail == 0) load(w0, wimg + (size_t)next->wreg0 * 64 + lane, next->nblk);
+        __builtin_amdgcn_sched_barrier(BNN_GEN_SCHED_MASK);
+        step(w[s_ & 1], in[s_]);
+        return true;
+    });
+    static_while<4>([&](auto J) {
+        constexpr int j = J;
+        if (j >= ntail) return false;
+        if (pre_next && j + 1 == ntail) {
+            load(w0, wimg + (size_t)next->wreg0 * 64 + lane, next->nblk);
+            __builtin_amdgcn_sched_barrier(BNN_GEN_SCHED_MASK);
+        }
+        step(wt[j], in[NQI - 4 + j]);
+        return true;
+    });
+    static_while<NB - 1>([&](auto NBI) {
+        constexpr int nb = NBI;
+        if (nb >= nblk - 1) return false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[4 * nb + q] = relu_lim4(out[4 * nb + q], lim);
+        return true;
+    });
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[NQO - 4 + q] = relu_lim4(out[NQO - 4 + q], lim);
+}
+
 // A regress_nn layer whose registers did not fit the LDS image: block nb's registers are gathered from the flat vector (L2) into the
 // wave's staging area, eight loads in flight, and the layer routine above then runs one block at a time from there.
 DEVINL void gen_stage_block(const GenLayer ly, int nb, const float* __restrict__ We, float* stage, int lane) {
@@ -179,7 +279,14 @@ DEVINL void gen_merge(const GenMerge mg, float& ma, float& qa, float mb, float q
 // buckets, any network).  A policy whose get() returns a constexpr GenArch by value (written by bnn_spec_source, compiled at run time for ONE
 // network: specialize.py) turns every early exit, trip count and image offset below into a constant: the layer loops unroll into one
 // straight-line tile body that the compiler schedules as a whole, like the pretrained network's own kernel.
+// pool_regs_of<AS>::lq: latent groups whose Welford state the tile loop keeps in registers (policies that declare pool_lq; else 0 = LDS)
+template <class AS, class = void>
+struct pool_regs_of { static constexpr int lq = 0; };
+template <class AS>
+struct pool_regs_of<AS, std::void_t<decltype(AS::pool_lq)>> { static constexpr int lq = AS::pool_lq; };
+
 struct ArchRuntime {
+    static constexpr bool kq_major = false;   // weight image block-major (register (nb, kq) at nb * nkq + kq), gen_layer
     static DEVINL const GenArch& get(const GenParams& P) { return *P.g; }
 };
 
@@ -234,7 +341,8 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
             for (int l = 1; l < nl; ++l)
                 if (G.layer[l].wreg0 >= 0 && R >= G.layer[l].wreg0) li = l;
             const GenLayer ly = G.layer[li];
-            const int rr = R - ly.wreg0, nb = rr / ly.nkq, kq = rr - nb * ly.nkq;
+            const int rr = R - ly.wreg0;
+            const int nb = AS::kq_major ? rr % ly.nblk : rr / ly.nkq, kq = AS::kq_major ? rr / ly.nblk : rr - nb * ly.nkq;
             const int neuron = 16 * nb + 4 * q + i, k = 4 * kq + kk;
             // zero_megno / zero_mmr / zero_nan / zero_eplusminus (:452-500) as zero weights on the masked input columns; the noisy
             // forward keeps them (masked columns carry pure noise)
@@ -283,9 +391,11 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
         const bool valid0 = sys0 < b1;
         const int64_t sysc0 = valid0 ? sys0 : b1 - 1;
         const float* sysp = p.x + sysc0 * rowstride;
-        for (int g = 0; g < lq; ++g) {
-            poolm4[g * 64 + lane] = (f32x4){0, 0, 0, 0};
-            poolq4[g * 64 + lane] = (f32x4){0, 0, 0, 0};
+        if constexpr (pool_regs_of<AS>::lq == 0) {
+            for (int g = 0; g < lq; ++g) {
+                poolm4[g * 64 + lane] = (f32x4){0, 0, 0, 0};
+                poolq4[g * 64 + lane] = (f32x4){0, 0, 0, 0};
+            }
         }
         float gmean = 0.0f, gm2 = 0.0f;
         // XPREF: the next tile's rows are fetched right behind layer 1 of the current one (a tile of work to land).  The widest
@@ -298,10 +408,28 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
             asm volatile("" ::: "memory");
         }
         f32x4 a[HQ], b[HQ];
+        float w0[HQ / 4];   // kq-major forms: the first step's weight registers of the NEXT layer, requested by the layer before it
+        if constexpr (AS::kq_major) {
+            const float* s0 = wimg + (size_t)G.layer[0].wreg0 * 64 + lane;
+            static_while<HQ / 4 - 1>([&](auto NBI) {
+                constexpr int nb = NBI;
+                if (nb >= G.layer[0].nblk - 1) return false;
+                w0[nb] = s0[nb * 64];
+                return true;
+            });
+            w0[HQ / 4 - 1] = s0[(G.layer[0].nblk - 1) * 64];
+        }
         // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps, state in LDS
         const int lat_nfull = 4 * (G.layer[G.n_feat - 1].nblk - 1);   // latent groups at their natural quads; the rest at the array's tail
-        auto welford = [&](const f32x4 y, int g, float rcn) {
-            f32x4 mean = poolm4[g * 64 + lane], m2 = poolq4[g * 64 + lane];
+        // (specialised forms with AS::pool_regs: the state stays in registers across the tiles -- latent groups are compile-time there --
+        // and is written to the same LDS rows once, in front of the tail)
+        constexpr int PLQ = pool_regs_of<AS>::lq;
+        f32x4 pm[PLQ > 0 ? PLQ : 1], pq[PLQ > 0 ? PLQ : 1];
+        if constexpr (PLQ > 0) {
+#pragma unroll
+            for (int g = 0; g < PLQ; ++g) { pm[g] = (f32x4){0, 0, 0, 0}; pq[g] = (f32x4){0, 0, 0, 0}; }
+        }
+        auto welford_step = [](const f32x4 y, float rcn, f32x4& mean, f32x4& m2) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float dl = y[i] - mean[i];
@@ -309,31 +437,43 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
                 m2[i] = fmaf(dl, y[i] - mn, m2[i]);
                 mean[i] = mn;
             }
-            poolm4[g * 64 + lane] = mean;
-            poolq4[g * 64 + lane] = m2;
         };
         float* latrow = nullptr;   // this lane's row of the latents output (debug / side-effect output, bnn_feature_nn_f32)
-        auto welford_out = [&](const f32x4 y, int g, float rcn) {
-            welford(y, g, rcn);
+        auto latents_out = [&](const f32x4 y, int g) __attribute__((always_inline)) {
             if (latrow) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (4 * g + i < L) latrow[4 * g + i] = y[i];
             }
         };
-        auto pool = [&](const f32x4 (&y)[HQ], float rcn) {
-            static_while<HQ - 4>([&](auto GI) {
-                constexpr int g = GI;
-                if (g >= lat_nfull) return false;
-                welford_out(y[g], g, rcn);
-                return true;
-            });
-            static_while<4>([&](auto JI) {
-                constexpr int j = JI;
-                if (lat_nfull + j >= lq) return false;
-                welford_out(y[HQ - 4 + j], lat_nfull + j, rcn);
-                return true;
-            });
+        auto welford_out = [&](const f32x4 y, int g, float rcn) __attribute__((always_inline)) {
+            f32x4 mean = poolm4[g * 64 + lane], m2 = poolq4[g * 64 + lane];
+            welford_step(y, rcn, mean, m2);
+            poolm4[g * 64 + lane] = mean;
+            poolq4[g * 64 + lane] = m2;
+            latents_out(y, g);
+        };
+        auto pool = [&](const f32x4 (&y)[HQ], float rcn) __attribute__((always_inline)) {
+            if constexpr (PLQ > 0) {
+                static_for<PLQ>([&](auto GI) {
+                    constexpr int g = GI, phys = g < AS::lat_nfull ? g : HQ - 4 + (g - AS::lat_nfull);
+                    welford_step(y[phys], rcn, pm[g], pq[g]);
+                    latents_out(y[phys], g);
+                });
+            } else {
+                static_while<HQ - 4>([&](auto GI) {
+                    constexpr int g = GI;
+                    if (g >= lat_nfull) return false;
+                    welford_out(y[g], g, rcn);
+                    return true;
+                });
+                static_while<4>([&](auto JI) {
+                    constexpr int j = JI;
+                    if (lat_nfull + j >= lq) return false;
+                    welford_out(y[HQ - 4 + j], lat_nfull + j, rcn);
+                    return true;
+                });
+            }
         };
 
         for (int it = 0; it < ntiles; ++it) {
@@ -374,7 +514,16 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
                     }
                 });
             }
-            gen_layer<FQ, HQ, true>(xr, a, G.layer[0], G.layer[0].nkq, wimg, bimg, lane);
+            auto layer_first = [&](const f32x4 (&in_)[FQ], f32x4 (&out_)[HQ]) __attribute__((always_inline)) {
+                if constexpr (AS::kq_major) gen_layer_kq<FQ, HQ, true>(in_, out_, G.layer[0], G.layer[0].nkq, wimg, bimg, lane, w0, true, &G.layer[G.n_feat > 1 ? 1 : 0]);
+                else gen_layer<FQ, HQ, true>(in_, out_, G.layer[0], G.layer[0].nkq, wimg, bimg, lane);
+            };
+            auto layer_next = [&](const f32x4 (&in_)[HQ], f32x4 (&out_)[HQ], int l_) __attribute__((always_inline)) {
+                if constexpr (AS::kq_major)
+                    gen_layer_kq<HQ, HQ, true>(in_, out_, G.layer[l_], 4 * (G.layer[l_ - 1].nblk - 1), wimg, bimg, lane, w0, true, &G.layer[l_ + 1 < G.n_feat ? l_ + 1 : 0]);
+                else gen_layer<HQ, HQ, true>(in_, out_, G.layer[l_], 4 * (G.layer[l_ - 1].nblk - 1), wimg, bimg, lane);
+            };
+            layer_first(xr, a);
             // x of this tile is dead: fetch the next tile's rows into the same registers
             if constexpr (XPREF) {
                 const int tn = 4 * (it + 1) + ph0;
@@ -384,17 +533,21 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
             // the remaining Linear modules of feature_nn, ping-pong between the two register arrays
             int l = 1;
             for (; l + 1 < G.n_feat; l += 2) {
-                gen_layer<HQ, HQ, true>(a, b, G.layer[l], 4 * (G.layer[l - 1].nblk - 1), wimg, bimg, lane);
-                gen_layer<HQ, HQ, true>(b, a, G.layer[l + 1], 4 * (G.layer[l].nblk - 1), wimg, bimg, lane);
+                layer_next(a, b, l);
+                layer_next(b, a, l + 1);
             }
             if (l < G.n_feat) {
-                gen_layer<HQ, HQ, true>(a, b, G.layer[l], 4 * (G.layer[l - 1].nblk - 1), wimg, bimg, lane);
+                layer_next(a, b, l);
                 if (tv) pool(b, rcn);   // lanes past T sit the tile out
             } else if (tv) {
                 pool(a, rcn);
             }
         }
 
+        if constexpr (PLQ > 0) {
+#pragma unroll
+            for (int g = 0; g < PLQ; ++g) { poolm4[g * 64 + lane] = pm[g]; poolq4[g * 64 + lane] = pq[g]; }
+        }
         // ---- tail: merge the four partitions of every latent, sampled moments (compute_summary_stats :420-431)
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
@@ -492,11 +645,22 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
         float r0, r1;   // the two outputs are neurons 0, 1 of the last Linear's only (= last) block
         {
             int nfull = smq;   // the summary sits at its natural quads
-            for (int l = G.n_feat; l < nl; ++l) {
-                gen_layer<HQ, HQ, false, true>(a, b, G.layer[l], nfull, wimg, bimg, lane, We, stage);
-                nfull = 4 * (G.layer[l].nblk - 1);
+            if constexpr (AS::kq_major) {   // (compile-time layer count: unrolled, every layer's shapes fold)
+                static_for<AS::n_reg>([&](auto LI) {
+                    constexpr int l = AS::n_feat + LI;
+                    if (G.layer[l].wreg0 >= 0) gen_layer_kq<HQ, HQ, false>(a, b, G.layer[l], nfull, wimg, bimg, lane, w0, false, nullptr);
+                    else gen_layer<HQ, HQ, false, true>(a, b, G.layer[l], nfull, wimg, bimg, lane, We, stage);
+                    nfull = 4 * (G.layer[l].nblk - 1);
 #pragma unroll
-                for (int i = 0; i < HQ; ++i) a[i] = b[i];
+                    for (int i = 0; i < HQ; ++i) a[i] = b[i];
+                });
+            } else {
+                for (int l = G.n_feat; l < nl; ++l) {
+                    gen_layer<HQ, HQ, false, true>(a, b, G.layer[l], nfull, wimg, bimg, lane, We, stage);
+                    nfull = 4 * (G.layer[l].nblk - 1);
+#pragma unroll
+                    for (int i = 0; i < HQ; ++i) a[i] = b[i];
+                }
             }
             r0 = a[HQ - 4][0]; r1 = a[HQ - 4][1];
         }

@@ -26,9 +26,17 @@ _DEPS = ("bnn_generic.hip.h", "bnn_generic.h", "bnn_common.hip.h", "bnn_stats.hi
 
 
 def cache_dir():
-    d = os.environ.get("BNN_SPEC_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "bnn_chaos_model_amd", "spec")
-    os.makedirs(d, exist_ok=True)
-    return d
+    """BNN_SPEC_CACHE, else csrc/_spec next to the library (in-tree, like the built .so: it travels with the tree), else ~/.cache."""
+    for d in (os.environ.get("BNN_SPEC_CACHE"), os.path.join(CSRC, "_spec"), os.path.join(os.path.expanduser("~"), ".cache", "bnn_chaos_model_amd", "spec")):
+        if not d:
+            continue
+        try:
+            os.makedirs(d, exist_ok=True)
+            if os.access(d, os.W_OK):
+                return d
+        except OSError:
+            pass
+    raise RuntimeError("no writable cache directory for specialised kernels (set BNN_SPEC_CACHE)")
 
 
 def _key(src):
@@ -41,24 +49,37 @@ def _key(src):
 
 
 def compile_source(src, verbose=False):
-    """hipcc --genco of one generated source -> code object bytes (cached by the hash of source + kernel headers + flags)."""
+    """hipcc --genco of one generated source -> (code object bytes, info) -- cached by the hash of source + kernel headers + flags.
+    info = {"vgpr", "agpr", "scratch", "lds", "compile_s"}: the compiler's own resource report for the kernel."""
+    import json
+    import re
+    import time
     path = os.path.join(cache_dir(), f"spec_{_key(src)}.hsaco")
-    if not os.path.exists(path):
+    if not (os.path.exists(path) and os.path.exists(path + ".json")):
         cc = _build.hipcc()
         with tempfile.TemporaryDirectory() as td:
             sp = os.path.join(td, "spec.hip")
             with open(sp, "w") as f:
                 f.write(src)
             tmp = os.path.join(td, "spec.hsaco")
-            cmd = [cc] + SPEC_FLAGS + ["-I", CSRC, "-I", INCLUDE, sp, "-o", tmp]
+            cmd = [cc] + SPEC_FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-I", CSRC, "-I", INCLUDE, sp, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
+            t0 = time.time()
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed on the specialised kernel:\n" + r.stderr[-4000:])
+            num = lambda k: int((re.search(k + r":\s*(\d+)", r.stderr) or [0, -1])[1])
+            info = {"vgpr": num("VGPRs"), "agpr": num("AGPRs"), "scratch": num(r"ScratchSize \[bytes/lane\]"), "vgpr_spill": num("VGPRs Spill"),
+                    "lds": num(r"LDS Size \[bytes/block\]"), "compile_s": round(time.time() - t0, 1)}
             _move(tmp, path)
+            with open(path + f".{os.getpid()}.json", "w") as f:
+                json.dump(info, f)
+            os.replace(path + f".{os.getpid()}.json", path + ".json")
     with open(path, "rb") as f:
-        return f.read()
+        image = f.read()
+    with open(path + ".json") as f:
+        return image, json.load(f)
 
 
 def _move(src, dst):
@@ -68,16 +89,52 @@ def _move(src, dst):
     os.replace(part, dst)   # atomic: concurrent ranks compiling the same form race to the same bytes
 
 
+VARIANTS = (N.SPEC_POOL_REGS, 0, N.SPEC_BLOCK_MAJOR)   # tried in this order: the first whose code object needs no scratch is taken
+
+
+def best_variant(arch, noisy, w8, verbose=False):
+    """Compile the tuning variants of one form until one has no scratch; -> (image, info incl. "flags")."""
+    best = None
+    for flags in VARIANTS:
+        image, info = compile_source(N.spec_source(arch, noisy, w8, flags), verbose=verbose)
+        info = dict(info, flags=flags)
+        if info["scratch"] == 0:
+            return image, info
+        if best is None or info["scratch"] < best[1]["scratch"]:
+            best = (image, info)
+    return best
+
+
+def prewarm(archs, noisy=(False, True), w8=(None,), jobs=None):
+    """Compile the specialised forms of several networks into the cache, in parallel, WITHOUT a device (hipcc cross-compiles):
+    archs = [(hidden, latent, depth_in, depth_out, n_features, fix_megno), ...].  Returns [(arch, noisy, w8, info)]."""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs_ = []
+    for (H, L, din, dout, NF, megno) in archs:
+        a = N.BnnArch(NF, H, L, int(bool(megno)), (1 << 7) if megno else 0, 0.5, 0.0, din, dout)
+        for nz in noisy:
+            for w in w8:
+                try:
+                    N.spec_source(a, nz, w, 0)
+                except N.NativeError:
+                    continue   # (a form this network cannot have, e.g. eight waves next to a large image)
+                jobs_.append(((H, L, din, dout, NF, megno), a, nz, w))
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        infos = list(ex.map(lambda j: best_variant(j[1], j[2], j[3])[1], jobs_))
+    return [(j[0], j[2], j[3], i) for j, i in zip(jobs_, infos)]
+
+
 def specialize(plan, noisy=(False, True), w8=None, verbose=False):
     """Compile (or fetch from the cache) and attach the plan's specialised forms.  noisy: which forms -- forward(noisy_val=False) and
     forward_swag_fast use the quiet one, forward(noisy_val=True) the noisy one.  w8: None = the builder's choice of eight waves at 256
-    registers vs four at 512; True / False to force (A/B).  Returns the plan."""
+    registers vs four at 512; True / False to force (A/B).  Returns the plan (plan.spec_info[noisy] = the compiler's resource report)."""
     if isinstance(noisy, bool):
         noisy = (noisy,)
     for nz in noisy:
         if plan.spec_attached(nz) and getattr(plan, "_spec_w8", {}).get(nz, "unset") == w8:
             continue
-        image = compile_source(plan.spec_source(nz, w8), verbose=verbose)
+        image, info = best_variant(plan.arch, nz, w8, verbose=verbose)
         plan.attach_spec(image, nz, w8)
         plan.__dict__.setdefault("_spec_w8", {})[nz] = w8
+        plan.__dict__.setdefault("spec_info", {})[bool(nz)] = info
     return plan
