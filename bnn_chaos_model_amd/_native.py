@@ -85,7 +85,7 @@ def lib():
     L.bnn_forward_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64,
                                   _vp, _vp, _vp, _vp]
     L.bnn_spec_source.argtypes = [C.POINTER(BnnArch), C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
-    L.bnn_plan_attach_spec.argtypes = [_vp, C.c_int32, C.c_int32, _vp, C.c_size_t]
+    L.bnn_plan_attach_spec.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t]
     L.bnn_plan_spec_attached.argtypes = [_vp, C.c_int32]
     L.bnn_feature_nn_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp]
     L.bnn_forward_lowp_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, C.c_int32,
@@ -182,9 +182,9 @@ class Plan:
         """HIP source of this network's specialised form of the generic engine (bnn_spec_source; needs no device)."""
         return spec_source(self.arch, noisy, w8, flags)
 
-    def attach_spec(self, image, noisy=False, w8=None):
+    def attach_spec(self, image, noisy=False, w8=None, flags=0):
         """Load a compiled specialised form (code object bytes) into the plan; the current device must be the plan's."""
-        check(lib().bnn_plan_attach_spec(self.handle, int(bool(noisy)), -1 if w8 is None else int(bool(w8)), image, len(image)))
+        check(lib().bnn_plan_attach_spec(self.handle, int(bool(noisy)), -1 if w8 is None else int(bool(w8)), int(flags), image, len(image)))
 
     def spec_attached(self, noisy=False):
         return bool(check(lib().bnn_plan_spec_attached(self.handle, int(bool(noisy)))))

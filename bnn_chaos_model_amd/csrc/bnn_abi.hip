@@ -641,25 +641,32 @@ int bnn_plan_destroy(bnn_plan* pl) {
     return 0;
 }
 
+// the descriptor of one specialised form: the quiet kq-major forms drop the plan's masked input columns from layer 0
+static int spec_arch(const bnn_arch* a, int32_t w8, int32_t noisy, int32_t flags, GenArch* g) {
+    if (flags & ~(BNN_SPEC_POOL_REGS | BNN_SPEC_BLOCK_MAJOR)) return fail(BNN_ERR_INVALID, "unknown specialisation flag");
+    if (noisy != 0 && noisy != 1) return fail(BNN_ERR_INVALID, "noisy must be 0 or 1");
+    const char* why = "";
+    const uint64_t drop = (noisy || (flags & BNN_SPEC_BLOCK_MAJOR)) ? 0 : a->zero_mask;
+    if (gen_build_spec(a->n_features, a->hidden, a->latent, a->depth_in, a->depth_out, a->fix_megno != 0, w8, drop, g, &why))
+        return fail(BNN_ERR_UNSUPPORTED, why);
+    return 0;
+}
+
 int bnn_spec_source(const bnn_arch* arch, int32_t w8, int32_t noisy, int32_t flags, char* buf, size_t cap) {
     int rc = check_arch(arch);
     if (rc) return rc;
     GenArch g;
-    const char* why = "";
-    if (gen_build_spec(arch->n_features, arch->hidden, arch->latent, arch->depth_in, arch->depth_out, arch->fix_megno != 0, w8, &g, &why))
-        return fail(BNN_ERR_UNSUPPORTED, why);
-    if (flags & ~(BNN_SPEC_POOL_REGS | BNN_SPEC_BLOCK_MAJOR)) return fail(BNN_ERR_INVALID, "unknown specialisation flag");
-    return gen_spec_source(g, noisy, (flags & BNN_SPEC_POOL_REGS) ? 1 : 0, (flags & BNN_SPEC_BLOCK_MAJOR) ? 1 : 0, buf, cap);
+    rc = spec_arch(arch, w8, noisy, flags, &g);
+    if (rc) return rc;
+    return gen_spec_source(g, noisy, (flags & BNN_SPEC_POOL_REGS) ? 1 : 0, (flags & BNN_SPEC_BLOCK_MAJOR) ? 1 : 0,
+                           g.in_live ? arch->zero_mask : 0, buf, cap);
 }
 
-int bnn_plan_attach_spec(bnn_plan* pl, int32_t noisy, int32_t w8, const void* image, size_t bytes) {
+int bnn_plan_attach_spec(bnn_plan* pl, int32_t noisy, int32_t w8, int32_t flags, const void* image, size_t bytes) {
     if (!pl || !image || !bytes) return fail(BNN_ERR_INVALID, "plan/image is NULL");
-    if (noisy != 0 && noisy != 1) return fail(BNN_ERR_INVALID, "noisy must be 0 or 1");
     GenArch g;
-    const char* why = "";
-    const bnn_arch* a = &pl->arch;
-    if (gen_build_spec(a->n_features, a->hidden, a->latent, a->depth_in, a->depth_out, a->fix_megno != 0, w8, &g, &why))
-        return fail(BNN_ERR_UNSUPPORTED, why);
+    int rc = spec_arch(&pl->arch, w8, noisy, flags, &g);
+    if (rc) return rc;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != pl->device) return fail(BNN_ERR_INVALID, "the plan lives on another device than the current one");

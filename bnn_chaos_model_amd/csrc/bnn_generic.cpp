@@ -16,7 +16,8 @@ constexpr int HQ_BUCKETS[] = {12, 16, 24, 32};
 int mlp_nlin(int layers) { return layers == 0 ? 1 : layers + 2; }   // mlp() (spock_reg_model.py:301-321)
 }  // namespace
 
-static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool megno, bool spec, int w8, GenArch* out, const char** why) {
+static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool megno, bool spec, int w8, uint64_t drop_mask, GenArch* out,
+                          const char** why) {
     static const char* msg_f = "n_features must be 41 or 82 (time_series_features x (1 + include_derivatives))";
     static const char* msg_w = "hidden and latent must be in [1, 128] and the summary width 2 latent (+ 2) at most 128";
     static const char* msg_d = "depth `in` / `out` must be >= 0 with at most 16 Linear modules in the two MLPs together";
@@ -40,13 +41,19 @@ static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool
         const int ll = feat ? l : l - g.n_feat, nn = feat ? g.n_feat : g.n_reg;
         GenLayer& y = g.layer[l];
         y.K = ll == 0 ? (feat ? F : SM) : H;
+        if (l == 0 && spec && drop_mask) {   // layer 0 over the unmasked columns only
+            int nlive = 0;
+            for (int c = 0; c < F; ++c) nlive += !(c < 64 && ((drop_mask >> c) & 1ull));
+            if (nlive < 1) { *why = "every input column is masked"; return -2; }
+            if (nlive < F) { g.in_live = nlive; y.K = nlive; }
+        }
         y.N = ll == nn - 1 ? (feat ? L : 2) : H;
         y.relu = ll < nn - 1 ? 1 : 0;
         y.nkq = (y.K + 3) / 4;
         const int groups = (y.N + 3) / 4;
         y.nblk = (groups + 3) / 4;
         y.ng_last = groups - 4 * (y.nblk - 1);
-        y.off_w = off; off += y.N * y.K;
+        y.off_w = off; off += y.N * (l == 0 ? F : y.K);
         y.off_b = off; off += y.N;
         y.bias0 = bias0; bias0 += 16 * y.nblk;
         y.wreg0 = -1;
@@ -92,14 +99,14 @@ static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool
 }
 
 int gen_build(int F, int H, int L, int depth_in, int depth_out, bool megno, GenArch* out, const char** why) {
-    return gen_build_impl(F, H, L, depth_in, depth_out, megno, false, -1, out, why);
+    return gen_build_impl(F, H, L, depth_in, depth_out, megno, false, -1, 0, out, why);
 }
 
-int gen_build_spec(int F, int H, int L, int depth_in, int depth_out, bool megno, int w8, GenArch* out, const char** why) {
-    return gen_build_impl(F, H, L, depth_in, depth_out, megno, true, w8, out, why);
+int gen_build_spec(int F, int H, int L, int depth_in, int depth_out, bool megno, int w8, uint64_t drop_mask, GenArch* out, const char** why) {
+    return gen_build_impl(F, H, L, depth_in, depth_out, megno, true, w8, drop_mask, out, why);
 }
 
-int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, char* buf, size_t cap) {
+int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, char* buf, size_t cap) {
     std::string s;
     char t[256];
     auto add = [&](const char* fmt, auto... a) { snprintf(t, sizeof t, fmt, a...); s += t; };
@@ -109,9 +116,22 @@ int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major,
     add("    static constexpr int n_feat = %d, n_reg = %d;\n", g.n_feat, g.n_reg);
     add("    static constexpr int pool_lq = %d, lat_nfull = %d;   // Welford state of the pool in registers (0: in LDS)\n", pool_regs ? g.lq : 0,
         4 * (g.layer[g.n_feat - 1].nblk - 1));
+    if (g.in_live) {   // layer 0 over the unmasked columns: logical input k -> column live(k) (padding slots repeat column live(0): zero weights)
+        add("    static constexpr int in_q = %d;   // input quads of layer 0 after dropping the masked columns\n", g.layer[0].nkq);
+        s += "    static constexpr int live(int k) {\n        constexpr int t[] = {";
+        int first = -1, n = 0;
+        for (int c = 0; c < g.F; ++c)
+            if (!(c < 64 && ((drop_mask >> c) & 1ull))) {
+                if (first < 0) first = c;
+                add("%d, ", c);
+                ++n;
+            }
+        for (; n < 4 * g.layer[0].nkq; ++n) add("%d, ", first);
+        s += "};\n        return t[k];\n    }\n";
+    }
     s += "    static DEVINL GenArch get(const GenParams&) {\n        constexpr GenArch value = {\n";
-    add("            %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d,\n            {\n", g.F, g.H, g.L, g.SM, g.d, g.megno, g.n_feat,
-        g.n_reg, g.nwreg, g.nbias, g.fq, g.hq, g.lq, g.smq, g.nin_blocks, g.reg_in_lds, g.nwaves, g.lds_bytes, g.off_inlv, g.off_sumlv);
+    add("            %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d,\n            {\n", g.F, g.H, g.L, g.SM, g.d, g.megno, g.n_feat,
+        g.n_reg, g.nwreg, g.nbias, g.fq, g.hq, g.lq, g.smq, g.nin_blocks, g.reg_in_lds, g.nwaves, g.lds_bytes, g.off_inlv, g.off_sumlv, g.in_live);
     for (int l = 0; l < g.n_feat + g.n_reg; ++l) {
         const GenLayer& y = g.layer[l];
         add("                {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d},\n", y.K, y.N, y.nkq, y.nblk, y.ng_last, y.off_w, y.off_b, y.wreg0, y.bias0, y.relu);

@@ -52,6 +52,8 @@ struct GenArch {
     int32_t nwaves;               // waves per workgroup (8 for the narrowest bucket, else 4; 2 or 1 when the LDS budget forces it)
     int32_t lds_bytes;            // dynamic LDS of the launch
     int32_t off_inlv, off_sumlv;  // input_noise_logvar [F], summary_noise_logvar [SM]
+    int32_t in_live;              // specialised quiet forms: layer 0 multiplies only the in_live unmasked columns (layer[0].K = in_live, its
+                                  // weight rows are still F apart); 0 = every column (masked ones as zero weights)
     GenLayer layer[GEN_MAX_LAYERS];
 };
 
@@ -62,11 +64,14 @@ int gen_build(int n_features, int hidden, int latent, int depth_in, int depth_ou
 // Host: the descriptor of the network's SPECIALISED form (compiled at run time for this one network, bnn_spec_source): the activation
 // arrays are sized exactly (hq = 4 x the widest layer's blocks) instead of by bucket; w8 = 1 asks for the eight-wave / 256-register
 // form (refused when eight waves' LDS does not fit), 0 for four waves (or fewer) at 512 registers, -1 lets the builder choose.
-int gen_build_spec(int n_features, int hidden, int latent, int depth_in, int depth_out, bool megno, int w8, GenArch* out, const char** why);
+// drop_mask: input columns (bits below 64) layer 0 leaves out altogether -- the plan's zero mask for the quiet form (the same sums: a
+// masked column only ever added +0), 0 for the noisy form (masked columns carry noise there) and for the block-major variant.
+int gen_build_spec(int n_features, int hidden, int latent, int depth_in, int depth_out, bool megno, int w8, uint64_t drop_mask, GenArch* out,
+                   const char** why);
 
 // Host: the HIP source of that form -- `static constexpr GenArch` + one extern "C" kernel `bnn_spec_forward` around generic_body.
 // Returns the length of the text (without the terminator); writes at most cap bytes.
-int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, char* buf, size_t cap);
+int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, char* buf, size_t cap);
 
 // Per-wave LDS floats: pool state (mean, M2 per latent group, lane-major), Philox scratch, summaries, MEGNO partitions, and -- when
 // regress_nn's registers are not in the image -- a staging area for one block of them.

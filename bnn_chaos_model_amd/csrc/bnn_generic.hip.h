@@ -285,6 +285,12 @@ struct pool_regs_of { static constexpr int lq = 0; };
 template <class AS>
 struct pool_regs_of<AS, std::void_t<decltype(AS::pool_lq)>> { static constexpr int lq = AS::pool_lq; };
 
+// in_compact_of<AS>::q: input quads of layer 0 when the policy drops the masked columns (declares in_q and live(k)); else 0
+template <class AS, class = void>
+struct in_compact_of { static constexpr int q = 0; };
+template <class AS>
+struct in_compact_of<AS, std::void_t<decltype(AS::in_q)>> { static constexpr int q = AS::in_q; };
+
 struct ArchRuntime {
     static constexpr bool kq_major = false;   // weight image block-major (register (nb, kq) at nb * nkq + kq), gen_layer
     static DEVINL const GenArch& get(const GenParams& P) { return *P.g; }
@@ -346,9 +352,13 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
             const int neuron = 16 * nb + 4 * q + i, k = 4 * kq + kk;
             // zero_megno / zero_mmr / zero_nan / zero_eplusminus (:452-500) as zero weights on the masked input columns; the noisy
             // forward keeps them (masked columns carry pure noise)
-            const bool masked = li == 0 && !noisy && k < 64 && ((p.zero_mask >> k) & 1ull);
+            int kc = k, stride = ly.K;   // column of the flat weight row behind logical input k
+            if constexpr (in_compact_of<AS>::q > 0) {
+                if (li == 0) { stride = G.F; kc = AS::live(k < ly.K ? k : 0); }
+            }
+            const bool masked = li == 0 && !noisy && kc < 64 && ((p.zero_mask >> kc) & 1ull);
             const bool live = neuron < ly.N && k < ly.K && !masked;
-            const float v = We[live ? ly.off_w + neuron * ly.K + k : 0];
+            const float v = We[live ? ly.off_w + neuron * stride + kc : 0];
             wimg[R * 64 + lane] = live ? v : 0.0f;
         }
         if (wave == 0) wimg[G.nwreg * 64 + lane] = 0.0f;
@@ -515,7 +525,17 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
                 });
             }
             auto layer_first = [&](const f32x4 (&in_)[FQ], f32x4 (&out_)[HQ]) __attribute__((always_inline)) {
-                if constexpr (AS::kq_major) gen_layer_kq<FQ, HQ, true>(in_, out_, G.layer[0], G.layer[0].nkq, wimg, bimg, lane, w0, true, &G.layer[G.n_feat > 1 ? 1 : 0]);
+                if constexpr (in_compact_of<AS>::q > 0) {   // the unmasked columns only: a renaming of the row's registers
+                    constexpr int CQ = in_compact_of<AS>::q;
+                    f32x4 xc[CQ];
+                    static_for<CQ>([&](auto Q_) {
+                        static_for<4>([&](auto KK) {
+                            constexpr int q_ = Q_, kk = KK, c = AS::live(4 * q_ + kk);
+                            xc[q_][kk] = in_[c >> 2][c & 3];
+                        });
+                    });
+                    gen_layer_kq<CQ, HQ, true>(xc, out_, G.layer[0], G.layer[0].nkq, wimg, bimg, lane, w0, true, &G.layer[G.n_feat > 1 ? 1 : 0]);
+                } else if constexpr (AS::kq_major) gen_layer_kq<FQ, HQ, true>(in_, out_, G.layer[0], G.layer[0].nkq, wimg, bimg, lane, w0, true, &G.layer[G.n_feat > 1 ? 1 : 0]);
                 else gen_layer<FQ, HQ, true>(in_, out_, G.layer[0], G.layer[0].nkq, wimg, bimg, lane);
             };
             auto layer_next = [&](const f32x4 (&in_)[HQ], f32x4 (&out_)[HQ], int l_) __attribute__((always_inline)) {

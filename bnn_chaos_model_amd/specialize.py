@@ -92,32 +92,46 @@ def _move(src, dst):
 VARIANTS = (N.SPEC_POOL_REGS, 0, N.SPEC_BLOCK_MAJOR)   # tried in this order: the first whose code object needs no scratch is taken
 
 
-def best_variant(arch, noisy, w8, verbose=False):
-    """Compile the tuning variants of one form until one has no scratch; -> (image, info incl. "flags")."""
+def best_variant(arch, noisy, w8=None, verbose=False):
+    """Compile the tuning variants of one form until one has no scratch; -> (image, info incl. "flags" and "w8").
+    w8 = None searches the eight-wave forms first (two waves per SIMD won every same-box A/B where they fit without spilling:
+    profiles/r04_spec_engine.jsonl), then the four-wave ones."""
     best = None
-    for flags in VARIANTS:
-        image, info = compile_source(N.spec_source(arch, noisy, w8, flags), verbose=verbose)
-        info = dict(info, flags=flags)
-        if info["scratch"] == 0:
-            return image, info
-        if best is None or info["scratch"] < best[1]["scratch"]:
-            best = (image, info)
+    for w in ((True, False) if w8 is None else (bool(w8),)):
+        for flags in VARIANTS:
+            try:
+                src = N.spec_source(arch, noisy, w, flags)
+            except N.NativeError:
+                if w8 is not None:
+                    raise
+                break          # eight waves' LDS does not fit next to this network's image
+            image, info = compile_source(src, verbose=verbose)
+            info = dict(info, flags=flags, w8=w)
+            if info["scratch"] == 0:
+                return image, info
+            if best is None or info["scratch"] < best[1]["scratch"]:
+                best = (image, info)
     return best
 
 
 def prewarm(archs, noisy=(False, True), w8=(None,), jobs=None):
     """Compile the specialised forms of several networks into the cache, in parallel, WITHOUT a device (hipcc cross-compiles):
-    archs = [(hidden, latent, depth_in, depth_out, n_features, fix_megno), ...].  Returns [(arch, noisy, w8, info)]."""
+    archs = [(hidden, latent, depth_in, depth_out, n_features, fix_megno[, zero_mask]), ...] (the quiet forms are compiled for the
+    column mask too; default: the pretrained ensemble's).  Returns [(arch, noisy, w8, info)]."""
     from concurrent.futures import ThreadPoolExecutor
     jobs_ = []
-    for (H, L, din, dout, NF, megno) in archs:
-        a = N.BnnArch(NF, H, L, int(bool(megno)), (1 << 7) if megno else 0, 0.5, 0.0, din, dout)
+    from .ops import V50_ZERO_MASK
+    for t in archs:
+        H, L, din, dout, NF, megno = t[:6]
+        mask = (t[6] if len(t) > 6 else V50_ZERO_MASK) | ((1 << 7) if megno else 0)
+        a = N.BnnArch(NF, H, L, int(bool(megno)), mask, 0.5, 0.0, din, dout)
         for nz in noisy:
             for w in w8:
-                try:
-                    N.spec_source(a, nz, w, 0)
-                except N.NativeError:
-                    continue   # (a form this network cannot have, e.g. eight waves next to a large image)
+                if w is not None:
+                    try:
+                        N.spec_source(a, nz, w, 0)
+                    except N.NativeError:
+                        continue   # (a form this network cannot have, e.g. eight waves next to a large image)
                 jobs_.append(((H, L, din, dout, NF, megno), a, nz, w))
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         infos = list(ex.map(lambda j: best_variant(j[1], j[2], j[3])[1], jobs_))
@@ -134,7 +148,7 @@ def specialize(plan, noisy=(False, True), w8=None, verbose=False):
         if plan.spec_attached(nz) and getattr(plan, "_spec_w8", {}).get(nz, "unset") == w8:
             continue
         image, info = best_variant(plan.arch, nz, w8, verbose=verbose)
-        plan.attach_spec(image, nz, w8)
+        plan.attach_spec(image, nz, info["w8"], info["flags"])
         plan.__dict__.setdefault("_spec_w8", {})[nz] = w8
         plan.__dict__.setdefault("spec_info", {})[bool(nz)] = info
     return plan

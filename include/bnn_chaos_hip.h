@@ -83,14 +83,15 @@ int bnn_plan_destroy(bnn_plan* plan);
  * compile it with hipcc --genco --offload-arch=gfx950 -I<csrc> and the library's own flags: bnn_chaos_model_amd/specialize.py does);
  * bnn_plan_attach_spec loads the resulting code object into the plan (current device = the plan's); from then on the generic route
  * of every entry point launches it for that `noisy` form.  w8: 1 = eight waves at 256 registers, 0 = at most four at 512,
- * -1 = the builder's choice -- the same value must be given to both calls.  Results are bit-identical to the ahead-of-time form's
+ * -1 = the builder's choice -- the same w8 and flags must be given to both calls.  The quiet forms are compiled for the plan's column
+ * mask as well (layer 0 multiplies the unmasked columns only).  Results are bit-identical to the ahead-of-time form's
  * (same accumulation order); what changes is the schedule. */
 #define BNN_SPEC_POOL_REGS 1 /* flags: the pool's Welford state in registers across the tiles (else in LDS); a tuning choice -- the caller
                                 compiles, looks at the code object's scratch size and falls back (specialize.py does) */
 #define BNN_SPEC_BLOCK_MAJOR 2 /* flags: the ahead-of-time form's block-major layer routine (fewest registers: the widest networks) instead of
                                   the input-quad-major one with its one-step-ahead weight reads */
 int bnn_spec_source(const bnn_arch* arch, int32_t w8, int32_t noisy, int32_t flags, char* buf, size_t cap);
-int bnn_plan_attach_spec(bnn_plan* plan, int32_t noisy, int32_t w8, const void* image, size_t bytes);
+int bnn_plan_attach_spec(bnn_plan* plan, int32_t noisy, int32_t w8, int32_t flags, const void* image, size_t bytes);
 int bnn_plan_spec_attached(const bnn_plan* plan, int32_t noisy); /* 1 / 0 */
 /* Accumulation order used by the kernels for Linear layer `layer` (0 .. number of Linear modules - 1, feature_nn's first): `order`
  * receives up to `cap` entries (input indices; the accumulator starts at the bias).  The generic engine's order is the natural one
