@@ -534,13 +534,15 @@ def main():
         kin = 41 if noisy else 31
         generic = bool(net) or args.engine != "auto"
         alg_flop, exe_flop, alg_bytes = ALG_FLOP_PER_EVAL, EXEC_FLOP_PER_EVAL[kin], ALG_BYTES_PER_EVAL
+        pad4 = lambda n: 4 * ((n + 3) // 4)
         if net:   # another network: the same two counts from its shapes (the v50 mask leaves 31 of the first 41 columns live)
             a5 = (NF, net["hidden"], net["latent"], net["depth_in"], net["depth_out"])
             alg_flop = net_flop_per_eval(*a5)
-            exe_flop = net_flop_per_eval(*a5, live_cols=NF if noisy else NF - 10)
             alg_bytes = 100 * NF * 4 + 8
-        elif generic and not noisy:
-            exe_flop = net_flop_per_eval(41, 40, 20, 1, 1, live_cols=33)   # the generic engine skips whole masked quads only: 33 columns multiplied
+        else:
+            a5 = (41, 40, 20, 1, 1)
+        if generic:   # columns layer 0 multiplies: whole input quads; the specialised quiet form drops the masked columns first
+            exe_flop = net_flop_per_eval(*a5, live_cols=pad4(a5[0] - 10) if (args.engine == "spec" and not noisy) else pad4(a5[0]))
         ach_tflops = evals_per_launch * alg_flop / (kern_ms * 1e-3) / 1e12
         exe_tflops = evals_per_launch * exe_flop / (kern_ms * 1e-3) / 1e12
         ach_gbs = evals_per_launch * alg_bytes / (kern_ms * 1e-3) / 1e9

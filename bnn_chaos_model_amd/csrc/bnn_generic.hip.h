@@ -158,6 +158,12 @@ DEVINL void gen_layer(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLayer 
 #ifndef BNN_GEN_SCHED_MASK
 #define BNN_GEN_SCHED_MASK 0
 #endif
+// BNN_GEN_ABLATE (measurement builds of the specialised forms only, scripts/spec_ablate_r04.sh; results are WRONG): 1 = accumulators start
+// at zero instead of the bias image, 2 = no pool update, 4 = the first tile's x rows are reused, 8 = no ReLU, 16 = no weight reads past
+// the first step of a layer
+#ifndef BNN_GEN_ABLATE
+#define BNN_GEN_ABLATE 0
+#endif
 template <int NQI, int NQO, bool TRIM, int NQN = NQO>
 DEVINL void gen_layer_kq(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLayer ly, int in_nfull, const float* wimg, const float* bimg, int lane,
                          float (&w0)[NQO / 4], bool have_w0, const GenLayer* next) {
@@ -188,11 +194,11 @@ DEVINL void gen_layer_kq(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLay
         constexpr int nb = NBI;
         if (nb >= nblk - 1) return false;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) out[4 * nb + q] = bq[4 * nb + q];
+        for (int q = 0; q < 4; ++q) out[4 * nb + q] = (BNN_GEN_ABLATE & 1) ? (f32x4){0, 0, 0, 0} : bq[4 * nb + q];
         return true;
     });
 #pragma unroll
-    for (int q = 0; q < 4; ++q) out[NQO - 4 + q] = bq[4 * (nblk - 1) + q];
+    for (int q = 0; q < 4; ++q) out[NQO - 4 + q] = (BNN_GEN_ABLATE & 1) ? (f32x4){0, 0, 0, 0} : bq[4 * (nblk - 1) + q];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) w[0][nb] = w0[nb];
     auto step = [&](const float (&wr)[NB], const f32x4 xin) {
@@ -217,7 +223,10 @@ DEVINL void gen_layer_kq(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLay
     static_while<NQI>([&](auto S) {
         constexpr int s_ = S;
         if (s_ >= in_nfull) return false;
-        if (s_ + 1 < in_nfull) load(w[(s_ + 1) & 1], wp + (size_t)(s_ + 1) * nblk * 64, nblk);
+        if ((BNN_GEN_ABLATE & 16) && s_ + 1 < in_nfull) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) w[(s_ + 1) & 1][nb] = w[s_ & 1][nb];
+        } else if (s_ + 1 < in_nfull) load(w[(s_ + 1) & 1], wp + (size_t)(s_ + 1) * nblk * 64, nblk);
         else if (pre_next && ntail == 0) load(w0, wimg + (size_t)next->wreg0 * 64 + lane, next->nblk);
         __builtin_amdgcn_sched_barrier(BNN_GEN_SCHED_MASK);
         step(w[s_ & 1], in[s_]);
@@ -233,6 +242,7 @@ DEVINL void gen_layer_kq(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLay
         step(wt[j], in[NQI - 4 + j]);
         return true;
     });
+    if (BNN_GEN_ABLATE & 8) return;
     static_while<NB - 1>([&](auto NBI) {
         constexpr int nb = NBI;
         if (nb >= nblk - 1) return false;
@@ -545,7 +555,7 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
             };
             layer_first(xr, a);
             // x of this tile is dead: fetch the next tile's rows into the same registers
-            if constexpr (XPREF) {
+            if constexpr (XPREF && !(BNN_GEN_ABLATE & 4)) {
                 const int tn = 4 * (it + 1) + ph0;
                 gen_load_row<FQ>(sysp + (int64_t)(tn < T ? tn : T - 1) * F, xr);
                 asm volatile("" ::: "memory");
@@ -558,7 +568,8 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
             }
             if (l < G.n_feat) {
                 layer_next(a, b, l);
-                if (tv) pool(b, rcn);   // lanes past T sit the tile out
+                if (tv && !(BNN_GEN_ABLATE & 2)) pool(b, rcn);   // lanes past T sit the tile out
+                if (BNN_GEN_ABLATE & 2) asm volatile("" :: "v"(b[0]), "v"(b[HQ - 4]));
             } else if (tv) {
                 pool(a, rcn);
             }

@@ -39,9 +39,14 @@ def cache_dir():
     raise RuntimeError("no writable cache directory for specialised kernels (set BNN_SPEC_CACHE)")
 
 
+def _extra_flags():
+    """BNN_SPEC_DEFINES="BNN_GEN_ABLATE=2 ...": measurement builds (part of the cache key; never set in production)."""
+    return ["-D" + d for d in os.environ.get("BNN_SPEC_DEFINES", "").split()]
+
+
 def _key(src):
     h = hashlib.sha256(src.encode())
-    h.update(" ".join(SPEC_FLAGS).encode())
+    h.update(" ".join(SPEC_FLAGS + _extra_flags()).encode())
     for name in _DEPS:   # the kernel source the generated file includes
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -62,7 +67,7 @@ def compile_source(src, verbose=False):
             with open(sp, "w") as f:
                 f.write(src)
             tmp = os.path.join(td, "spec.hsaco")
-            cmd = [cc] + SPEC_FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-I", CSRC, "-I", INCLUDE, sp, "-o", tmp]
+            cmd = [cc] + SPEC_FLAGS + _extra_flags() + ["-Rpass-analysis=kernel-resource-usage", "-I", CSRC, "-I", INCLUDE, sp, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             t0 = time.time()
@@ -144,11 +149,14 @@ def specialize(plan, noisy=(False, True), w8=None, verbose=False):
     registers vs four at 512; True / False to force (A/B).  Returns the plan (plan.spec_info[noisy] = the compiler's resource report)."""
     if isinstance(noisy, bool):
         noisy = (noisy,)
-    for nz in noisy:
-        if plan.spec_attached(nz) and getattr(plan, "_spec_w8", {}).get(nz, "unset") == w8:
-            continue
-        image, info = best_variant(plan.arch, nz, w8, verbose=verbose)
+    todo = [bool(nz) for nz in noisy if not (plan.spec_attached(nz) and getattr(plan, "_spec_w8", {}).get(bool(nz), "unset") == w8)]
+    if not todo:
+        return plan
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(todo)) as ex:   # the forms compile side by side (hipcc subprocesses)
+        built = list(ex.map(lambda nz: best_variant(plan.arch, nz, w8, verbose=verbose), todo))
+    for nz, (image, info) in zip(todo, built):
         plan.attach_spec(image, nz, info["w8"], info["flags"])
         plan.__dict__.setdefault("_spec_w8", {})[nz] = w8
-        plan.__dict__.setdefault("spec_info", {})[bool(nz)] = info
+        plan.__dict__.setdefault("spec_info", {})[nz] = info
     return plan

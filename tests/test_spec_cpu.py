@@ -1,0 +1,65 @@
+"""Run-time specialisation of the generic forward engine, the parts that need no GPU (specialize.py, bnn_spec_source): the generated
+source, the compile + cache round trip (hipcc cross-compiles gfx950 here), the variant search's resource report."""
+import re
+
+import pytest
+
+hipcc = pytest.importorskip("bnn_chaos_model_amd.csrc.build").hipcc
+
+
+@pytest.fixture(scope="module")
+def N():
+    from bnn_chaos_model_amd import _native
+    return _native
+
+
+def arch(N, H=30, L=12, din=0, dout=0, NF=41, mask=None):
+    from bnn_chaos_model_amd.ops import V50_ZERO_MASK
+    return N.BnnArch(NF, H, L, 0, V50_ZERO_MASK if mask is None else mask, 0.5, 0.0, din, dout)
+
+
+def test_source_is_deterministic_and_carries_the_shapes(N):
+    a = arch(N, 40, 20, 1, 1)
+    src = N.spec_source(a, False, True, N.SPEC_POOL_REGS)
+    assert src == N.spec_source(a, False, True, N.SPEC_POOL_REGS)
+    assert 'extern "C" __global__ __launch_bounds__(512, 1) void bnn_spec_forward' in src
+    assert "generic_body<11, 12, true, bnn::SpecArch, 0>" in src and "pool_lq = 5" in src
+    # the quiet form multiplies the 31 unmasked columns only (8 input quads; padding repeats a live column), in ascending order
+    assert "in_q = 8" in src
+    live = [int(v) for v in re.search(r"constexpr int t\[\] = \{([^}]*)\}", src).group(1).split(",") if v.strip()]
+    assert live[:31] == [c for c in range(41) if c not in (1, 2, 3, 4, 5, 6, 7, 38, 39, 40)] and live[31] == live[0] and len(live) == 32
+    assert "{31, 40, 8, 3, 2," in src                      # layer 0: K = 31 live inputs, 8 quads, 3 blocks, 2 groups in the last
+    noisy = N.spec_source(a, True, True, 0)                # the noisy form keeps every column (masked ones carry noise) and the LDS pool
+    assert "in_q" not in noisy and "pool_lq = 0" in noisy and "SpecArch, 1>" in noisy and "{41, 40, 11, 3, 2," in noisy
+    assert "in_q" not in N.spec_source(arch(N, 40, 20, 1, 1, mask=0), False, True, 0)          # nothing masked: nothing to drop
+    assert "kq_major = false" in N.spec_source(a, False, False, N.SPEC_BLOCK_MAJOR)
+    four = N.spec_source(a, False, False, 0)
+    assert "__launch_bounds__(256, 1)" in four and "12, false," in four
+
+
+def test_limits_are_errors(N):
+    with pytest.raises(N.NativeError):
+        N.spec_source(arch(N), False, True, 64)                                    # unknown flag
+    with pytest.raises(N.NativeError):
+        N.spec_source(arch(N, 128, 32, 1, 1), False, True, 0)                      # eight waves do not fit next to that image
+    with pytest.raises(N.NativeError):
+        N.spec_source(arch(N, 200, 20, 1, 1), False, None, 0)                      # the engine's own width limit
+    assert "generic_body<21, " in N.spec_source(arch(N, 40, 20, 1, 1, NF=82), False, None, 0)
+
+
+def test_compile_cache_and_resource_report(N, tmp_path, monkeypatch):
+    from bnn_chaos_model_amd import specialize as S
+    hipcc()   # RuntimeError when ROCm's compiler is missing: nothing to test then
+    monkeypatch.setenv("BNN_SPEC_CACHE", str(tmp_path))
+    assert S.cache_dir() == str(tmp_path)
+    a = arch(N)
+    image, info = S.best_variant(a, False)
+    assert b"bnn_spec_forward" in image and info["scratch"] == 0 and info["w8"] is True and info["flags"] == N.SPEC_POOL_REGS
+    assert 0 < info["vgpr"] <= 256 and 0 < info["lds"] <= 160 * 1024
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert len(files) == 2 and files[0].endswith(".hsaco") and files[1].endswith(".hsaco.json")
+    image2, info2 = S.best_variant(a, False)               # second time: from the cache, same bytes, same report
+    assert image2 == image and info2 == info and sorted(p.name for p in tmp_path.iterdir()) == files
+    monkeypatch.setenv("BNN_SPEC_DEFINES", "BNN_GEN_ABLATE=2")   # measurement builds key differently
+    S.best_variant(a, False)
+    assert len(list(tmp_path.iterdir())) == 4
