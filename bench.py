@@ -277,6 +277,8 @@ def parse(argv=None):
     ap.add_argument("--engine", default="auto", choices=("auto", "generic", "spec"),
                     help="generic: force the generic forward engine (LDS-streamed weights); spec: its run-time-compiled form for this network (specialize.py)")
     ap.add_argument("--spec-w8", default="auto", choices=("auto", "0", "1"), help="--engine spec: eight waves at 256 registers (1), four at 512 (0), builder's choice")
+    ap.add_argument("--timesteps", type=int, default=100, help="series length T (100 = every BASELINE config; others: the ragged lengths of the reference's "
+                    "`augment`, which the generic engine / its specialised forms take)")
     ap.add_argument("--net", default="", help="hidden,latent,in,out[,features]: another hparams-built network on a synthetic ensemble (generic engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-systems", type=int, default=8192, help="systems of the batch the CPU baselines are timed on")
@@ -397,6 +399,11 @@ def main():
         ops.specialize(plan, noisy=(noisy,), w8={"auto": None, "0": False, "1": True}[args.spec_w8])
         spec_compile_s = time.time() - t0
     x = synthetic_x(B, dev, seed=123 + rank, F=NF)    # this rank's shard
+    T_ = args.timesteps
+    if T_ != 100:
+        if not 2 <= T_ <= 100:
+            raise SystemExit("--timesteps must be in [2, 100]")
+        x = x[:, :T_].contiguous()
     wa, w2, pd = synthetic_net_ensemble(S, plan.d, 30, dev) if net else synthetic_ensemble(S, dev)   # replicated ensemble (29 MB)
     if nch == 1:
         seed_idx = (torch.arange(J, dtype=torch.int32) % S).to(dev)  # dense grid: every seed x every sample
@@ -532,17 +539,22 @@ def main():
     if rank == 0:
         evals_per_launch = B * R
         kin = 41 if noisy else 31
-        generic = bool(net) or args.engine != "auto"
+        T_ = args.timesteps
+        ragged = T_ % 4 != 0 or T_ < 8     # the pretrained network's own kernels take whole tiles of four timesteps: other lengths go to the generic route
+        generic = bool(net) or args.engine != "auto" or ragged
+        spec_form = args.engine == "spec" or (args.engine == "auto" and ragged and not net)   # (the embedded forms of the pretrained network)
         alg_flop, exe_flop, alg_bytes = ALG_FLOP_PER_EVAL, EXEC_FLOP_PER_EVAL[kin], ALG_BYTES_PER_EVAL
         pad4 = lambda n: 4 * ((n + 3) // 4)
         if net:   # another network: the same two counts from its shapes (the v50 mask leaves 31 of the first 41 columns live)
             a5 = (NF, net["hidden"], net["latent"], net["depth_in"], net["depth_out"])
-            alg_flop = net_flop_per_eval(*a5)
-            alg_bytes = 100 * NF * 4 + 8
+            alg_flop = net_flop_per_eval(*a5, T=T_)
+            alg_bytes = T_ * NF * 4 + 8
         else:
             a5 = (41, 40, 20, 1, 1)
-        if generic:   # columns layer 0 multiplies: whole input quads; the specialised quiet form drops the masked columns first
-            exe_flop = net_flop_per_eval(*a5, live_cols=pad4(a5[0] - 10) if (args.engine == "spec" and not noisy) else pad4(a5[0]))
+            if T_ != 100:
+                alg_flop, alg_bytes = net_flop_per_eval(*a5, T=T_), T_ * 41 * 4 + 8
+        if generic:   # columns layer 0 multiplies: whole input quads; the specialised quiet form drops the masked columns first; whole tiles of 4 timesteps
+            exe_flop = net_flop_per_eval(*a5, T=pad4(T_), live_cols=pad4(a5[0] - 10) if (spec_form and not noisy) else pad4(a5[0]))
         ach_tflops = evals_per_launch * alg_flop / (kern_ms * 1e-3) / 1e12
         exe_tflops = evals_per_launch * exe_flop / (kern_ms * 1e-3) / 1e12
         ach_gbs = evals_per_launch * alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -565,7 +577,7 @@ def main():
                   ("multiswag, in-kernel draw per workgroup" if args.single_launch else "multiswag, draw-once workspace + forward"))
         if generic:
             kernel = (("bnn_spec_forward: the generic engine compiled at run time for this network (specialize.py, %.1f s incl. cache lookup; w8 %s)" % (spec_compile_s, args.spec_w8)
-                       if args.engine == "spec" else "bnn_forward_generic_kernel (weight registers streamed from an LDS image; draw-once workspace)") +
+                       if args.engine == "spec" else "bnn_spec_forward_v50q/n: the pretrained network's specialised forms compiled into the library (ragged series length)" if spec_form else "bnn_forward_generic_kernel (weight registers streamed from an LDS image; draw-once workspace)") +
                       (f", network hidden={net['hidden']} latent={net['latent']} in={net['depth_in']} out={net['depth_out']} features={NF}" if net else
                        ", the pretrained network forced onto the generic engine"))
         if lowp:
@@ -575,7 +587,7 @@ def main():
             "metric": "system x MC-sample forward evals/sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_OF[args.precision], "data": "synthetic",
-            "config": {"workload": wl["name"], "systems_per_gpu": B, "seeds": S, "mc_samples": M, "draws": J, "chunks": nch, "timesteps": 100,
+            "config": {"workload": wl["name"], "systems_per_gpu": B, "seeds": S, "mc_samples": M, "draws": J, "chunks": nch, "timesteps": args.timesteps,
                        "features": NF, "kernel": kernel,
                        "noise": ("in-kernel Philox: Philox4x32-7 for the input-noise stream (4 100 of the 4 180 normals of a noisy evaluation), "
                                  "Philox4x32-10 for every other stream" if noisy else "in-kernel Philox4x32-10"),

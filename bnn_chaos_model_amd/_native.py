@@ -87,6 +87,7 @@ def lib():
     L.bnn_spec_source.argtypes = [C.POINTER(BnnArch), C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
     L.bnn_plan_attach_spec.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t]
     L.bnn_plan_spec_attached.argtypes = [_vp, C.c_int32]
+    L.bnn_spec_embedded_source.argtypes = [C.c_char_p, C.c_size_t]
     L.bnn_feature_nn_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp]
     L.bnn_forward_lowp_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, C.c_int32,
                                        _vp, _vp, _vp, _vp]
@@ -126,7 +127,7 @@ EXPORTS = ("bnn_abi_version", "bnn_last_error", "bnn_device_count", "bnn_param_c
            "bnn_moments_f64", "bnn_truncnorm_f32", "bnn_prior_resample_f32", "bnn_regress_f32", "bnn_group_min_f32", "bnn_quantiles_f32", "bnn_feature_pack_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32",
            "bnn_prior_table_f32", "bnn_stats_draw_f32", "bnn_multiswag_stats_f32", "bnn_sketch_bins", "bnn_sketch_update_u32",
            "bnn_sketch_quantiles_f32", "bnn_forward_lowp_f32", "bnn_multiswag_moments_f64", "bnn_multiswag_bands_f32", "bnn_feature_nn_f32", "bnn_spec_source", "bnn_plan_attach_spec",
-           "bnn_plan_spec_attached")
+           "bnn_plan_spec_attached", "bnn_spec_embedded_source")
 
 
 def check(rc):
@@ -157,6 +158,14 @@ def spec_source(arch, noisy=False, w8=None, flags=0):
     n = check(lib().bnn_spec_source(C.byref(arch), w, int(bool(noisy)), int(flags), None, 0))
     buf = C.create_string_buffer(n + 1)
     check(lib().bnn_spec_source(C.byref(arch), w, int(bool(noisy)), int(flags), buf, n + 1))
+    return buf.value.decode()
+
+
+def spec_embedded_source():
+    """Text of csrc/bnn_fwd_v50spec.hip as the library would generate it now (scripts/regen_embedded.py writes it)."""
+    n = check(lib().bnn_spec_embedded_source(None, 0))
+    buf = C.create_string_buffer(n + 1)
+    check(lib().bnn_spec_embedded_source(buf, n + 1))
     return buf.value.decode()
 
 

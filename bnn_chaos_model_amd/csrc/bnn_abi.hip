@@ -547,6 +547,8 @@ struct bnn_plan {
     GenArch spec_gen[2];
     hipModule_t spec_mod[2] = {nullptr, nullptr};
     hipFunction_t spec_fn[2] = {nullptr, nullptr};
+    bool emb[2] = {false, false};   // the pretrained network's specialised forms compiled into the library (bnn_fwd_v50spec.hip) apply: [noisy]
+    GenArch emb_gen[2];
     int device = 0;
 };
 
@@ -609,6 +611,11 @@ int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
         pl->tab[1] = build_tables(arch->zero_mask, true, pl->megno);
         if (pl->d != layout_of(pl->megno).D) { delete pl; return fail(BNN_ERR_INVALID, "internal: the two engines disagree on the parameter count"); }
     }
+    if (pl->v50net && !pl->megno) {   // the forms of bnn_fwd_v50spec.hip: noisy under any mask, quiet under the pretrained one
+        const char* why = "";
+        pl->emb[1] = gen_build_spec(F, H, L, 1, 1, false, 1, 0, &pl->emb_gen[1], &why) == 0;
+        pl->emb[0] = arch->zero_mask == V50_ZERO_MASK && gen_build_spec(F, H, L, 1, 1, false, 1, V50_ZERO_MASK, &pl->emb_gen[0], &why) == 0;
+    }
     if (hipGetDevice(&pl->device) != hipSuccess) {
         delete pl;
         return fail(BNN_ERR_NO_DEVICE, "no HIP device");
@@ -650,6 +657,11 @@ static int spec_arch(const bnn_arch* a, int32_t w8, int32_t noisy, int32_t flags
     if (gen_build_spec(a->n_features, a->hidden, a->latent, a->depth_in, a->depth_out, a->fix_megno != 0, w8, drop, g, &why))
         return fail(BNN_ERR_UNSUPPORTED, why);
     return 0;
+}
+
+int bnn_spec_embedded_source(char* buf, size_t cap) {
+    const int n = gen_spec_embedded_source(buf, cap);
+    return n < 0 ? fail(BNN_ERR_UNSUPPORTED, "internal: the pretrained network's specialised descriptor") : n;
 }
 
 int bnn_spec_source(const bnn_arch* arch, int32_t w8, int32_t noisy, int32_t flags, char* buf, size_t cap) {
@@ -776,7 +788,10 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     if (g->engine < 0 || g->engine > 2) return fail(BNN_ERR_INVALID, "grid.engine must be 0 (choose), 1 (generic) or 2 (specialised)");
     const bool generic = !pl->v50net || (g->T % 4) != 0 || g->T < 8 || g->engine != 0;
     // the network's own compiled form of the generic engine, when one is attached (engine 2 insists on it)
-    const bool spec = generic && g->engine != 1 && pl->spec_fn[noisy ? 1 : 0] != nullptr;
+    const int nz = noisy ? 1 : 0;
+    const bool spec_mod = generic && g->engine != 1 && pl->spec_fn[nz] != nullptr;
+    const bool spec_emb = generic && g->engine != 1 && !spec_mod && pl->emb[nz];   // (an attached form wins over the embedded one)
+    const bool spec = spec_mod || spec_emb;
     if (g->engine == 2 && !spec) return fail(BNN_ERR_UNSUPPORTED, "grid.engine = 2: no specialised form is attached to this plan (bnn_plan_attach_spec)");
     if (generic && lowp) return fail(BNN_ERR_UNSUPPORTED, "the reduced-precision kernels are built for the pretrained network at T % 4 == 0 only");
     if (generic && fused) return fail(BNN_ERR_UNSUPPORTED, "the in-prologue draw (W_workspace = NULL) exists for the pretrained network at T % 4 == 0 only: pass a [J, d] workspace");
@@ -812,7 +827,12 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
         P.m23 = gen_merge_consts(cnt[2], cnt[3]);
         P.m0123 = gen_merge_consts(cnt[0] + cnt[1], cnt[2] + cnt[3]);
         P.noisy = noisy ? 1 : 0;
-        if (spec) {
+        if (spec_emb) {
+            e = launch_fwd_v50spec(noisy, (unsigned)nblk, st, P);
+            if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("embedded specialised forward kernel launch: ") + hipGetErrorString(e));
+            return 0;
+        }
+        if (spec_mod) {
             size_t psz = sizeof(P);
             void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &P, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz, HIP_LAUNCH_PARAM_END};
             e = hipModuleLaunchKernel(pl->spec_fn[noisy ? 1 : 0], (unsigned)nblk, 1, 1, 64u * pl->spec_gen[noisy ? 1 : 0].nwaves, 1, 1, 0, st, nullptr, cfg);

@@ -106,12 +106,11 @@ int gen_build_spec(int F, int H, int L, int depth_in, int depth_out, bool megno,
     return gen_build_impl(F, H, L, depth_in, depth_out, megno, true, w8, drop_mask, out, why);
 }
 
-int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, char* buf, size_t cap) {
-    std::string s;
+// One form's policy struct + kernel.  tag = "" for a stand-alone (run-time compiled) file, else the suffix of the names in the embedded unit.
+static void spec_form(std::string& s, const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, const char* tag) {
     char t[256];
     auto add = [&](const char* fmt, auto... a) { snprintf(t, sizeof t, fmt, a...); s += t; };
-    s += "// generated by bnn_spec_source (bnn_generic.cpp): the generic forward engine compiled for ONE network -- every shape a constant\n";
-    s += "#include \"bnn_generic.hip.h\"\n\nnamespace bnn {\nstruct SpecArch {\n";
+    add("namespace bnn {\nstruct SpecArch%s {\n", tag);
     add("    static constexpr bool kq_major = %s;\n", block_major ? "false" : "true");
     add("    static constexpr int n_feat = %d, n_reg = %d;\n", g.n_feat, g.n_reg);
     add("    static constexpr int pool_lq = %d, lat_nfull = %d;   // Welford state of the pool in registers (0: in LDS)\n", pool_regs ? g.lq : 0,
@@ -138,15 +137,44 @@ int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major,
     }
     s += "            }};\n        return value;\n    }\n};\n}  // namespace bnn\n\n";
     const bool w8 = g.nwaves == 8;
-    add("extern \"C\" __global__ __launch_bounds__(%d, 1) void bnn_spec_forward(const bnn::GenParams P) {\n", w8 ? 512 : 256);
+    add("extern \"C\" __global__ __launch_bounds__(%d, 1) void bnn_spec_forward%s(const bnn::GenParams P) {\n", w8 ? 512 : 256, tag);
     add("    __shared__ __attribute__((aligned(16))) float lds[%d];\n", g.lds_bytes / 4);
-    add("    bnn::generic_body<%d, %d, %s, bnn::SpecArch, %d>(P, lds);\n}\n", g.fq, g.hq, w8 ? "true" : "false", noisy ? 1 : 0);
+    add("    bnn::generic_body<%d, %d, %s, bnn::SpecArch%s, %d>(P, lds);\n}\n", g.fq, g.hq, w8 ? "true" : "false", tag, noisy ? 1 : 0);
+}
+
+static int copy_out(const std::string& s, char* buf, size_t cap) {
     if (buf && cap) {
         const size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
         memcpy(buf, s.data(), n);
         buf[n] = 0;
     }
     return (int)s.size();
+}
+
+int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, char* buf, size_t cap) {
+    std::string s = "// generated by bnn_spec_source (bnn_generic.cpp): the generic forward engine compiled for ONE network -- every shape a constant\n"
+                    "#include \"bnn_generic.hip.h\"\n\n";
+    spec_form(s, g, noisy, pool_regs, block_major, drop_mask, "");
+    return copy_out(s, buf, cap);
+}
+
+int gen_spec_embedded_source(char* buf, size_t cap) {
+    GenArch q, n;
+    const char* why = "";
+    if (gen_build_spec(F, H, L, 1, 1, false, 1, V50_ZERO_MASK, &q, &why) || gen_build_spec(F, H, L, 1, 1, false, 1, 0, &n, &why)) return -2;
+    std::string s = "// bnn_fwd_v50spec.hip -- GENERATED by bnn_spec_embedded_source (bnn_generic.cpp; scripts/regen_embedded.py), do not edit:\n"
+                    "// the pretrained network's two specialised forms of the generic forward engine (DESIGN.md section 4.10), compiled into the\n"
+                    "// library so that its ragged series lengths (T % 4 != 0, T < 8) need no compiler at run time.  Quiet form: the pretrained\n"
+                    "// column mask; noisy form: any mask.  tests/test_spec_cpu.py regenerates this text and compares.\n"
+                    "#include \"bnn_generic.hip.h\"\n\n";
+    spec_form(s, q, 0, 1, 0, V50_ZERO_MASK, "_v50q");
+    s += "\n";
+    spec_form(s, n, 1, 1, 0, 0, "_v50n");
+    s += "\nnamespace bnn {\nhipError_t launch_fwd_v50spec(bool noisy, unsigned nblk, hipStream_t st, const GenParams& P) {\n"
+         "    if (noisy) hipLaunchKernelGGL(bnn_spec_forward_v50n, dim3(nblk), dim3(512), 0, st, P);\n"
+         "    else hipLaunchKernelGGL(bnn_spec_forward_v50q, dim3(nblk), dim3(512), 0, st, P);\n"
+         "    return hipGetLastError();\n}\n}  // namespace bnn\n";
+    return copy_out(s, buf, cap);
 }
 
 }  // namespace bnn

@@ -87,6 +87,7 @@ hipError_t launch_fwd_lowp(int precision, unsigned nblk, hipStream_t st, const F
 hipError_t launch_fwd_megno(bool k31, bool fused, bool noisy, unsigned nblk, hipStream_t st, const FwdParams& p);  // hparams['fix_megno'] layout
 
 hipError_t launch_fwd_generic(const GenArch& g, unsigned nblk, hipStream_t st, const GenParams& P);  // any hparams network, any T >= 2
+hipError_t launch_fwd_v50spec(bool noisy, unsigned nblk, hipStream_t st, const GenParams& P);          // the pretrained network's specialised forms (generated unit)
 
 constexpr int MAX_DEVICES = 64;
 inline int current_device_slot() {

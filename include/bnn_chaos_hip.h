@@ -93,6 +93,10 @@ int bnn_plan_destroy(bnn_plan* plan);
 int bnn_spec_source(const bnn_arch* arch, int32_t w8, int32_t noisy, int32_t flags, char* buf, size_t cap);
 int bnn_plan_attach_spec(bnn_plan* plan, int32_t noisy, int32_t w8, int32_t flags, const void* image, size_t bytes);
 int bnn_plan_spec_attached(const bnn_plan* plan, int32_t noisy); /* 1 / 0 */
+/* The pretrained network's own two forms are compiled into the library (bnn_fwd_v50spec.hip, generated: this call returns its text):
+ * its ragged series lengths (T % 4 != 0, T < 8 -- everything its register-resident kernels do not take) run on them without any
+ * compiler at run time; quiet form under the pretrained column mask, noisy form under any mask. */
+int bnn_spec_embedded_source(char* buf, size_t cap);
 /* Accumulation order used by the kernels for Linear layer `layer` (0 .. number of Linear modules - 1, feature_nn's first): `order`
  * receives up to `cap` entries (input indices; the accumulator starts at the bias).  The generic engine's order is the natural one
  * (0, 1, 2, ...) for every layer; the v50 kernels permute regress_nn's.

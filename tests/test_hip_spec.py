@@ -110,3 +110,30 @@ def test_surface_specialize(tmp_path, ops):
         nbad, mx = close_report(o.numpy(), z[f"forward_noisy{int(noisy)}_out"])
         assert nbad == 0, (noisy, nbad, mx)
     assert m._plan().spec_attached(False) and m._plan().spec_attached(True)
+
+
+def test_pretrained_network_ragged_T_runs_on_the_embedded_forms(ops, swag_states, inputs):
+    """The pretrained network's two specialised forms are compiled INTO the library (bnn_fwd_v50spec.hip): at ragged series lengths the
+    default route takes them with nothing attached and no compiler at run time -- bit-identical to the ahead-of-time generic form.
+    Quiet form: the pretrained mask only; noisy form: any mask."""
+    from bnn_chaos_model_amd import _native as N
+    wa, w2, pd = (dev(swag_states[0][k][None]) for k in ("w_avg", "w2_avg", "pre_D"))
+    for mask in (ops.V50_ZERO_MASK, 0):
+        plan = N.Plan(mask)          # (a plan of its own: ops.get_plan's cached one may have had forms attached by the tests above)
+        assert plan.v50net and not plan.spec_attached(False) and not plan.spec_attached(True)
+        W = ops.swag_draw(wa, w2, pd, torch.zeros(3, dtype=torch.int32), philox_seed=5, plan=plan)
+        for T in (99, 37, 6, 2, 100):
+            x = dev(inputs["slow"][:, :T])
+            for noisy in (False, True):
+                kw = dict(philox_seed=4, draw_id0=9, system_id0=2, plan=plan, noisy=noisy, debug=True)
+                a = ops.forward(x, W, engine="generic", **kw)
+                if mask == 0 and not noisy:
+                    with pytest.raises(N.NativeError):
+                        ops.forward(x, W, engine="spec", **kw)      # no quiet form for another mask: an error, the default route stays generic
+                    continue
+                b = ops.forward(x, W, engine="spec", **kw)
+                for u, v in zip(a, b):
+                    assert torch.equal(u, v), (mask, T, noisy)
+                if T != 100:
+                    for u, v in zip(a, ops.forward(x, W, **kw)):
+                        assert torch.equal(u, v)

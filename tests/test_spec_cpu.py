@@ -63,3 +63,14 @@ def test_compile_cache_and_resource_report(N, tmp_path, monkeypatch):
     monkeypatch.setenv("BNN_SPEC_DEFINES", "BNN_GEN_ABLATE=2")   # measurement builds key differently
     S.best_variant(a, False)
     assert len(list(tmp_path.iterdir())) == 4
+
+
+def test_embedded_unit_matches_its_generator(N):
+    """csrc/bnn_fwd_v50spec.hip (the pretrained network's two specialised forms, compiled into the library) is generated text: the
+    committed file must be what the library's generator writes today (scripts/regen_embedded.py rewrites it)."""
+    import os
+    from bnn_chaos_model_amd.csrc import build
+    with open(os.path.join(os.path.dirname(build.__file__), "bnn_fwd_v50spec.hip")) as f:
+        assert f.read() == N.spec_embedded_source()
+    src = N.spec_embedded_source()
+    assert "bnn_spec_forward_v50q" in src and "bnn_spec_forward_v50n" in src and "in_q = 8" in src and "launch_fwd_v50spec" in src
