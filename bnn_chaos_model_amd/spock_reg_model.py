@@ -22,6 +22,8 @@ from collections import OrderedDict
 from copy import deepcopy as copy  # noqa: F401  (the reference module exports it: spock_reg_model.py, `from copy import deepcopy as copy`)
 
 import numpy as np
+import os
+
 import torch
 from torch import nn
 
@@ -159,6 +161,7 @@ class VarModel:
         self._w = torch.cat([v.detach().reshape(-1) for v in sd.values()]).float().contiguous()  # flat vector [d]
 
         self._latents_cache, self._last_latents_args = None, None
+        self._spec = ((False, True), None) if os.environ.get("BNN_AUTO_SPECIALIZE", "") not in ("", "0") else None
         self.megno_location = 7
         self.mmr_location = [3, 6]
         self.nan_location = [38, 39, 40]
@@ -251,8 +254,11 @@ class VarModel:
     def specialize(self, noisy=(False, True), w8=None):
         """Not in the reference (PyTorch needs no such step): compile this model's network into its own form of the generic forward
         engine (specialize.py: ~10 s of hipcc per form, cached on disk) -- bit-identical outputs, the schedule of a kernel written
-        for these shapes.  The pretrained ensemble's network at T % 4 == 0 keeps its own kernels either way."""
-        ops.specialize(self._plan(), noisy=noisy, w8=w8)
+        for these shapes.  The pretrained ensemble's network at T % 4 == 0 keeps its own kernels either way.  Every plan the model
+        hands out from now on (other devices of a multi-GPU call, another column mask) is specialised the same way.
+        BNN_AUTO_SPECIALIZE=1 in the environment does this for every model at construction."""
+        self._spec = (tuple(noisy) if not isinstance(noisy, bool) else (noisy,), w8)
+        self._plan()
         return self
 
     def train(self, mode=True):
@@ -300,8 +306,13 @@ class VarModel:
         return torch.ops.bnn_chaos
 
     def _plan(self, zero_mask=None, device=None):
-        return ops.get_plan(self.zero_mask() if zero_mask is None else zero_mask, self.lowest, device=device, fix_megno=self.fix_megno,
+        plan = ops.get_plan(self.zero_mask() if zero_mask is None else zero_mask, self.lowest, device=device, fix_megno=self.fix_megno,
                             **self._arch)
+        spec = getattr(self, "_spec", None)
+        if spec is not None and plan.__dict__.get("_spec_req") != spec and not (plan.v50net and not self.fix_megno):
+            ops.specialize(plan, noisy=spec[0], w8=spec[1])   # (the pretrained network has its forms in the library: nothing to compile)
+            plan.__dict__["_spec_req"] = spec                  # once per plan
+        return plan
 
     @property
     def _latent(self):

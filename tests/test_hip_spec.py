@@ -40,6 +40,7 @@ def warm_cache():
     from bnn_chaos_model_amd import specialize as S
     S.prewarm(NETS, noisy=(False, True), w8=(None,))
     S.prewarm([(56, 14, 1, 1, 41, False)], noisy=(False,), w8=(False, True))
+    S.prewarm([(64, 16, 1, 1, 41, False, 0)], noisy=(False, True), w8=(None,))
 
 
 @pytest.mark.parametrize("net", NETS, ids=lambda n: "h%dl%d_%d%d_f%d%s" % (n[0], n[1], n[2], n[3], n[4], "_megno" if n[5] else ""))
@@ -110,6 +111,8 @@ def test_surface_specialize(tmp_path, ops):
         nbad, mx = close_report(o.numpy(), z[f"forward_noisy{int(noisy)}_out"])
         assert nbad == 0, (noisy, nbad, mx)
     assert m._plan().spec_attached(False) and m._plan().spec_attached(True)
+    other = m._plan(zero_mask=0)                       # every plan the model hands out afterwards is specialised the same way
+    assert other is not m._plan() and other.spec_attached(False) and other.spec_attached(True)
 
 
 def test_pretrained_network_ragged_T_runs_on_the_embedded_forms(ops, swag_states, inputs):
