@@ -613,8 +613,8 @@ int bnn_plan_create(const bnn_arch* arch, bnn_plan** out) {
     }
     if (pl->v50net && !pl->megno) {   // the forms of bnn_fwd_v50spec.hip: noisy under any mask, quiet under the pretrained one
         const char* why = "";
-        pl->emb[1] = gen_build_spec(F, H, L, 1, 1, false, 1, 0, &pl->emb_gen[1], &why) == 0;
-        pl->emb[0] = arch->zero_mask == V50_ZERO_MASK && gen_build_spec(F, H, L, 1, 1, false, 1, V50_ZERO_MASK, &pl->emb_gen[0], &why) == 0;
+        pl->emb[1] = gen_build_spec(F, H, L, 1, 1, false, 1, 0, 1, &pl->emb_gen[1], &why) == 0;
+        pl->emb[0] = arch->zero_mask == V50_ZERO_MASK && gen_build_spec(F, H, L, 1, 1, false, 1, V50_ZERO_MASK, 1, &pl->emb_gen[0], &why) == 0;
     }
     if (hipGetDevice(&pl->device) != hipSuccess) {
         delete pl;
@@ -654,7 +654,7 @@ static int spec_arch(const bnn_arch* a, int32_t w8, int32_t noisy, int32_t flags
     if (noisy != 0 && noisy != 1) return fail(BNN_ERR_INVALID, "noisy must be 0 or 1");
     const char* why = "";
     const uint64_t drop = (noisy || (flags & BNN_SPEC_BLOCK_MAJOR)) ? 0 : a->zero_mask;
-    if (gen_build_spec(a->n_features, a->hidden, a->latent, a->depth_in, a->depth_out, a->fix_megno != 0, w8, drop, g, &why))
+    if (gen_build_spec(a->n_features, a->hidden, a->latent, a->depth_in, a->depth_out, a->fix_megno != 0, w8, drop, (flags & BNN_SPEC_POOL_REGS) ? 1 : 0, g, &why))
         return fail(BNN_ERR_UNSUPPORTED, why);
     return 0;
 }

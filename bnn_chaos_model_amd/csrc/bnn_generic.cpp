@@ -16,8 +16,8 @@ constexpr int HQ_BUCKETS[] = {12, 16, 24, 32};
 int mlp_nlin(int layers) { return layers == 0 ? 1 : layers + 2; }   // mlp() (spock_reg_model.py:301-321)
 }  // namespace
 
-static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool megno, bool spec, int w8, uint64_t drop_mask, GenArch* out,
-                          const char** why) {
+static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool megno, bool spec, int w8, uint64_t drop_mask, int pool_regs,
+                          GenArch* out, const char** why) {
     static const char* msg_f = "n_features must be 41 or 82 (time_series_features x (1 + include_derivatives))";
     static const char* msg_w = "hidden and latent must be in [1, 128] and the summary width 2 latent (+ 2) at most 128";
     static const char* msg_d = "depth `in` / `out` must be >= 0 with at most 16 Linear modules in the two MLPs together";
@@ -29,6 +29,7 @@ static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool
     if (depth_in < 0 || depth_out < 0 || mlp_nlin(depth_in) + mlp_nlin(depth_out) > GEN_MAX_LAYERS) { *why = msg_d; return -2; }
     GenArch g{};
     g.F = F; g.H = H; g.L = L; g.SM = SM; g.megno = megno ? 1 : 0;
+    g.pool_lds = (spec && pool_regs) ? 0 : 1;
     g.n_feat = mlp_nlin(depth_in); g.n_reg = mlp_nlin(depth_out);
     g.lq = (L + 3) / 4; g.smq = (SM + 3) / 4;
     g.fq = F == 41 ? 11 : 21;
@@ -99,11 +100,12 @@ static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool
 }
 
 int gen_build(int F, int H, int L, int depth_in, int depth_out, bool megno, GenArch* out, const char** why) {
-    return gen_build_impl(F, H, L, depth_in, depth_out, megno, false, -1, 0, out, why);
+    return gen_build_impl(F, H, L, depth_in, depth_out, megno, false, -1, 0, 0, out, why);
 }
 
-int gen_build_spec(int F, int H, int L, int depth_in, int depth_out, bool megno, int w8, uint64_t drop_mask, GenArch* out, const char** why) {
-    return gen_build_impl(F, H, L, depth_in, depth_out, megno, true, w8, drop_mask, out, why);
+int gen_build_spec(int F, int H, int L, int depth_in, int depth_out, bool megno, int w8, uint64_t drop_mask, int pool_regs, GenArch* out,
+                   const char** why) {
+    return gen_build_impl(F, H, L, depth_in, depth_out, megno, true, w8, drop_mask, pool_regs, out, why);
 }
 
 // One form's policy struct + kernel.  tag = "" for a stand-alone (run-time compiled) file, else the suffix of the names in the embedded unit.
@@ -129,8 +131,8 @@ static void spec_form(std::string& s, const GenArch& g, int noisy, int pool_regs
         s += "};\n        return t[k];\n    }\n";
     }
     s += "    static DEVINL GenArch get(const GenParams&) {\n        constexpr GenArch value = {\n";
-    add("            %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d,\n            {\n", g.F, g.H, g.L, g.SM, g.d, g.megno, g.n_feat,
-        g.n_reg, g.nwreg, g.nbias, g.fq, g.hq, g.lq, g.smq, g.nin_blocks, g.reg_in_lds, g.nwaves, g.lds_bytes, g.off_inlv, g.off_sumlv, g.in_live);
+    add("            %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d,\n            {\n", g.F, g.H, g.L, g.SM, g.d, g.megno, g.n_feat,
+        g.n_reg, g.nwreg, g.nbias, g.fq, g.hq, g.lq, g.smq, g.nin_blocks, g.reg_in_lds, g.nwaves, g.lds_bytes, g.off_inlv, g.off_sumlv, g.pool_lds, g.in_live);
     for (int l = 0; l < g.n_feat + g.n_reg; ++l) {
         const GenLayer& y = g.layer[l];
         add("                {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d},\n", y.K, y.N, y.nkq, y.nblk, y.ng_last, y.off_w, y.off_b, y.wreg0, y.bias0, y.relu);
@@ -161,7 +163,7 @@ int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major,
 int gen_spec_embedded_source(char* buf, size_t cap) {
     GenArch q, n;
     const char* why = "";
-    if (gen_build_spec(F, H, L, 1, 1, false, 1, V50_ZERO_MASK, &q, &why) || gen_build_spec(F, H, L, 1, 1, false, 1, 0, &n, &why)) return -2;
+    if (gen_build_spec(F, H, L, 1, 1, false, 1, V50_ZERO_MASK, 1, &q, &why) || gen_build_spec(F, H, L, 1, 1, false, 1, 0, 1, &n, &why)) return -2;
     std::string s = "// bnn_fwd_v50spec.hip -- GENERATED by bnn_spec_embedded_source (bnn_generic.cpp; scripts/regen_embedded.py), do not edit:\n"
                     "// the pretrained network's two specialised forms of the generic forward engine (DESIGN.md section 4.10), compiled into the\n"
                     "// library so that its ragged series lengths (T % 4 != 0, T < 8) need no compiler at run time.  Quiet form: the pretrained\n"

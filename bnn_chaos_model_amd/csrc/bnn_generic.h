@@ -52,6 +52,8 @@ struct GenArch {
     int32_t nwaves;               // waves per workgroup (8 for the narrowest bucket, else 4; 2 or 1 when the LDS budget forces it)
     int32_t lds_bytes;            // dynamic LDS of the launch
     int32_t off_inlv, off_sumlv;  // input_noise_logvar [F], summary_noise_logvar [SM]
+    int32_t pool_lds;             // 1: the pool's Welford state has LDS rows (2 lq KB per wave); 0: it lives in registers and the four partitions
+                                  // are merged by DPP (specialised forms with BNN_SPEC_POOL_REGS): no pool rows at all
     int32_t in_live;              // specialised quiet forms: layer 0 multiplies only the in_live unmasked columns (layer[0].K = in_live, its
                                   // weight rows are still F apart); 0 = every column (masked ones as zero weights)
     GenLayer layer[GEN_MAX_LAYERS];
@@ -66,8 +68,9 @@ int gen_build(int n_features, int hidden, int latent, int depth_in, int depth_ou
 // form (refused when eight waves' LDS does not fit), 0 for four waves (or fewer) at 512 registers, -1 lets the builder choose.
 // drop_mask: input columns (bits below 64) layer 0 leaves out altogether -- the plan's zero mask for the quiet form (the same sums: a
 // masked column only ever added +0), 0 for the noisy form (masked columns carry noise there) and for the block-major variant.
-int gen_build_spec(int n_features, int hidden, int latent, int depth_in, int depth_out, bool megno, int w8, uint64_t drop_mask, GenArch* out,
-                   const char** why);
+// pool_regs: the BNN_SPEC_POOL_REGS variant (no pool rows in LDS: more waves fit next to a large image).
+int gen_build_spec(int n_features, int hidden, int latent, int depth_in, int depth_out, bool megno, int w8, uint64_t drop_mask, int pool_regs,
+                   GenArch* out, const char** why);
 
 // Host: the HIP source of that form -- `static constexpr GenArch` + one extern "C" kernel `bnn_spec_forward` around generic_body.
 // Returns the length of the text (without the terminator); writes at most cap bytes.
@@ -80,7 +83,7 @@ int gen_spec_embedded_source(char* buf, size_t cap);
 // regress_nn's registers are not in the image -- a staging area for one block of them.
 BNN_HD inline int gen_sum_stride(const GenArch& g) { return 4 * g.smq; }   // (the 2 L pool normals share the summaries' rows: 2 L <= SM)
 BNN_HD inline int gen_wave_floats(const GenArch& g) {
-    return 2 * g.lq * 256 + 16 * gen_sum_stride(g) + 128 + (g.reg_in_lds ? 0 : g.hq * 64);
+    return (g.pool_lds ? 2 * g.lq * 256 : 0) + 16 * gen_sum_stride(g) + 128 + (g.reg_in_lds ? 0 : g.hq * 64);
 }
 // Workgroup-shared LDS floats: weight registers (+ one pad register for the read-ahead), biases, noise scales.
 BNN_HD inline int gen_wimg_floats(const GenArch& g) { return (g.nwreg + 1) * 64; }

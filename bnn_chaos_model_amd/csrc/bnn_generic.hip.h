@@ -285,6 +285,17 @@ DEVINL void gen_merge(const GenMerge mg, float& ma, float& qa, float mb, float q
     }
 }
 
+// The same merge between two lanes of a quad (state in registers, partner's through DPP): `self_is_b` orders the operands (a = the lower
+// partition), and the pair (0,1) / (2,3) step takes its constants per lane -- both results are formed and one is selected.
+DEVINL void gen_merge_lanes(const GenMerge lo, const GenMerge hi, bool sel_hi, bool self_is_b, float& m, float& q, float om, float oq) {
+    const float ma = self_is_b ? om : m, qa = self_is_b ? oq : q, mb = self_is_b ? m : om, qb = self_is_b ? q : oq;
+    float m1 = ma, q1 = qa, m2 = ma, q2 = qa;
+    gen_merge(lo, m1, q1, mb, qb);
+    gen_merge(hi, m2, q2, mb, qb);
+    m = sel_hi ? m2 : m1;
+    q = sel_hi ? q2 : q1;
+}
+
 // Where the kernel reads the network's shapes from.  ArchRuntime: the descriptor in global memory (scalar loads: the ahead-of-time
 // buckets, any network).  A policy whose get() returns a constexpr GenArch by value (written by bnn_spec_source, compiled at run time for ONE
 // network: specialize.py) turns every early exit, trip count and image offset below into a constant: the layer loops unroll into one
@@ -396,9 +407,9 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
     const float nm1 = (float)(T - 1), nT = (float)T;
     const int64_t rowstride = (int64_t)T * F;
     const int SMS = gen_sum_stride(G);
-    float* poolm = wave0 + (size_t)wave * gen_wave_floats(G);   // [lq][64 lanes][4] running means
-    float* poolq = poolm + lq * 256;                            // [lq][64][4] running M2
-    float* sumscr = poolq + lq * 256;                           // [16 systems][SMS] the pool normals (entries n, L + n), overwritten in place by
+    float* poolm = wave0 + (size_t)wave * gen_wave_floats(G);   // [lq][64 lanes][4] running means   (no such rows when G.pool_lds == 0:
+    float* poolq = poolm + lq * 256;                            // [lq][64][4] running M2              state in registers, merged by DPP)
+    float* sumscr = G.pool_lds ? poolq + lq * 256 : poolm;                         // [16 systems][SMS] the pool normals (entries n, L + n), overwritten in place by
                                                                 // the summaries: the lane that consumes normal n of a system writes summary n
     float* epsscr = sumscr;
     float* megscr = sumscr + 16 * SMS;                          // [64 lanes][2] MEGNO partitions
@@ -575,10 +586,6 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
             }
         }
 
-        if constexpr (PLQ > 0) {
-#pragma unroll
-            for (int g = 0; g < PLQ; ++g) { poolm4[g * 64 + lane] = pm[g]; poolq4[g * 64 + lane] = pq[g]; }
-        }
         // ---- tail: merge the four partitions of every latent, sampled moments (compute_summary_stats :420-431)
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
@@ -593,18 +600,7 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
         }
         __builtin_amdgcn_wave_barrier();   // the pool state and the normals written above are read across lanes below (one wave's LDS
                                            // operations complete in order: no wait is needed, only the compiler must not reorder)
-        for (int n = ph; n < L; n += 4) {
-            const int g = n >> 2, c = n & 3;
-            float m[4], q2[4];
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                const int idx = (g * 64 + 4 * sl + pp) * 4 + c;
-                m[pp] = poolm[idx];
-                q2[pp] = poolq[idx];
-            }
-            gen_merge(P.m01, m[0], q2[0], m[1], q2[1]);
-            gen_merge(P.m23, m[2], q2[2], m[3], q2[3]);
-            gen_merge(P.m0123, m[0], q2[0], m[2], q2[2]);
+        auto finish = [&](int n, float mean_, float m2_) __attribute__((always_inline)) {   // latent n of this lane's system: sampled moments -> summary
             float e1, e2;
             if (p.eps) {
                 const float* ep = p.eps + (r * p.B + sysc) * 2 * L;
@@ -615,13 +611,47 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
                 e2 = epsscr[sl * SMS + L + n];
             }
             float mu_s, sd_s;
-            sampled_moments(m[0], q2[0], e1, e2, nm1, nT, mu_s, sd_s);
+            sampled_moments(mean_, m2_, e1, e2, nm1, nT, mu_s, sd_s);
             sumscr[sl * SMS + n] = mu_s;
             sumscr[sl * SMS + L + n] = sd_s;
             if (p.summary && valid) {
                 float* sp = p.summary + (r * p.B + sys) * SM;
                 sp[n] = mu_s;
                 sp[L + n] = sd_s;
+            }
+        };
+        if constexpr (PLQ > 0) {
+            // state in registers: the quad's four lanes hold the four partitions of the same latents -- (0,1) and (2,3) merge through
+            // quad_perm [1,0,3,2], the halves through [2,3,0,1], every lane ends with the system's merged state; lane ph finishes latent 4 g + ph
+            const bool odd = (ph & 1) != 0, upper = (ph & 2) != 0;
+            static_for<PLQ>([&](auto GI) {
+                constexpr int g = GI;
+                f32x4 m = pm[g], q2 = pq[g];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float mi = m[i], qi = q2[i];
+                    gen_merge_lanes(P.m01, P.m23, upper, odd, mi, qi, quad_perm<0xB1>(mi), quad_perm<0xB1>(qi));
+                    gen_merge_lanes(P.m0123, P.m0123, false, upper, mi, qi, quad_perm<0x4E>(mi), quad_perm<0x4E>(qi));
+                    m[i] = mi; q2[i] = qi;
+                }
+                const float mm = ph == 0 ? m[0] : ph == 1 ? m[1] : ph == 2 ? m[2] : m[3];
+                const float qq = ph == 0 ? q2[0] : ph == 1 ? q2[1] : ph == 2 ? q2[2] : q2[3];
+                if (4 * g + ph < L) finish(4 * g + ph, mm, qq);
+            });
+        } else {
+            for (int n = ph; n < L; n += 4) {
+                const int g = n >> 2, c = n & 3;
+                float m[4], q2[4];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int idx = (g * 64 + 4 * sl + pp) * 4 + c;
+                    m[pp] = poolm[idx];
+                    q2[pp] = poolq[idx];
+                }
+                gen_merge(P.m01, m[0], q2[0], m[1], q2[1]);
+                gen_merge(P.m23, m[2], q2[2], m[3], q2[3]);
+                gen_merge(P.m0123, m[0], q2[0], m[2], q2[2]);
+                finish(n, m[0], q2[0]);
             }
         }
         if (ph == 0) {
