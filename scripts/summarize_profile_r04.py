@@ -18,7 +18,7 @@ def short(name):
     return name.split("(")[0].replace("void ", "")
 
 
-for wl in ("c3", "c2", "noisy", "c5", "c4", "gen_v50", "gen_h64l16", "gen_noisy", "small"):
+for wl in ("c3", "c2", "noisy", "c5", "c4", "gen_v50", "gen_h64l16", "gen_noisy", "spec_v50", "spec_h64l16", "spec_noisy", "spec_t99", "small"):
     f = os.path.join(src, wl, "trace_kernel_stats.csv")
     if os.path.exists(f):
         rows = list(csv.DictReader(open(f)))
@@ -55,6 +55,8 @@ outn = pmc("pmc_noisy_")
 json.dump(outn, open(os.path.join(dst, "r04_pmc_summary_noisy.json"), "w"), indent=1, sort_keys=True)
 outg = pmc("pmc_gen_v50_")
 json.dump(outg, open(os.path.join(dst, "r04_pmc_summary_generic_v50.json"), "w"), indent=1, sort_keys=True)
+outs = pmc("pmc_spec_v50_")
+json.dump(outs, open(os.path.join(dst, "r04_pmc_summary_spec_v50.json"), "w"), indent=1, sort_keys=True)
 
 
 def accounting(d, n_simd=1024, n_xcd=8):
@@ -78,8 +80,8 @@ def accounting(d, n_simd=1024, n_xcd=8):
 
 
 acc = {}
-for name, d in list(out.items()) + list(outn.items()) + list(outg.items()):
-    if ("forward_kernel" in name or "forward_generic_kernel" in name) and "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+for name, d in list(out.items()) + list(outn.items()) + list(outg.items()) + list(outs.items()):
+    if ("forward_kernel" in name or "forward_generic_kernel" in name or "bnn_spec_forward" in name) and "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
         acc[name] = accounting(d)
 json.dump(acc, open(os.path.join(dst, "r04_issue_accounting.json"), "w"), indent=1, sort_keys=True)
 
