@@ -34,6 +34,22 @@ NETS = [(40, 20, 1, 1, 41, False), (64, 16, 1, 1, 41, False), (33, 7, 1, 1, 41, 
         (40, 20, 1, 1, 82, False), (48, 24, 1, 1, 41, True), (72, 20, 1, 1, 41, False)]
 
 
+def fixture_archs():
+    """(hidden, latent, in, out, features, fix_megno, mask) of the reference-generated fixture networks used below."""
+    from bnn_chaos_model_amd import ops as o
+    out = []
+    for name in ("h64l16", "deep22", "deriv82", "h48megno", "allcols", "lin00", "h33l7"):
+        z = load_golden(f"case_arch_{name}.npz")
+        hp = json.loads(str(z["hparams_json"]))
+        for k, v in list(hp.items()):
+            if isinstance(v, str) and v in ("True", "False"):
+                hp[k] = v == "True"
+        mask = o.zero_mask_from_flags(hp.get("fix_megno", False), hp.get("fix_megno2", False), hp["include_mmr"], hp["include_nan"],
+                                      hp.get("include_eplusminus", True))
+        out.append((hp["hidden"], hp["latent"], hp["in"], hp["out"], int(z["n_features"]), hp.get("fix_megno", False), mask))
+    return out
+
+
 @pytest.fixture(scope="module", autouse=True)
 def warm_cache():
     """Compile every form this module attaches, side by side (hipcc subprocesses; nothing to do when the in-tree cache travelled)."""
@@ -41,6 +57,7 @@ def warm_cache():
     S.prewarm(NETS, noisy=(False, True), w8=(None,))
     S.prewarm([(56, 14, 1, 1, 41, False)], noisy=(False,), w8=(False, True))
     S.prewarm([(64, 16, 1, 1, 41, False, 0)], noisy=(False, True), w8=(None,))
+    S.prewarm(fixture_archs(), noisy=(False, True), w8=(None,))
 
 
 @pytest.mark.parametrize("net", NETS, ids=lambda n: "h%dl%d_%d%d_f%d%s" % (n[0], n[1], n[2], n[3], n[4], "_megno" if n[5] else ""))
@@ -68,6 +85,50 @@ def test_specialised_form_is_bit_identical_to_the_generic_engine(net, ops):
     a = ops.forward(x, W6, nchunks=3, philox_seed=5, plan=plan, engine="generic")
     b = ops.forward(x, W6, nchunks=3, philox_seed=5, plan=plan, engine="spec")
     assert torch.equal(a, b)
+
+
+FIXTURE_NETS = ("h64l16", "deep22", "deriv82", "h48megno", "allcols", "lin00", "h33l7")
+
+
+def _fixture_plan(ops, z):
+    hp = json.loads(str(z["hparams_json"]))
+    for k, v in list(hp.items()):
+        if isinstance(v, str) and v in ("True", "False"):
+            hp[k] = v == "True"
+    mask = ops.zero_mask_from_flags(hp.get("fix_megno", False), hp.get("fix_megno2", False), hp["include_mmr"], hp["include_nan"],
+                                    hp.get("include_eplusminus", True))
+    plan = ops.get_plan(mask, 0.1 if hp.get("lower_std", False) else 0.5, fix_megno=hp.get("fix_megno", False), n_features=int(z["n_features"]),
+                        hidden=hp["hidden"], latent=hp["latent"], depth_in=hp["in"], depth_out=hp["out"])
+    return plan, hp
+
+
+@pytest.mark.parametrize("name", FIXTURE_NETS)
+def test_specialised_forms_against_the_reference_fixtures(name, ops):
+    """The specialised forms -- each fixture's own column mask compiled in, masked columns dropped from layer 0 -- against what the
+    UNMODIFIED reference produced for that network (tests/golden/make_golden_arch.py): 1e-5 relative, zero exceedances, quiet and noisy,
+    forward and forward_swag_fast; and bit-identical to the ahead-of-time form on the same tapes."""
+    z = load_golden(f"case_arch_{name}.npz")
+    plan, hp = _fixture_plan(ops, z)
+    ops.specialize(plan)
+    tp = lambda pfx: [z[f"{pfx}_{i:03d}"] for i in range(int(z[pfx + "_n"]))]
+    x, W = dev(z["x"]), dev(z["swagfast_w"][None])
+    for noisy in (0, 1):
+        t = tp(f"forward_noisy{noisy}_tape")
+        e1, e2 = (t[1], t[2]) if noisy else (t[0], t[1])
+        eps = dev(np.stack([e1, e2], 1)[None])
+        kw = dict(eps_in=dev(t[0][None]), eps_sum=dev(t[3][None])) if noisy else {}
+        a = ops.forward(x, W, eps=eps, plan=plan, debug=True, engine="spec", **kw)
+        b = ops.forward(x, W, eps=eps, plan=plan, debug=True, engine="generic", **kw)
+        nbad, mx = close_report(a[0][0].cpu().numpy(), z[f"forward_noisy{noisy}_out"])
+        assert nbad == 0, (name, noisy, nbad, mx)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v), (name, noisy)
+    t = tp("swagfast_tape")
+    wa, w2, pd = dev(z["w_avg"][None]), dev(z["w2_avg"][None]), dev(z["pre_D"][None])
+    out = ops.multiswag(x, wa, w2, pd, torch.zeros(1, dtype=torch.int32), dev(t[0]), dev(t[1].reshape(1, -1)), dev(np.stack([t[2], t[3]], 1)[None]),
+                        plan=plan, engine="spec")
+    nbad, mx = close_report(out[0].cpu().numpy(), z["swagfast_out"])
+    assert nbad == 0, (name, nbad, mx)
 
 
 def test_both_wave_forms_and_errors(ops):
