@@ -44,9 +44,24 @@ def _extra_flags():
     return ["-D" + d for d in os.environ.get("BNN_SPEC_DEFINES", "").split()]
 
 
+_cc_id = None
+
+
+def _compiler_id():
+    """First line of `hipcc --version` (a ROCm upgrade must not be served the old compiler's code objects)."""
+    global _cc_id
+    if _cc_id is None:
+        try:
+            _cc_id = subprocess.run([_build.hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout.strip().split("\n")[0]
+        except Exception:
+            _cc_id = "unknown"
+    return _cc_id
+
+
 def _key(src):
     h = hashlib.sha256(src.encode())
     h.update(" ".join(SPEC_FLAGS + _extra_flags()).encode())
+    h.update(_compiler_id().encode())
     for name in _DEPS:   # the kernel source the generated file includes
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())

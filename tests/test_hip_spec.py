@@ -85,6 +85,17 @@ def test_specialised_form_is_bit_identical_to_the_generic_engine(net, ops):
     a = ops.forward(x, W6, nchunks=3, philox_seed=5, plan=plan, engine="generic")
     b = ops.forward(x, W6, nchunks=3, philox_seed=5, plan=plan, engine="spec")
     assert torch.equal(a, b)
+    # the statistics tail fused into the specialised kernel (the default route once attached) == the stand-alone epilogue on the
+    # ahead-of-time form's (mu, std); the slab driver's moments likewise
+    wa = W6[:2].contiguous()
+    w2 = wa ** 2 + 1e-4
+    pd = wa[:, :, None] + 0.01 * torch.randn(2, plan.d, 5, generator=g, device="cuda")
+    idx = torch.tensor([0, 1, 1, 0, 1, 0], dtype=torch.int32)
+    tq = ops.multiswag_stats(x, wa, w2, pd, idx, nchunks=3, philox_seed=3, draw_id0=6, system_id0=77, plan=plan)
+    ms = ops.multiswag(x, wa, w2, pd, idx, nchunks=3, philox_seed=3, draw_id0=6, system_id0=77, plan=plan)
+    assert torch.equal(tq, ops.stats_draw(ms, philox_seed=3, row_id0=2, system_id0=77))
+    if not plan.v50net:   # (the pretrained network at T = 100 runs its own kernels on the default route: another regress_nn order)
+        assert torch.equal(ms, ops.multiswag(x, wa, w2, pd, idx, nchunks=3, philox_seed=3, draw_id0=6, system_id0=77, plan=plan, engine="generic"))
 
 
 FIXTURE_NETS = ("h64l16", "deep22", "deriv82", "h48megno", "allcols", "lin00", "h33l7")
