@@ -78,16 +78,20 @@ def sharded_predictive_moments(local_moments_fn, B, group=None):
 class MultiSwagSharded:
     """Predictive moments of the dense (systems x draws) MultiSWAG grid on this rank's GPU, gathered over ranks."""
 
-    def __init__(self, w_avg, w2_avg, pre_D, zero_mask=None, lowest_std=0.5, group=None, draws_per_launch=256, devices=None, **arch):
+    def __init__(self, w_avg, w2_avg, pre_D, zero_mask=None, lowest_std=0.5, group=None, draws_per_launch=256, devices=None, specialize=False,
+                 **arch):
         """devices=None: one process per GPU (torch.distributed), this rank's current device.  devices="all" / an int / a list:
         ONE process drives those GPUs (multidevice.DeviceSet): predictive_moments / predictive_quantiles then take the WHOLE x
         (host or device memory), shard it, and return the assembled table on the first device.
-        **arch: n_features / hidden / latent / depth_in / depth_out / fix_megno of a network other than the pretrained one."""
+        **arch: n_features / hidden / latent / depth_in / depth_out / fix_megno of a network other than the pretrained one;
+        specialize=True compiles that network's own form of the generic engine (ops.specialize; every rank / device finds the code
+        objects in the shared cache after the first has written them)."""
         from . import ops
         self.ops = ops
         self.state = (w_avg, w2_avg, pre_D)
         self._mask = ops.V50_ZERO_MASK if zero_mask is None else zero_mask
         self._lowest, self._arch = lowest_std, arch
+        self._specialize = bool(specialize)
         self.devset = None
         if devices is not None:
             from .multidevice import DeviceSet
@@ -97,7 +101,11 @@ class MultiSwagSharded:
         self.draws_per_launch = int(draws_per_launch)
 
     def _plan_on(self, device):
-        return self.ops.get_plan(self._mask, self._lowest, device=device, **self._arch)
+        plan = self.ops.get_plan(self._mask, self._lowest, device=device, **self._arch)
+        if self._specialize and not plan.v50net and not plan.__dict__.get("_spec_req"):
+            self.ops.specialize(plan, noisy=(False,))   # the MC drivers are quiet forwards
+            plan.__dict__["_spec_req"] = ((False,), None)
+        return plan
 
     def local_moments(self, x_local, seed_idx, philox_seed, system_id0, scale=0.5):
         """x_local [B_r,T,41] on this rank's GPU; seed_idx [J] (identical on every rank) -> float64 [B_r,4].

@@ -93,9 +93,11 @@ def compile_source(src, verbose=False):
             info = {"vgpr": num("VGPRs"), "agpr": num("AGPRs"), "scratch": num(r"ScratchSize \[bytes/lane\]"), "vgpr_spill": num("VGPRs Spill"),
                     "lds": num(r"LDS Size \[bytes/block\]"), "compile_s": round(time.time() - t0, 1)}
             _move(tmp, path)
-            with open(path + f".{os.getpid()}.json", "w") as f:
+            import uuid
+            tmpj = path + f".{uuid.uuid4().hex}.json.part"
+            with open(tmpj, "w") as f:
                 json.dump(info, f)
-            os.replace(path + f".{os.getpid()}.json", path + ".json")
+            os.replace(tmpj, path + ".json")
     with open(path, "rb") as f:
         image = f.read()
     with open(path + ".json") as f:
@@ -104,7 +106,8 @@ def compile_source(src, verbose=False):
 
 def _move(src, dst):
     import shutil
-    part = dst + f".{os.getpid()}.part"
+    import uuid
+    part = dst + f".{uuid.uuid4().hex}.part"   # (unique per writer: threads of one process may compile the same form too)
     shutil.copyfile(src, part)
     os.replace(part, dst)   # atomic: concurrent ranks compiling the same form race to the same bytes
 

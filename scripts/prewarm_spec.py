@@ -19,6 +19,7 @@ rows += S.prewarm([(56, 14, 1, 1, 41, False)], noisy=(False,), w8=(False, True))
 rows += S.prewarm([(64, 16, 1, 1, 41, False, 0)], noisy=(False, True), w8=(None,))
 import test_hip_spec   # noqa: E402  (tests/: the fixture networks with their own masks)
 rows += S.prewarm(test_hip_spec.fixture_archs(), noisy=(False, True), w8=(None,))
+rows += S.prewarm([(24, 6, 1, 1, 41, False)], noisy=(False,), w8=(None,))
 for net, nz, w, info in rows:
     print(net, "noisy" if nz else "quiet", "w8=%s" % w, info)
 print(f"{len(rows)} forms in {S.cache_dir()} ({time.time() - t0:.0f} s)")

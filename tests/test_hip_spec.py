@@ -58,6 +58,7 @@ def warm_cache():
     S.prewarm([(56, 14, 1, 1, 41, False)], noisy=(False,), w8=(False, True))
     S.prewarm([(64, 16, 1, 1, 41, False, 0)], noisy=(False, True), w8=(None,))
     S.prewarm(fixture_archs(), noisy=(False, True), w8=(None,))
+    S.prewarm([(24, 6, 1, 1, 41, False)], noisy=(False,), w8=(None,))
 
 
 @pytest.mark.parametrize("net", NETS, ids=lambda n: "h%dl%d_%d%d_f%d%s" % (n[0], n[1], n[2], n[3], n[4], "_megno" if n[5] else ""))
@@ -212,3 +213,22 @@ def test_pretrained_network_ragged_T_runs_on_the_embedded_forms(ops, swag_states
                 if T != 100:
                     for u, v in zip(a, ops.forward(x, W, **kw)):
                         assert torch.equal(u, v)
+
+
+def test_sharded_driver_specialize(ops):
+    """distributed.MultiSwagSharded(specialize=True): the MC driver's moments through the network's specialised form == through the
+    ahead-of-time form (same bits: float64 sums of identical samples)."""
+    from bnn_chaos_model_amd.distributed import MultiSwagSharded
+    arch = dict(hidden=24, latent=6, n_features=41, depth_in=1, depth_out=1)
+    plan = ops.get_plan(**arch)
+    assert not plan.spec_attached(False)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    wa = torch.randn(2, plan.d, generator=g, device="cuda") * 0.25
+    w2 = wa ** 2 + 1e-4
+    pd = wa[:, :, None] + 0.01 * torch.randn(2, plan.d, 5, generator=g, device="cuda")
+    x = torch.randn(200, 100, 41, generator=g, device="cuda")
+    idx = torch.tensor([0, 1] * 8, dtype=torch.int32)
+    a = MultiSwagSharded(wa, w2, pd, draws_per_launch=4, **arch).local_moments(x, idx, 7, 0)
+    b = MultiSwagSharded(wa, w2, pd, draws_per_launch=4, specialize=True, **arch).local_moments(x, idx, 7, 0)
+    assert plan.spec_attached(False) and not plan.spec_attached(True)
+    assert a.dtype == torch.float64 and torch.equal(a, b)
