@@ -129,6 +129,10 @@ static void spec_form(std::string& s, const GenArch& g, int noisy, int pool_regs
             }
         for (; n < 4 * g.layer[0].nkq; ++n) add("%d, ", first);
         s += "};\n        return t[k];\n    }\n";
+        unsigned xq = 0;   // quads of a row with a live column (or the raw MEGNO column of fix_megno, summarize_megno :480-484)
+        for (int c = 0; c < g.F; ++c)
+            if (!(c < 64 && ((drop_mask >> c) & 1ull)) || (g.megno && c == MEGNO_COL)) xq |= 1u << (c >> 2);
+        add("    static constexpr uint32_t x_quads = 0x%xu;   // quads of an input row that are read at all\n", xq);
     }
     s += "    static DEVINL GenArch get(const GenParams&) {\n        constexpr GenArch value = {\n";
     add("            %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d,\n            {\n", g.F, g.H, g.L, g.SM, g.d, g.megno, g.n_feat,

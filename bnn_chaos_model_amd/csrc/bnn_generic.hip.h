@@ -24,13 +24,20 @@
 
 namespace bnn {
 
-template <int FQ>
+// QMASK: bit q set = quad q of the row is read (specialised quiet forms leave out the quads whose columns are all masked: they are
+// never multiplied -- layer 0 runs over the live columns only)
+template <int FQ, uint32_t QMASK = 0xffffffffu>
 DEVINL void gen_load_row(const float* __restrict__ rp, f32x4 (&xr)[FQ]) {
     static_assert(FQ == 11 || FQ == 21, "41 or 82 features");
     constexpr int NFULL = FQ - 1;
 #pragma unroll
-    for (int q = 0; q < NFULL; ++q) xr[q] = *reinterpret_cast<const f32x4u*>(rp + 4 * q);
-    if constexpr (FQ == 11) {
+    for (int q = 0; q < NFULL; ++q) {
+        if ((QMASK >> q) & 1u) xr[q] = *reinterpret_cast<const f32x4u*>(rp + 4 * q);
+        else xr[q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    if constexpr (((QMASK >> NFULL) & 1u) == 0) {
+        xr[NFULL] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    } else if constexpr (FQ == 11) {
         xr[10] = (f32x4){rp[40], 0.0f, 0.0f, 0.0f};
     } else {
         const f32x2 t = *reinterpret_cast<const f32x2u*>(rp + 80);
@@ -312,6 +319,12 @@ struct in_compact_of { static constexpr int q = 0; };
 template <class AS>
 struct in_compact_of<AS, std::void_t<decltype(AS::in_q)>> { static constexpr int q = AS::in_q; };
 
+// xq_mask_of<AS>::value: quads of an input row the kernel reads (policies that declare x_quads; else all)
+template <class AS, class = void>
+struct xq_mask_of { static constexpr uint32_t value = 0xffffffffu; };
+template <class AS>
+struct xq_mask_of<AS, std::void_t<decltype(AS::x_quads)>> { static constexpr uint32_t value = AS::x_quads; };
+
 struct ArchRuntime {
     static constexpr bool kq_major = false;   // weight image block-major (register (nb, kq) at nb * nkq + kq), gen_layer
     static DEVINL const GenArch& get(const GenParams& P) { return *P.g; }
@@ -435,7 +448,7 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
         constexpr bool XPREF = HQ < 32 && !(W8 && HQ > 12);   // (the eight-wave form of the 16-quad bucket has no registers for it either)
         f32x4 xr[FQ];
         if constexpr (XPREF) {
-            gen_load_row<FQ>(sysp + (int64_t)(ph0 < T ? ph0 : T - 1) * F, xr);
+            gen_load_row<FQ, xq_mask_of<AS>::value>(sysp + (int64_t)(ph0 < T ? ph0 : T - 1) * F, xr);
             asm volatile("" ::: "memory");
         }
         f32x4 a[HQ], b[HQ];
@@ -513,7 +526,7 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
             const int tc = tv ? t : T - 1;
             const float rcn = p.rcp_tab[it];
             latrow = (p.latents && valid0 && tv) ? p.latents + (((r * p.B + sys0) * T) + t) * (int64_t)L : nullptr;
-            if constexpr (!XPREF) gen_load_row<FQ>(sysp + (int64_t)tc * F, xr);
+            if constexpr (!XPREF) gen_load_row<FQ, xq_mask_of<AS>::value>(sysp + (int64_t)tc * F, xr);
             if (G.megno && tv) {   // summarize_megno (:480-484): the RAW column, before the masks and before any noise
                 const float xm = xr[MEGNO_COL >> 2][MEGNO_COL & 3];
                 const float dl = xm - gmean;
@@ -568,7 +581,7 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
             // x of this tile is dead: fetch the next tile's rows into the same registers
             if constexpr (XPREF && !(BNN_GEN_ABLATE & 4)) {
                 const int tn = 4 * (it + 1) + ph0;
-                gen_load_row<FQ>(sysp + (int64_t)(tn < T ? tn : T - 1) * F, xr);
+                gen_load_row<FQ, xq_mask_of<AS>::value>(sysp + (int64_t)(tn < T ? tn : T - 1) * F, xr);
                 asm volatile("" ::: "memory");
             }
             // the remaining Linear modules of feature_nn, ping-pong between the two register arrays
