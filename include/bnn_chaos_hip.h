@@ -30,7 +30,9 @@ extern "C" {
 
 /* v3: bnn_arch carries the network depth (any hparams-built network, not only the pretrained ensemble's); bnn_philox_normal_f32 takes
  * the feature count; bnn_sketch_bins counts the NaN bin (the last hist row); bnn_fragment_table(which = 1) returns the weight-register
- * table; bnn_arch.reserved became fix_megno; bnn_build_flags() names the build. */
+ * table; bnn_arch.reserved became fix_megno; bnn_build_flags() names the build; bnn_feature_nn_f32 (the latents side effect);
+ * bnn_spec_source / bnn_plan_attach_spec / bnn_plan_spec_attached / bnn_spec_embedded_source (specialised forms of the generic engine);
+ * bnn_grid.engine = 2. */
 #define BNN_ABI_VERSION 3
 
 enum bnn_status {

@@ -232,3 +232,32 @@ def test_sharded_driver_specialize(ops):
     b = MultiSwagSharded(wa, w2, pd, draws_per_launch=4, specialize=True, **arch).local_moments(x, idx, 7, 0)
     assert plan.spec_attached(False) and not plan.spec_attached(True)
     assert a.dtype == torch.float64 and torch.equal(a, b)
+
+
+def test_specialised_form_at_scale_invariances(ops):
+    """200 000 systems x 30 draws (6e6 evaluations) of the (64, 16) network through its specialised form == the ahead-of-time form, bit
+    for bit; and the size-independent properties of the path hold on it: no dependence on the block size, on system sharding (global
+    Philox ids), on draw slabs; chunked draws cut torch.chunk pieces."""
+    plan = _plan(ops, 64, 16, 1, 1)
+    ops.specialize(plan, noisy=(False,))
+    g = torch.Generator(device="cuda").manual_seed(21)
+    B, J, seed = 200_000, 30, 5
+    x = torch.randn(B, 100, 41, generator=g, device="cuda") * 0.1 + torch.randn(B, 1, 41, generator=g, device="cuda")
+    W = torch.randn(J, plan.d, generator=g, device="cuda") * 0.2
+    kw = dict(philox_seed=seed, draw_id0=60, system_id0=1000, plan=plan)
+    full = ops.forward(x, W, engine="spec", **kw)
+    assert torch.isfinite(full).all() and torch.equal(full, ops.forward(x, W, engine="generic", **kw))
+    for spb in (64, 1024):
+        assert torch.equal(full, ops.forward(x, W, engine="spec", systems_per_block=spb, **kw))
+    cut = 70_001
+    lo = ops.forward(x[:cut], W, engine="spec", **kw)
+    hi = ops.forward(x[cut:], W, engine="spec", **dict(kw, system_id0=1000 + cut))
+    assert torch.equal(full, torch.cat([lo, hi], 1))
+    assert torch.equal(full[10:20], ops.forward(x, W[10:20], engine="spec", **dict(kw, draw_id0=70)))
+    ch = ops.forward(x, W, engine="spec", nchunks=10, **kw)        # draw j covers chunk j % 10 of the systems (torch.chunk)
+    assert ch.shape == (3, B, 2) and torch.equal(ch, ops.forward(x, W, engine="generic", nchunks=10, **kw))
+    csz = -(-B // 10)
+    for r, c in ((0, 0), (1, 3), (2, 9)):
+        sl = slice(c * csz, min((c + 1) * csz, B))
+        alone = ops.forward(x, W[r * 10 + c:r * 10 + c + 1], engine="spec", **dict(kw, draw_id0=6 + r))   # the same draw over every system, output-row id 60 / 10 + r
+        assert torch.equal(ch[r, sl], alone[0, sl])
