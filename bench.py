@@ -276,7 +276,8 @@ def parse(argv=None):
     ap.add_argument("--precision", default="f32", choices=sorted(DTYPE_OF), help="opt-in reduced-precision forward (workload c5 / c3 / c2)")
     ap.add_argument("--engine", default="auto", choices=("auto", "generic", "spec"),
                     help="generic: force the generic forward engine (LDS-streamed weights); spec: its run-time-compiled form for this network (specialize.py)")
-    ap.add_argument("--spec-w8", default="auto", choices=("auto", "0", "1"), help="--engine spec: eight waves at 256 registers (1), four at 512 (0), builder's choice")
+    ap.add_argument("--spec-w8", default="auto", choices=("auto", "0", "1", "2"),
+                    help="--engine spec: eight waves at 256 registers (1), four at 512 (0), sixteen at 128 (2: small networks), builder's choice")
     ap.add_argument("--timesteps", type=int, default=100, help="series length T (100 = every BASELINE config; others: the ragged lengths of the reference's "
                     "`augment`, which the generic engine / its specialised forms take)")
     ap.add_argument("--net", default="", help="hidden,latent,in,out[,features]: another hparams-built network on a synthetic ensemble (generic engine)")
@@ -396,7 +397,7 @@ def main():
     plan = ops.get_plan(**net) if net else ops.get_plan()
     if args.engine == "spec":   # compile this network's own form of the generic engine (cached on disk) before anything is timed
         t0 = time.time()
-        ops.specialize(plan, noisy=(noisy,), w8={"auto": None, "0": False, "1": True}[args.spec_w8])
+        ops.specialize(plan, noisy=(noisy,), w8={"auto": None, "0": False, "1": True, "2": 2}[args.spec_w8])
         spec_compile_s = time.time() - t0
     x = synthetic_x(B, dev, seed=123 + rank, F=NF)    # this rank's shard
     T_ = args.timesteps

@@ -153,8 +153,13 @@ SPEC_POOL_REGS = 1
 SPEC_BLOCK_MAJOR = 2
 
 
+def _waves_code(w8):
+    """None -> -1 (builder's choice), False -> 0 (at most four waves), True -> 1 (eight), 2 -> sixteen (four per SIMD at 128 registers)."""
+    return -1 if w8 is None else (2 if w8 == 2 and w8 is not True else int(bool(w8)))
+
+
 def spec_source(arch, noisy=False, w8=None, flags=0):
-    w = -1 if w8 is None else int(bool(w8))
+    w = _waves_code(w8)
     n = check(lib().bnn_spec_source(C.byref(arch), w, int(bool(noisy)), int(flags), None, 0))
     buf = C.create_string_buffer(n + 1)
     check(lib().bnn_spec_source(C.byref(arch), w, int(bool(noisy)), int(flags), buf, n + 1))
@@ -193,7 +198,7 @@ class Plan:
 
     def attach_spec(self, image, noisy=False, w8=None, flags=0):
         """Load a compiled specialised form (code object bytes) into the plan; the current device must be the plan's."""
-        check(lib().bnn_plan_attach_spec(self.handle, int(bool(noisy)), -1 if w8 is None else int(bool(w8)), int(flags), image, len(image)))
+        check(lib().bnn_plan_attach_spec(self.handle, int(bool(noisy)), _waves_code(w8), int(flags), image, len(image)))
 
     def spec_attached(self, noisy=False):
         return bool(check(lib().bnn_plan_spec_attached(self.handle, int(bool(noisy)))))

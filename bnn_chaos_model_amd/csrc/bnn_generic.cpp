@@ -21,7 +21,7 @@ static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool
     static const char* msg_f = "n_features must be 41 or 82 (time_series_features x (1 + include_derivatives))";
     static const char* msg_w = "hidden and latent must be in [1, 128] and the summary width 2 latent (+ 2) at most 128";
     static const char* msg_d = "depth `in` / `out` must be >= 0 with at most 16 Linear modules in the two MLPs together";
-    static const char* msg_8 = "eight waves' pool state does not fit LDS next to this network's weight image";
+    static const char* msg_8 = "that many waves' pool state does not fit LDS next to this network's weight image";
     static const char* msg_l = "feature_nn's weights do not fit the 160 KB of LDS (roughly F*H + in*H*H + H*L <= 36 000 floats)";
     if (F != 41 && F != 82) { *why = msg_f; return -2; }
     const int SM = 2 * L + (megno ? 2 : 0);
@@ -78,7 +78,9 @@ static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool
         GenArch t = g;
         t.nwreg = nwreg;
         t.reg_in_lds = reg_in_lds;
-        for (int nw : {8, 4, 2, 1}) {   // eight waves (two per SIMD) only where the kernel fits 256 registers: the narrowest bucket
+        for (int nw : {16, 8, 4, 2, 1}) {   // eight waves (two per SIMD) only where the kernel fits 256 registers: the narrowest bucket
+            if (nw == 16 && !(spec && w8 == 2)) continue;   // sixteen (four per SIMD, 128 registers): specialised forms of small networks, on request
+            if (nw != 16 && spec && w8 == 2) continue;
             if (nw == 8 && (spec ? w8 == 0 : false)) continue;
             if (nw == 8 && (spec ? w8 < 0 : true) && (t.hq > GEN_W8_HQ || t.fq != 11)) continue;
             if (nw != 8 && spec && w8 == 1) continue;
@@ -87,7 +89,7 @@ static int gen_build_impl(int F, int H, int L, int depth_in, int depth_out, bool
         return 0;
     };
     const int w_all = waves_for(nfeat_regs + nreg_regs, 1), w_feat = waves_for(nfeat_regs, 0);
-    if (!w_feat) { *why = (spec && w8 == 1) ? msg_8 : msg_l; return -2; }
+    if (!w_feat) { *why = (spec && w8 >= 1) ? msg_8 : msg_l; return -2; }
     g.reg_in_lds = (w_all >= w_feat) ? 1 : 0;
     g.nwaves = g.reg_in_lds ? w_all : w_feat;
     g.nwreg = nfeat_regs + (g.reg_in_lds ? nreg_regs : 0);
@@ -115,6 +117,7 @@ static void spec_form(std::string& s, const GenArch& g, int noisy, int pool_regs
     add("namespace bnn {\nstruct SpecArch%s {\n", tag);
     add("    static constexpr bool kq_major = %s;\n", block_major ? "false" : "true");
     add("    static constexpr int n_feat = %d, n_reg = %d;\n", g.n_feat, g.n_reg);
+    if (g.nwaves == 16) s += "    static constexpr bool x_late = true;   // four waves per SIMD at 128 registers: no row prefetch\n";
     add("    static constexpr int pool_lq = %d, lat_nfull = %d;   // Welford state of the pool in registers (0: in LDS)\n", pool_regs ? g.lq : 0,
         4 * (g.layer[g.n_feat - 1].nblk - 1));
     if (g.in_live) {   // layer 0 over the unmasked columns: logical input k -> column live(k) (padding slots repeat column live(0): zero weights)
@@ -142,8 +145,8 @@ static void spec_form(std::string& s, const GenArch& g, int noisy, int pool_regs
         add("                {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d},\n", y.K, y.N, y.nkq, y.nblk, y.ng_last, y.off_w, y.off_b, y.wreg0, y.bias0, y.relu);
     }
     s += "            }};\n        return value;\n    }\n};\n}  // namespace bnn\n\n";
-    const bool w8 = g.nwaves == 8;
-    add("extern \"C\" __global__ __launch_bounds__(%d, 1) void bnn_spec_forward%s(const bnn::GenParams P) {\n", w8 ? 512 : 256, tag);
+    const bool w8 = g.nwaves >= 8;
+    add("extern \"C\" __global__ __launch_bounds__(%d, 1) void bnn_spec_forward%s(const bnn::GenParams P) {\n", g.nwaves == 16 ? 1024 : w8 ? 512 : 256, tag);
     add("    __shared__ __attribute__((aligned(16))) float lds[%d];\n", g.lds_bytes / 4);
     add("    bnn::generic_body<%d, %d, %s, bnn::SpecArch%s, %d>(P, lds);\n}\n", g.fq, g.hq, w8 ? "true" : "false", tag, noisy ? 1 : 0);
 }

@@ -319,6 +319,12 @@ struct in_compact_of { static constexpr int q = 0; };
 template <class AS>
 struct in_compact_of<AS, std::void_t<decltype(AS::in_q)>> { static constexpr int q = AS::in_q; };
 
+// x_late_of<AS>::value: the tile's rows are read at the top of the tile instead of a tile ahead (policies that declare x_late)
+template <class AS, class = void>
+struct x_late_of { static constexpr bool value = false; };
+template <class AS>
+struct x_late_of<AS, std::void_t<decltype(AS::x_late)>> { static constexpr bool value = AS::x_late; };
+
 // xq_mask_of<AS>::value: quads of an input row the kernel reads (policies that declare x_quads; else all)
 template <class AS, class = void>
 struct xq_mask_of { static constexpr uint32_t value = 0xffffffffu; };
@@ -445,7 +451,8 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
         // XPREF: the next tile's rows are fetched right behind layer 1 of the current one (a tile of work to land).  The widest
         // bucket has no registers to hold them across the other layers (two 128-register activation arrays): it loads at the top of
         // the tile and waits (about 1 us of a tile of 20 us or more at those widths).
-        constexpr bool XPREF = HQ < 32 && !(W8 && HQ > 12);   // (the eight-wave form of the 16-quad bucket has no registers for it either)
+        constexpr bool XPREF = HQ < 32 && !(W8 && HQ > 12) && !x_late_of<AS>::value;   // (the eight-wave form of the 16-quad bucket has no registers for it either;
+                                                                                       // sixteen-wave forms: three partner waves cover the load instead)
         f32x4 xr[FQ];
         if constexpr (XPREF) {
             gen_load_row<FQ, xq_mask_of<AS>::value>(sysp + (int64_t)(ph0 < T ? ph0 : T - 1) * F, xr);

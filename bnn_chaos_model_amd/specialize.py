@@ -120,7 +120,7 @@ def best_variant(arch, noisy, w8=None, verbose=False):
     w8 = None searches the eight-wave forms first (two waves per SIMD won every same-box A/B where they fit without spilling:
     profiles/r04_spec_engine.jsonl), then the four-wave ones."""
     best = None
-    for w in ((True, False) if w8 is None else (bool(w8),)):
+    for w in ((True, False) if w8 is None else (w8,)):
         for flags in VARIANTS:
             try:
                 src = N.spec_source(arch, noisy, w, flags)
@@ -152,7 +152,7 @@ def prewarm(archs, noisy=(False, True), w8=(None,), jobs=None):
             for w in w8:
                 if w is not None:
                     try:
-                        N.spec_source(a, nz, w, 0)
+                        N.spec_source(a, nz, w, N.SPEC_POOL_REGS)
                     except N.NativeError:
                         continue   # (a form this network cannot have, e.g. eight waves next to a large image)
                 jobs_.append(((H, L, din, dout, NF, megno), a, nz, w))
