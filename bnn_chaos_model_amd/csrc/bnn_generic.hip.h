@@ -17,6 +17,13 @@
 //   * regress_nn runs through the same layer routine with lane = system (the four lanes of a quad repeat the work: 3 280 of
 //     407 280 MACs for the v50 shapes), its weight registers from the LDS image when they fit, else gathered from the flat vector.
 // Accumulation order per output: bias, then inputs ascending -- the oracle's natural order for every layer.
+//
+// ONE body, two ways to feed it its shapes: generic_body<FQ, HQ, W8, AS, NOISY> with AS = ArchRuntime is what the
+// ahead-of-time buckets (bnn_fwd_generic*.hip) instantiate; a policy whose get() returns a constexpr GenArch -- written by
+// bnn_spec_source for ONE network and compiled at run time (specialize.py), or generated ahead of time for the pretrained network
+// (bnn_fwd_v50spec.hip) -- folds every count, and switches on (by its traits) the input-quad-major layer routine with one-step-ahead
+// weight reads, the pool state in registers with a DPP merge, layer 0 over the unmasked columns only.  Same arithmetic, same order:
+// bit-identical outputs.
 #pragma once
 #include "bnn_common.hip.h"
 #include "bnn_generic.h"

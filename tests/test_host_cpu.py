@@ -443,3 +443,8 @@ def test_headline_kernels_use_no_scratch(N):
             assert k["vgpr"] <= 256 and k["agpr"] == 0 and k["scratch"] <= 320, k
         elif name.startswith("bnn::bnn_forward_generic_kernel<11"):
             assert k["scratch"] == 0, k
+    # the pretrained network's specialised forms compiled into the library: eight waves (256 registers), no scratch, LDS without pool rows
+    emb = {k["name"]: k for k in ks if k["name"].startswith("bnn_spec_forward_v50")}
+    assert sorted(emb) == ["bnn_spec_forward_v50n", "bnn_spec_forward_v50q"]
+    for k in emb.values():
+        assert k["vgpr"] <= 256 and k["agpr"] == 0 and k["scratch"] == 0 and k["vgpr_spills"] == 0 and 0 < k["lds"] <= 80 * 1024, k
