@@ -34,11 +34,14 @@ NETS = [(40, 20, 1, 1, 41, False), (64, 16, 1, 1, 41, False), (33, 7, 1, 1, 41, 
         (40, 20, 1, 1, 82, False), (48, 24, 1, 1, 41, True), (72, 20, 1, 1, 41, False)]
 
 
+FIXTURE_NETS = ("h64l16", "deep22", "deep30", "deriv82", "h48megno", "allcols", "lin00", "h33l7", "h20l10")
+
+
 def fixture_archs():
     """(hidden, latent, in, out, features, fix_megno, mask) of the reference-generated fixture networks used below."""
     from bnn_chaos_model_amd import ops as o
     out = []
-    for name in ("h64l16", "deep22", "deriv82", "h48megno", "allcols", "lin00", "h33l7"):
+    for name in FIXTURE_NETS:
         z = load_golden(f"case_arch_{name}.npz")
         hp = json.loads(str(z["hparams_json"]))
         for k, v in list(hp.items()):
@@ -97,9 +100,6 @@ def test_specialised_form_is_bit_identical_to_the_generic_engine(net, ops):
     assert torch.equal(tq, ops.stats_draw(ms, philox_seed=3, row_id0=2, system_id0=77))
     if not plan.v50net:   # (the pretrained network at T = 100 runs its own kernels on the default route: another regress_nn order)
         assert torch.equal(ms, ops.multiswag(x, wa, w2, pd, idx, nchunks=3, philox_seed=3, draw_id0=6, system_id0=77, plan=plan, engine="generic"))
-
-
-FIXTURE_NETS = ("h64l16", "deep22", "deriv82", "h48megno", "allcols", "lin00", "h33l7")
 
 
 def _fixture_plan(ops, z):
