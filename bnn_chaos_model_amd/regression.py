@@ -52,6 +52,14 @@ class FeatureRegressor(object):
         self._cpu_state = None
 
     # ---- every visible GPU from this one process (multidevice.py) ------------------------------------------------
+    def specialize(self, noisy=(False,), w8=None):
+        """Not in the reference: compile the ensemble's network into its own form of the generic forward engine (VarModel.specialize;
+        the members share one network, hence one plan per device and column mask).  The MC drivers are quiet forwards: noisy=(False,)
+        by default.  Returns self."""
+        for m in self.swag_ensemble:
+            m.specialize(noisy=noisy, w8=w8)
+        return self
+
     def device_set(self, devices=None):
         """devices: None = every visible GPU (an unchanged single-process script then uses the whole node); an int n = the first n;
         a list of indices / torch.devices = exactly those (a device may be named several times: logical shards on one card)."""

@@ -129,3 +129,10 @@ def test_another_network_through_the_batched_drivers(tmp_path):
     assert torch.equal(a["percentiles"], b["percentiles"]) and a["percentiles"].shape == (15, 5)
     with pytest.raises(NotImplementedError):
         fr.sample_full_swag_many(X[:, :, :40], samples=1)
+    # the same ensemble through its run-time-compiled kernels (FeatureRegressor.specialize): not a bit changes, on any shard
+    assert fr.specialize() is fr and fr.swag_ensemble[0]._plan().spec_attached(False)
+    np.random.seed(4); torch.manual_seed(4)
+    assert torch.equal(one, fr.sample_full_swag_many(X, samples=3, chunks=10, devices=[0, 0, 0]))
+    np.random.seed(5)
+    c = fr.predictive_bands(X, samples=32, chunks=5, trios=3, philox_seed=8, samples_per_launch=8, devices=[0, 0])
+    assert torch.equal(a["percentiles"], c["percentiles"])
