@@ -47,6 +47,22 @@ def test_limits_are_errors(N):
     assert "generic_body<21, " in N.spec_source(arch(N, 40, 20, 1, 1, NF=82), False, None, 0)
 
 
+def test_abi_argument_errors(N):
+    import ctypes as C
+    L = N.lib()
+    a = arch(N)
+    assert L.bnn_spec_source(None, -1, 0, 0, None, 0) < 0                                    # NULL arch
+    assert L.bnn_spec_source(C.byref(a), -1, 2, 0, None, 0) < 0                              # noisy is 0 / 1
+    n = L.bnn_spec_source(C.byref(a), -1, 0, N.SPEC_POOL_REGS, None, 0)
+    small = C.create_string_buffer(16)
+    assert L.bnn_spec_source(C.byref(a), -1, 0, N.SPEC_POOL_REGS, small, 16) == n and len(small.value) == 15   # truncated, terminated, full length returned
+    assert L.bnn_plan_attach_spec(None, 0, -1, 0, b"x", 1) < 0 and L.bnn_plan_spec_attached(None, 0) < 0
+    bad = N.BnnArch(41, 40, 20, 2, 0, 0.5, 0.0, 1, 1)                                         # fix_megno must be 0 / 1
+    assert L.bnn_spec_source(C.byref(bad), -1, 0, 0, None, 0) < 0
+    masked_all = N.BnnArch(41, 40, 20, 0, (1 << 41) - 1, 0.5, 0.0, 1, 1)                      # every column masked: nothing to multiply
+    assert L.bnn_spec_source(C.byref(masked_all), -1, 0, 0, None, 0) < 0 and b"masked" in L.bnn_last_error()
+
+
 def test_compile_cache_and_resource_report(N, tmp_path, monkeypatch):
     from bnn_chaos_model_amd import specialize as S
     hipcc()   # RuntimeError when ROCm's compiler is missing: nothing to test then
