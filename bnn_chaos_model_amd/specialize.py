@@ -112,29 +112,76 @@ def _move(src, dst):
     os.replace(part, dst)   # atomic: concurrent ranks compiling the same form race to the same bytes
 
 
-VARIANTS = (N.SPEC_POOL_REGS, 0, N.SPEC_BLOCK_MAJOR)   # tried in this order: the first whose code object needs no scratch is taken
+VARIANTS = (N.SPEC_POOL_REGS, N.SPEC_BLOCK_MAJOR)   # the candidates per wave count (flags 0 -- input-quad-major layers with the pool in
+                                                     # LDS rows -- never beat POOL_REGS where both compiled: BNN_SPEC_FORCE_FLAGS=0 still builds it)
 
 
-def best_variant(arch, noisy, w8=None, verbose=False):
-    """Compile the tuning variants of one form until one has no scratch; -> (image, info incl. "flags" and "w8").
-    w8 = None searches the eight-wave forms first (two waves per SIMD won every same-box A/B where they fit without spilling:
-    profiles/r04_spec_engine.jsonl), then the four-wave ones."""
-    best = None
+def candidates(arch, noisy, w8=None, verbose=False, jobs=None):
+    """Every (waves, variant) form of the network that the builder accepts, compiled side by side -> [(image, info)], info incl. "flags",
+    "w8" (True / False) and the compiler's resource report.  BNN_SPEC_FORCE_FLAGS=<n>: that variant only (measurements)."""
+    from concurrent.futures import ThreadPoolExecutor
+    variants = VARIANTS
+    if os.environ.get("BNN_SPEC_FORCE_FLAGS", "") != "":
+        variants = (int(os.environ["BNN_SPEC_FORCE_FLAGS"]),)
+    todo, refused = [], None
     for w in ((True, False) if w8 is None else (w8,)):
-        for flags in VARIANTS:
+        for flags in variants:
             try:
-                src = N.spec_source(arch, noisy, w, flags)
-            except N.NativeError:
-                if w8 is not None:
-                    raise
-                break          # eight waves' LDS does not fit next to this network's image
-            image, info = compile_source(src, verbose=verbose)
-            info = dict(info, flags=flags, w8=w)
-            if info["scratch"] == 0:
-                return image, info
-            if best is None or info["scratch"] < best[1]["scratch"]:
-                best = (image, info)
-    return best
+                todo.append((w, flags, N.spec_source(arch, noisy, w, flags)))
+            except N.NativeError as e:   # (a form this network cannot have, e.g. eight waves next to a large image)
+                refused = e
+    if not todo:
+        raise refused
+    uniq = {}
+    for w, flags, src in todo:      # (different requests can come out as the same text, e.g. when only four waves fit either way)
+        uniq.setdefault(src, (w, flags))
+    with ThreadPoolExecutor(max_workers=jobs or min(8, len(uniq))) as ex:
+        built = list(ex.map(lambda src: compile_source(src, verbose=verbose), uniq))
+    def nwaves(src):   # waves per workgroup the builder settled on (the 17th field of the GenArch initializer)
+        import re
+        return int(re.search(r"constexpr GenArch value = \{\s*([^{]*)\{", src).group(1).split(",")[16])
+
+    return [(image, dict(info, flags=uniq[src][1], w8=uniq[src][0], nwaves=nwaves(src))) for src, (image, info) in zip(uniq, built)]
+
+
+def rank_static(cands):
+    """Without a GPU to time them on (profiles/r04_spec_tuning.jsonl is what this order was read from): forms that put at least one wave
+    on every SIMD first (hidden 128: the only scratch-free form runs ONE wave per CU and is 4x slower than a spilling four-wave one);
+    among those, no scratch before scratch (82 features, noisy: eight spilling waves are 2.4x slower than four clean ones); then more
+    waves per CU; then the VARIANTS order."""
+    def waves_per_cu(info):
+        nw = info.get("nwaves") or (16 if (info["w8"] == 2 and info["w8"] is not True) else 8 if info["w8"] else 4)
+        # a workgroup of at most four waves that leaves half the LDS and half the registers free runs two to a CU
+        return 2 * nw if (nw <= 4 and info["lds"] <= 80 * 1024 and info["vgpr"] + max(info["agpr"], 0) <= 256) else nw
+
+    def key(c):
+        info = c[1]
+        return (waves_per_cu(info) < 4, info["scratch"] > 0, -waves_per_cu(info), info["scratch"],
+                VARIANTS.index(info["flags"]) if info["flags"] in VARIANTS else 9)
+    return sorted(cands, key=key)
+
+
+def best_variant(arch, noisy, w8=None, verbose=False, measure=None):
+    """-> (image, info) of the form to attach.  measure: callable(image, info) -> seconds (specialize() passes one when a GPU is there:
+    every candidate is timed on a small synthetic grid and the fastest wins -- results are bit-identical across candidates, only the
+    speed differs); None: rank_static."""
+    cands = rank_static(candidates(arch, noisy, w8, verbose=verbose))
+    if measure is None or len(cands) == 1:
+        return cands[0]
+    timed = []
+    for image, info in cands:
+        try:
+            timed.append((measure(image, info), image, info))
+        except Exception as e:   # a candidate that does not load or launch is not a candidate
+            if verbose:
+                print("candidate failed:", info, e)
+    if not timed:
+        return cands[0]
+    fastest = min(t[0] for t in timed)
+    timed.sort(key=lambda t: (t[0] > 1.03 * fastest, [id(c[0]) for c in cands].index(id(t[1]))))   # within 3 % of the fastest: the static order decides
+    info = dict(timed[0][2], tuned_ms=round(timed[0][0] * 1e3, 3),
+                candidates=[{"w8": i["w8"], "flags": i["flags"], "scratch": i["scratch"], "ms": round(t * 1e3, 3)} for t, _, i in timed])
+    return timed[0][1], info
 
 
 def prewarm(archs, noisy=(False, True), w8=(None,), jobs=None):
@@ -161,19 +208,80 @@ def prewarm(archs, noisy=(False, True), w8=(None,), jobs=None):
     return [(j[0], j[2], j[3], i) for j, i in zip(jobs_, infos)]
 
 
-def specialize(plan, noisy=(False, True), w8=None, verbose=False):
+def _measure_on(plan, nz):
+    """Times one attached candidate on a synthetic grid shaped like BASELINE configs[1] cut to 96 draws (10 000 systems x 100 timesteps:
+    1 920 workgroups of up to 512 systems, the last of each draw ragged; in-kernel Philox): seconds."""
+    import torch
+    from . import ops
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(10000, 100, plan.n_features, generator=g, device="cuda")
+    W = torch.randn(96, plan.d, generator=g, device="cuda") * 0.1
+
+    def run(image, info):
+        plan.attach_spec(image, nz, info["w8"], info["flags"])
+        best = float("inf")
+        for rep in range(3):
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            ops.forward(x, W, philox_seed=1, plan=plan, noisy=nz, engine="spec")
+            t1.record()
+            t1.synchronize()
+            if rep:
+                best = min(best, t0.elapsed_time(t1) * 1e-3)
+        return best
+    return run
+
+
+def _choice_path(arch, nz, w8):
+    import ctypes as C
+    h = hashlib.sha256(bytes(C.string_at(C.addressof(arch), C.sizeof(arch))) + repr((bool(nz), w8, _compiler_id())).encode())
+    for name in _DEPS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return os.path.join(cache_dir(), f"choice_{h.hexdigest()[:20]}.json")
+
+
+def specialize(plan, noisy=(False, True), w8=None, verbose=False, tune=True):
     """Compile (or fetch from the cache) and attach the plan's specialised forms.  noisy: which forms -- forward(noisy_val=False) and
-    forward_swag_fast use the quiet one, forward(noisy_val=True) the noisy one.  w8: None = the builder's choice of eight waves at 256
-    registers vs four at 512; True / False to force (A/B).  Returns the plan (plan.spec_info[noisy] = the compiler's resource report)."""
+    forward_swag_fast use the quiet one, forward(noisy_val=True) the noisy one.  w8: None = every wave count the builder accepts;
+    True / False / 2 to force eight / at most four / sixteen waves (A/B).  tune: time the candidates on this GPU and keep the fastest
+    (the decision is remembered next to the code objects); False: the static ranking.  Returns the plan (plan.spec_info[noisy] = the
+    compiler's resource report of the attached form, with the candidates' timings when it was tuned)."""
+    import json
     if isinstance(noisy, bool):
         noisy = (noisy,)
     todo = [bool(nz) for nz in noisy if not (plan.spec_attached(nz) and getattr(plan, "_spec_w8", {}).get(bool(nz), "unset") == w8)]
     if not todo:
         return plan
     from concurrent.futures import ThreadPoolExecutor
+
+    def one(nz):   # a decision remembered from an earlier run on this machine: compile (or fetch) just that form
+        cp = _choice_path(plan.arch, nz, w8)
+        if tune and os.path.exists(cp) and os.environ.get("BNN_SPEC_FORCE_FLAGS", "") == "":
+            with open(cp) as f:
+                want = json.load(f)
+            try:
+                image, info = compile_source(N.spec_source(plan.arch, nz, want["w8"], want["flags"]), verbose=verbose)
+            except N.NativeError:
+                return None
+            return image, dict(info, w8=want["w8"], flags=want["flags"], tuned_ms=want.get("tuned_ms"), candidates=want.get("candidates"))
+        return None
+
     with ThreadPoolExecutor(max_workers=len(todo)) as ex:   # the forms compile side by side (hipcc subprocesses)
-        built = list(ex.map(lambda nz: best_variant(plan.arch, nz, w8, verbose=verbose), todo))
-    for nz, (image, info) in zip(todo, built):
+        remembered = list(ex.map(one, todo))
+        cands = list(ex.map(lambda nz: None if remembered[todo.index(nz)] else rank_static(candidates(plan.arch, nz, w8, verbose=verbose)), todo))
+    for nz, rem, cs in zip(todo, remembered, cands):
+        if rem is not None:
+            image, info = rem
+        elif tune and len(cs) > 1:
+            image, info = best_variant(plan.arch, nz, w8, verbose=verbose, measure=_measure_on(plan, nz))
+            if os.environ.get("BNN_SPEC_FORCE_FLAGS", "") == "":
+                tmp = _choice_path(plan.arch, nz, w8) + f".{os.getpid()}.part"
+                with open(tmp, "w") as f:
+                    json.dump({"w8": info["w8"], "flags": info["flags"], "tuned_ms": info.get("tuned_ms"), "candidates": info.get("candidates")}, f)
+                os.replace(tmp, _choice_path(plan.arch, nz, w8))
+        else:
+            image, info = cs[0]
         plan.attach_spec(image, nz, info["w8"], info["flags"])
         plan.__dict__.setdefault("_spec_w8", {})[nz] = w8
         plan.__dict__.setdefault("spec_info", {})[nz] = info

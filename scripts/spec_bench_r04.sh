@@ -21,12 +21,13 @@ if [ "$1" = "quick" ]; then
   run "--workload c2"
   exit 0
 fi
-for net in "" "--net 64,16,1,1" "--net 20,10,1,1" "--net 40,20,2,2" "--net 40,20,1,1,82" "--net 128,32,1,1 --steps 3"; do
+for net in "" "--net 64,16,1,1" "--net 20,10,1,1" "--net 40,20,2,2" "--net 40,20,1,1,82" "--net 64,32,1,1" "--net 80,20,1,1" "--net 100,30,1,1 --steps 5" "--net 128,32,1,1 --steps 3"; do
   run "--workload c2 $net --engine generic"
-  run "--workload c2 $net --engine spec --spec-w8 0"
-  case "$net" in *128*) ;; *) run "--workload c2 $net --engine spec --spec-w8 1" ;; esac
+  run "--workload c2 $net --engine spec"            # the form the specialiser's measured selection attaches
+  case "$net" in ""|*64,16*) run "--workload c2 $net --engine spec --spec-w8 0"; run "--workload c2 $net --engine spec --spec-w8 1";; esac
 done
 run "--workload noisy --engine generic"
-run "--workload noisy --engine spec --spec-w8 0"
-run "--workload noisy --engine spec --spec-w8 1"
+run "--workload noisy --engine spec"
 run "--workload noisy"
+run "--workload c2 --timesteps 99"
+run "--workload c2 --timesteps 99 --engine generic"

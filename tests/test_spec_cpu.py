@@ -69,16 +69,29 @@ def test_compile_cache_and_resource_report(N, tmp_path, monkeypatch):
     monkeypatch.setenv("BNN_SPEC_CACHE", str(tmp_path))
     assert S.cache_dir() == str(tmp_path)
     a = arch(N)
-    image, info = S.best_variant(a, False)
+    cands = S.candidates(a, False)                         # every (waves, variant) form the builder accepts, compiled side by side
+    assert {(i["w8"], i["flags"]) for _, i in cands} == {(w, f) for w in (True, False) for f in S.VARIANTS}
+    image, info = S.best_variant(a, False)                 # no GPU here: the static ranking -- eight waves, pool in registers, no scratch
     assert b"bnn_spec_forward" in image and info["scratch"] == 0 and info["w8"] is True and info["flags"] == N.SPEC_POOL_REGS
     assert 0 < info["vgpr"] <= 256 and 0 < info["lds"] <= 160 * 1024
     files = sorted(p.name for p in tmp_path.iterdir())
-    assert len(files) == 2 and files[0].endswith(".hsaco") and files[1].endswith(".hsaco.json")
+    assert len(files) == 2 * len(cands) and sum(f.endswith(".hsaco") for f in files) == len(cands)
     image2, info2 = S.best_variant(a, False)               # second time: from the cache, same bytes, same report
     assert image2 == image and info2 == info and sorted(p.name for p in tmp_path.iterdir()) == files
     monkeypatch.setenv("BNN_SPEC_DEFINES", "BNN_GEN_ABLATE=2")   # measurement builds key differently
     S.best_variant(a, False)
-    assert len(list(tmp_path.iterdir())) == 4
+    assert len(list(tmp_path.iterdir())) == 4 * len(cands)
+    monkeypatch.delenv("BNN_SPEC_DEFINES")
+    # the ranking without a GPU (read off profiles/r04_spec_tuning.jsonl): a wave on every SIMD first, then no scratch, then more waves
+    assert all(i["nwaves"] == (8 if i["w8"] else 4) for _, i in cands)
+    fake = lambda w8, flags, scratch, lds=100000, vgpr=200, agpr=0, nwaves=None: (b"", dict(w8=w8, flags=flags, scratch=scratch, lds=lds, vgpr=vgpr, agpr=agpr,
+                                                                                               nwaves=nwaves or (8 if w8 else 4)))
+    pick = lambda *c: (lambda i: (i["w8"], i["flags"]))(S.rank_static(list(c))[0][1])
+    assert pick(fake(False, 2, 0, lds=137000, vgpr=256, agpr=144, nwaves=1), fake(False, 1, 892, lds=152880, vgpr=256, agpr=256)) == (False, 1)   # hidden 128
+    assert pick(fake(True, 1, 652, lds=150000, vgpr=256), fake(False, 1, 0, lds=61744, vgpr=256, agpr=196), fake(False, 2, 0, lds=70000, vgpr=256, agpr=190)) == (False, 1)   # 82 features, noisy
+    assert pick(fake(False, 1, 0), fake(True, 1, 0), fake(True, 2, 0), fake(False, 2, 0)) == (True, 1)                                          # all clean: eight waves
+    assert pick(fake(False, 1, 0, lds=120000, vgpr=250, agpr=200), fake(False, 1, 0, lds=60000, vgpr=170, agpr=50))[0] is False
+    assert S.rank_static([fake(False, 1, 0, lds=120000, vgpr=250, agpr=200), fake(False, 1, 0, lds=60000, vgpr=170, agpr=50)])[0][1]["lds"] == 60000   # two four-wave workgroups per CU beat one
 
 
 def test_embedded_unit_matches_its_generator(N):
