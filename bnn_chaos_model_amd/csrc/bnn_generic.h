@@ -79,12 +79,15 @@ int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major,
 // pretrained mask, noisy under any) as one translation unit of the library, with their launcher.
 int gen_spec_embedded_source(char* buf, size_t cap);
 
-// Per-wave LDS floats: pool state (mean, M2 per latent group, lane-major), Philox scratch, summaries, MEGNO partitions, and -- when
-// regress_nn's registers are not in the image -- a staging area for one block of them.
+// Per-wave LDS floats: the pool state (mean, M2 per latent group, lane-major) while the tiles run and -- IN THE SAME ROWS, once the
+// partitions are merged -- the staging area for one block of regress_nn's weight registers when those are not in the image
+// (gen_pool_stage_floats = the larger of the two); then the summaries / Philox scratch and the MEGNO partitions.
 BNN_HD inline int gen_sum_stride(const GenArch& g) { return 4 * g.smq; }   // (the 2 L pool normals share the summaries' rows: 2 L <= SM)
-BNN_HD inline int gen_wave_floats(const GenArch& g) {
-    return (g.pool_lds ? 2 * g.lq * 256 : 0) + 16 * gen_sum_stride(g) + 128 + (g.reg_in_lds ? 0 : g.hq * 64);
+BNN_HD inline int gen_pool_stage_floats(const GenArch& g) {
+    const int pool = g.pool_lds ? 2 * g.lq * 256 : 0, stage = g.reg_in_lds ? 0 : g.hq * 64;
+    return pool > stage ? pool : stage;
 }
+BNN_HD inline int gen_wave_floats(const GenArch& g) { return gen_pool_stage_floats(g) + 16 * gen_sum_stride(g) + 128; }
 // Workgroup-shared LDS floats: weight registers (+ one pad register for the read-ahead), biases, noise scales.
 BNN_HD inline int gen_wimg_floats(const GenArch& g) { return (g.nwreg + 1) * 64; }
 BNN_HD inline int gen_nsc_floats(const GenArch& g) { return 4 * ((g.F + 3) / 4) + 4 * ((g.SM + 3) / 4) + 8 * g.nin_blocks * 2; }

@@ -435,11 +435,12 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
     const int SMS = gen_sum_stride(G);
     float* poolm = wave0 + (size_t)wave * gen_wave_floats(G);   // [lq][64 lanes][4] running means   (no such rows when G.pool_lds == 0:
     float* poolq = poolm + lq * 256;                            // [lq][64][4] running M2              state in registers, merged by DPP)
-    float* sumscr = G.pool_lds ? poolq + lq * 256 : poolm;                         // [16 systems][SMS] the pool normals (entries n, L + n), overwritten in place by
+    float* stage = poolm;                                       // [hq][64] weight registers of one block (regress_nn layers outside the image):
+                                                                // the pool rows again -- they are dead once the partitions are merged
+    float* sumscr = poolm + gen_pool_stage_floats(G);           // [16 systems][SMS] the pool normals (entries n, L + n), overwritten in place by
                                                                 // the summaries: the lane that consumes normal n of a system writes summary n
     float* epsscr = sumscr;
     float* megscr = sumscr + 16 * SMS;                          // [64 lanes][2] MEGNO partitions
-    float* stage = megscr + 128;                                // [hq][64] weight registers of one block (regress_nn layers outside the image)
     f32x4* poolm4 = reinterpret_cast<f32x4*>(poolm);
     f32x4* poolq4 = reinterpret_cast<f32x4*>(poolq);
 
