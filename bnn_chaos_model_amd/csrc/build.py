@@ -28,6 +28,13 @@ def hipcc():
     raise RuntimeError("hipcc not found (need ROCm; this library has no CPU build)")
 
 
+def clean_env():
+    """Environment for the compiler subprocesses: without a profiler's preloaded tool library (under `rocprofv3 --pmc` every child that
+    inherits LD_PRELOAD initialises the GPU before its main() and then execs its own helpers -- which GPU pools may refuse)."""
+    drop = ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")
+    return {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("ROCPROF", "ROCPROFILER_", "ROCP_"))}
+
+
 def _mtime(name):
     return os.path.getmtime(os.path.join(HERE, name))
 
@@ -86,7 +93,7 @@ def build(force=False, verbose=False, extra=(), out=None):
         cmd = [cc] + CFLAGS + UNIT_FLAGS.get(src, []) + list(extra) + build_flags_define + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd, cwd=HERE)
+        subprocess.check_call(cmd, cwd=HERE, env=clean_env())
         return obj
 
     # a build with extra switches names itself: bnn_build_flags() returns them, bench.py writes them into its JSON line
@@ -99,7 +106,7 @@ def build(force=False, verbose=False, extra=(), out=None):
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", so + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=HERE)
+    subprocess.check_call(cmd, cwd=HERE, env=clean_env())
     os.replace(so + ".tmp", so)
     with open(so + ".srchash", "w") as f:
         f.write(source_hash(extra))

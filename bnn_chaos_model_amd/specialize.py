@@ -44,6 +44,9 @@ def _extra_flags():
     return ["-D" + d for d in os.environ.get("BNN_SPEC_DEFINES", "").split()]
 
 
+_clean_env = _build.clean_env
+
+
 _cc_id = None
 
 
@@ -52,7 +55,7 @@ def _compiler_id():
     global _cc_id
     if _cc_id is None:
         try:
-            _cc_id = subprocess.run([_build.hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout.strip().split("\n")[0]
+            _cc_id = subprocess.run([_build.hipcc(), "--version"], capture_output=True, text=True, timeout=60, env=_clean_env()).stdout.strip().split("\n")[0]
         except Exception:
             _cc_id = "unknown"
     return _cc_id
@@ -86,7 +89,7 @@ def compile_source(src, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             t0 = time.time()
-            r = subprocess.run(cmd, capture_output=True, text=True)
+            r = subprocess.run(cmd, capture_output=True, text=True, env=_clean_env())
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed on the specialised kernel:\n" + r.stderr[-4000:])
             num = lambda k: int((re.search(k + r":\s*(\d+)", r.stderr) or [0, -1])[1])
