@@ -3,10 +3,11 @@
 The reference builds its network from hparams (spock_reg_model.py:301-321, 346-362) and PyTorch runs whatever comes out at the same
 speed.  Here the ahead-of-time generic engine reads the shapes from a descriptor: every trip count is a run-time number behind an
 early exit, and the kernel is a nest of small basic blocks the compiler cannot schedule across.  `specialize(plan)` compiles the
-SAME kernel source (csrc/bnn_generic.hip.h) for the plan's one network with every shape a compile-time constant -- about ten seconds
-of hipcc per form, cached on disk -- and attaches the code object to the plan; from then on every entry point that would take the
-generic route launches it.  Accumulation order and arithmetic are those of the ahead-of-time form: results are bit-identical
-(tests/test_hip_spec.py); only the schedule changes.
+SAME kernel source (csrc/bnn_generic.hip.h) for the plan's one network with every shape a compile-time constant -- a handful of
+candidate forms (waves per workgroup x layer routine), ten to forty seconds of hipcc side by side, cached on disk --, times the
+candidates on the GPU, keeps the fastest (remembered next to the code objects) and attaches it to the plan; from then on every entry
+point that would take the generic route launches it.  Accumulation order and arithmetic are those of the ahead-of-time form: results
+are bit-identical (tests/test_hip_spec.py); only the schedule changes.
 
 Needs hipcc at run time (ROCm's own compiler: this is a ROCm-only library).  No hipcc -> RuntimeError; nothing falls back silently,
 and an un-specialised plan keeps working on the ahead-of-time form."""
