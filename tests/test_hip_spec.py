@@ -261,3 +261,45 @@ def test_specialised_form_at_scale_invariances(ops):
         sl = slice(c * csz, min((c + 1) * csz, B))
         alone = ops.forward(x, W[r * 10 + c:r * 10 + c + 1], engine="spec", **dict(kw, draw_id0=6 + r))   # the same draw over every system, output-row id 60 / 10 + r
         assert torch.equal(ch[r, sl], alone[0, sl])
+
+
+def random_archs():
+    """[(hidden, latent, in, out, features, fix_megno, mask, T)] of the sweep below (seeded; scripts/prewarm_spec.py compiles them too)."""
+    from bnn_chaos_model_amd.ops import V50_ZERO_MASK
+    rng = np.random.default_rng(777)
+    out = []
+    for trial in range(7):
+        F = 82 if trial == 4 else 41
+        H = int(rng.choice([1, 8, 17, 24, 49, 64, 77, 100]))
+        L = int(rng.choice([1, 2, 5, 12, 20, 31, 48]))
+        din, dout = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+        megno = bool(rng.integers(0, 2))
+        mask = (V50_ZERO_MASK if trial % 3 == 1 else int(rng.integers(0, 1 << 41))) | ((1 << 7) if megno else 0)
+        out.append((H, L, din, dout, F, megno, mask, int(rng.choice([2, 3, 5, 8, 37, 100]))))
+    return out
+
+
+def test_random_architectures_every_candidate_form(ops):
+    """Seeded random networks (widths 1..100, depths 0..3, 41 / 82 features, fix_megno, random column masks, ragged T): EVERY candidate
+    form the specialiser would choose from (waves per workgroup x layer routine) equals the ahead-of-time generic engine bit for bit,
+    quiet and noisy.  (scripts/dev/spec_random_sweep.py is the long version: 16 networks, 112 forms.)"""
+    from bnn_chaos_model_amd import _native as N, specialize as S
+    rng = np.random.default_rng(778)
+    nforms = 0
+    for (H, L, din, dout, F, megno, mask, T) in random_archs():
+        try:
+            plan = N.Plan(mask, 0.5, n_features=F, hidden=H, latent=L, fix_megno=megno, depth_in=din, depth_out=dout)
+        except N.NativeError as e:      # outside the LDS budget: an error, never a wrong answer
+            assert "LDS" in str(e), e
+            continue
+        x = dev((rng.standard_normal((37, 1, F)) + 0.2 * rng.standard_normal((37, T, F))).astype(np.float32))
+        W = dev((rng.standard_normal((3, plan.d)) * (0.6 / np.sqrt(max(H, 8)))).astype(np.float32))
+        for nz in (False, True):
+            kw = dict(philox_seed=9, draw_id0=3, system_id0=11, plan=plan, noisy=nz, debug=True)
+            ref = ops.forward(x, W, engine="generic", **kw)
+            for image, info in S.candidates(plan.arch, nz):
+                plan.attach_spec(image, nz, info["w8"], info["flags"])
+                for u, v in zip(ref, ops.forward(x, W, engine="spec", **kw)):
+                    assert torch.equal(u, v), (trial, F, H, L, din, dout, megno, hex(mask), T, nz, info)
+                nforms += 1
+    assert nforms >= 24
