@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off validation (GPU): seeded random networks -- widths 1..128, depths 0..3, 41 / 82 features, fix_megno, random column masks,
 random T -- through EVERY candidate form of the specialiser (waves x variant), each against the ahead-of-time generic engine bit for
-bit (quiet and noisy).  usage: python scripts/dev/spec_random_sweep.py [trials]"""
+bit (quiet and noisy).  usage: python scripts/dev/spec_random_sweep.py [trials [seed]]"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from bnn_chaos_model_amd import _native as N, ops, specialize as S  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-rng = np.random.default_rng(4242)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
 nforms = 0
 for trial in range(trials):
