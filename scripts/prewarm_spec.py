@@ -16,7 +16,7 @@ t0 = time.time()
 full = "--bench" in sys.argv
 rows = S.prewarm(TEST_NETS + (BENCH_NETS if full else []), noisy=(False, True), w8=(None, False, True) if full else (None,))
 rows += S.prewarm([(56, 14, 1, 1, 41, False)], noisy=(False,), w8=(False, True))
-rows += S.prewarm([(64, 16, 1, 1, 41, False, 0)], noisy=(False, True), w8=(None,))
+rows += S.prewarm([(64, 16, 1, 1, 41, False, 0), (64, 16, 1, 1, 41, False, 1 << 3)], noisy=(False, True), w8=(None,))
 import test_hip_spec   # noqa: E402  (tests/: the fixture networks with their own masks)
 rows += S.prewarm(test_hip_spec.fixture_archs(), noisy=(False, True), w8=(None,))
 rows += S.prewarm([(24, 6, 1, 1, 41, False)], noisy=(False,), w8=(None,))

@@ -162,7 +162,7 @@ def test_both_wave_forms_and_errors(ops):
         ops.specialize(big, noisy=(False,), w8=True)              # eight waves' pool state does not fit next to that image
 
 
-def test_surface_specialize(tmp_path, ops):
+def test_surface_specialize(tmp_path, ops, monkeypatch):
     """load_swag(...).specialize(): forward_swag_fast / forward replay the reference's fixture through the specialised form."""
     from bnn_chaos_model_amd import checkpoint, spock_reg_model as srm
     z = load_golden("case_arch_h64l16.npz")
@@ -186,6 +186,9 @@ def test_surface_specialize(tmp_path, ops):
     assert m._plan().spec_attached(False) and m._plan().spec_attached(True)
     other = m._plan(zero_mask=0)                       # every plan the model hands out afterwards is specialised the same way
     assert other is not m._plan() and other.spec_attached(False) and other.spec_attached(True)
+    monkeypatch.setenv("BNN_AUTO_SPECIALIZE", "1")     # the same for every model of the process, without touching the script
+    m2 = srm.load_swag(str(p)).eval()
+    assert m2._spec is not None and m2._plan(zero_mask=1 << 3).spec_attached(False)
 
 
 def test_pretrained_network_ragged_T_runs_on_the_embedded_forms(ops, swag_states, inputs):
