@@ -151,6 +151,7 @@ def stream_ptr():
 
 SPEC_POOL_REGS = 1
 SPEC_BLOCK_MAJOR = 2
+SPEC_RESIDENT = 4
 
 
 def _waves_code(w8):

@@ -650,7 +650,8 @@ int bnn_plan_destroy(bnn_plan* pl) {
 
 // the descriptor of one specialised form: the quiet kq-major forms drop the plan's masked input columns from layer 0
 static int spec_arch(const bnn_arch* a, int32_t w8, int32_t noisy, int32_t flags, GenArch* g) {
-    if (flags & ~(BNN_SPEC_POOL_REGS | BNN_SPEC_BLOCK_MAJOR)) return fail(BNN_ERR_INVALID, "unknown specialisation flag");
+    if (flags & ~(BNN_SPEC_POOL_REGS | BNN_SPEC_BLOCK_MAJOR | BNN_SPEC_RESIDENT)) return fail(BNN_ERR_INVALID, "unknown specialisation flag");
+    if ((flags & BNN_SPEC_RESIDENT) && (flags & BNN_SPEC_BLOCK_MAJOR)) return fail(BNN_ERR_INVALID, "BNN_SPEC_RESIDENT belongs to the input-quad-major forms");
     if (noisy != 0 && noisy != 1) return fail(BNN_ERR_INVALID, "noisy must be 0 or 1");
     const char* why = "";
     const uint64_t drop = (noisy || (flags & BNN_SPEC_BLOCK_MAJOR)) ? 0 : a->zero_mask;
@@ -670,8 +671,13 @@ int bnn_spec_source(const bnn_arch* arch, int32_t w8, int32_t noisy, int32_t fla
     GenArch g;
     rc = spec_arch(arch, w8, noisy, flags, &g);
     if (rc) return rc;
+    if (flags & BNN_SPEC_RESIDENT) {   // a few dozen registers at most: beyond that nothing is left for the activations
+        int nw = 0;
+        for (int l = 0; l < g.n_feat; ++l) nw += g.layer[l].nkq * g.layer[l].nblk;
+        if (nw > 112) return fail(BNN_ERR_UNSUPPORTED, "feature_nn's weight registers do not fit next to the activations (more than 112)");
+    }
     return gen_spec_source(g, noisy, (flags & BNN_SPEC_POOL_REGS) ? 1 : 0, (flags & BNN_SPEC_BLOCK_MAJOR) ? 1 : 0,
-                           g.in_live ? arch->zero_mask : 0, buf, cap);
+                           g.in_live ? arch->zero_mask : 0, buf, cap, (flags & BNN_SPEC_RESIDENT) ? 1 : 0);
 }
 
 int bnn_plan_attach_spec(bnn_plan* pl, int32_t noisy, int32_t w8, int32_t flags, const void* image, size_t bytes) {

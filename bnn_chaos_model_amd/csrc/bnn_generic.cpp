@@ -111,13 +111,29 @@ int gen_build_spec(int F, int H, int L, int depth_in, int depth_out, bool megno,
 }
 
 // One form's policy struct + kernel.  tag = "" for a stand-alone (run-time compiled) file, else the suffix of the names in the embedded unit.
-static void spec_form(std::string& s, const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, const char* tag) {
+static void spec_form(std::string& s, const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, const char* tag, int resident = 0) {
     char t[256];
     auto add = [&](const char* fmt, auto... a) { snprintf(t, sizeof t, fmt, a...); s += t; };
     add("namespace bnn {\nstruct SpecArch%s {\n", tag);
     add("    static constexpr bool kq_major = %s;\n", block_major ? "false" : "true");
     add("    static constexpr int n_feat = %d, n_reg = %d;\n", g.n_feat, g.n_reg);
     if (g.nwaves == 16) s += "    static constexpr bool x_late = true;   // four waves per SIMD at 128 registers: no row prefetch\n";
+    if (resident && !block_major) {   // feature_nn's weight registers stay in VGPRs: the layer tables as constexpr functions
+        int nw = 0;
+        for (int l = 0; l < g.n_feat; ++l) nw += g.layer[l].nkq * g.layer[l].nblk;
+        add("    static constexpr int n_wres = %d;   // feature_nn's weight registers, resident across the tiles\n", nw);
+        auto table = [&](const char* name, auto field) {
+            add("    static constexpr int %s(int l) {\n        constexpr int t[] = {", name);
+            for (int l = 0; l < g.n_feat; ++l) add("%d, ", field(g.layer[l]));
+            s += "};\n        return t[l];\n    }\n";
+        };
+        table("nkq", [](const GenLayer& y) { return y.nkq; });
+        table("nblk", [](const GenLayer& y) { return y.nblk; });
+        table("ng_last", [](const GenLayer& y) { return y.ng_last; });
+        table("wreg0", [](const GenLayer& y) { return y.wreg0; });
+        table("bias0", [](const GenLayer& y) { return y.bias0; });
+        table("relu", [](const GenLayer& y) { return y.relu; });
+    }
     add("    static constexpr int pool_lq = %d, lat_nfull = %d;   // Welford state of the pool in registers (0: in LDS)\n", pool_regs ? g.lq : 0,
         4 * (g.layer[g.n_feat - 1].nblk - 1));
     if (g.in_live) {   // layer 0 over the unmasked columns: logical input k -> column live(k) (padding slots repeat column live(0): zero weights)
@@ -160,10 +176,10 @@ static int copy_out(const std::string& s, char* buf, size_t cap) {
     return (int)s.size();
 }
 
-int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, char* buf, size_t cap) {
+int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, char* buf, size_t cap, int resident) {
     std::string s = "// generated by bnn_spec_source (bnn_generic.cpp): the generic forward engine compiled for ONE network -- every shape a constant\n"
                     "#include \"bnn_generic.hip.h\"\n\n";
-    spec_form(s, g, noisy, pool_regs, block_major, drop_mask, "");
+    spec_form(s, g, noisy, pool_regs, block_major, drop_mask, "", resident);
     return copy_out(s, buf, cap);
 }
 

@@ -74,7 +74,7 @@ int gen_build_spec(int n_features, int hidden, int latent, int depth_in, int dep
 
 // Host: the HIP source of that form -- `static constexpr GenArch` + one extern "C" kernel `bnn_spec_forward` around generic_body.
 // Returns the length of the text (without the terminator); writes at most cap bytes.
-int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, char* buf, size_t cap);
+int gen_spec_source(const GenArch& g, int noisy, int pool_regs, int block_major, uint64_t drop_mask, char* buf, size_t cap, int resident = 0);
 // Host: the text of bnn_fwd_v50spec.hip -- the pretrained network's two specialised forms (eight waves, pool in registers; quiet under the
 // pretrained mask, noisy under any) as one translation unit of the library, with their launcher.
 int gen_spec_embedded_source(char* buf, size_t cap);

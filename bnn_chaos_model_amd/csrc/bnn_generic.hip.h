@@ -268,6 +268,50 @@ DEVINL void gen_layer_kq(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLay
     for (int q = 0; q < 4; ++q) out[NQO - 4 + q] = relu_lim4(out[NQO - 4 + q], lim);
 }
 
+// feature_nn layer LI of a specialised form whose weight registers STAY IN VGPRs across the tiles (policies with n_wres > 0: networks
+// whose feature_nn is a few dozen registers, like the pretrained one): wres[] is loaded from the image once per workgroup, and the
+// policy's constexpr tables (nkq(l), nblk(l), ng_last(l), wreg0(l), bias0(l), relu(l)) make every index a compile-time constant.  Same
+// step order as gen_layer_kq -- bias, inputs ascending per output -- without a single LDS read in the layer but the biases.
+template <int NQI, int NQO, class AS, int LI, int NW>
+DEVINL void gen_layer_res(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const float* bimg, const float (&wres)[NW]) {
+    constexpr int nkq = AS::nkq(LI), nblk = AS::nblk(LI), ng = AS::ng_last(LI), wr0 = AS::wreg0(LI);
+    constexpr int in_nfull = LI == 0 ? nkq : 4 * (AS::nblk(LI > 0 ? LI - 1 : 0) - 1), ntail = nkq - in_nfull;
+    constexpr int lim = AS::relu(LI) ? 0 : (int)0x80000000;
+    static_assert(nkq <= NQI && 4 * nblk <= NQO && ntail >= 0 && ntail <= 4 && wr0 + nkq * nblk <= NW, "layer tables");
+    const f32x4* bq = reinterpret_cast<const f32x4*>(bimg + AS::bias0(LI));
+    static_for<nblk - 1>([&](auto NBI) {
+        constexpr int nb = NBI;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[4 * nb + q] = bq[4 * nb + q];
+    });
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[NQO - 4 + q] = bq[4 * (nblk - 1) + q];
+    static_for<nkq>([&](auto S) {
+        constexpr int s_ = S, phys = s_ < in_nfull ? s_ : NQI - 4 + (s_ - in_nfull);
+        static_for<4>([&](auto KK) {
+            constexpr int kk = KK;
+            static_for<nblk - 1>([&](auto NBI) {
+                constexpr int nb = NBI;
+                static_for<4>([&](auto Q) {
+                    constexpr int q = Q;
+                    out[4 * nb + q] = mfma4b<4 * kk + q>(wres[wr0 + s_ * nblk + nb], in[phys][kk], out[4 * nb + q]);
+                });
+            });
+            static_for<ng>([&](auto Q) {
+                constexpr int q = Q;
+                out[NQO - 4 + q] = mfma4b<4 * kk + q>(wres[wr0 + s_ * nblk + nblk - 1], in[phys][kk], out[NQO - 4 + q]);
+            });
+        });
+    });
+    static_for<nblk - 1>([&](auto NBI) {
+        constexpr int nb = NBI;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[4 * nb + q] = relu_lim4(out[4 * nb + q], lim);
+    });
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[NQO - 4 + q] = relu_lim4(out[NQO - 4 + q], lim);
+}
+
 // A regress_nn layer whose registers did not fit the LDS image: block nb's registers are gathered from the flat vector (L2) into the
 // wave's staging area, eight loads in flight, and the layer routine above then runs one block at a time from there.
 DEVINL void gen_stage_block(const GenLayer ly, int nb, const float* __restrict__ We, float* stage, int lane) {
@@ -325,6 +369,12 @@ template <class AS, class = void>
 struct in_compact_of { static constexpr int q = 0; };
 template <class AS>
 struct in_compact_of<AS, std::void_t<decltype(AS::in_q)>> { static constexpr int q = AS::in_q; };
+
+// resident_of<AS>::n: feature_nn weight registers a policy keeps in VGPRs across the tiles (declares n_wres and the layer tables; else 0)
+template <class AS, class = void>
+struct resident_of { static constexpr int n = 0; };
+template <class AS>
+struct resident_of<AS, std::void_t<decltype(AS::n_wres)>> { static constexpr int n = AS::n_wres; };
 
 // x_late_of<AS>::value: the tile's rows are read at the top of the tile instead of a tile ahead (policies that declare x_late)
 template <class AS, class = void>
@@ -428,6 +478,13 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
         }
     }
     __syncthreads();
+    // resident forms: feature_nn's weight registers leave the image once, here
+    constexpr int NWR = resident_of<AS>::n;
+    float wres[NWR > 0 ? NWR : 1];
+    if constexpr (NWR > 0) {
+#pragma unroll
+        for (int R = 0; R < NWR; ++R) wres[R] = wimg[R * 64 + lane];
+    }
 
     const int T = p.T, ntiles = p.ntiles;
     const float nm1 = (float)(T - 1), nT = (float)T;
@@ -592,13 +649,40 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
                     gen_layer_kq<HQ, HQ, true>(in_, out_, G.layer[l_], 4 * (G.layer[l_ - 1].nblk - 1), wimg, bimg, lane, w0, true, &G.layer[l_ + 1 < G.n_feat ? l_ + 1 : 0]);
                 else gen_layer<HQ, HQ, true>(in_, out_, G.layer[l_], 4 * (G.layer[l_ - 1].nblk - 1), wimg, bimg, lane);
             };
-            layer_first(xr, a);
+            if constexpr (NWR > 0) {   // weights in registers: every layer index is a compile-time constant (gen_layer_res)
+                if constexpr (in_compact_of<AS>::q > 0) {
+                    constexpr int CQ = in_compact_of<AS>::q;
+                    f32x4 xc[CQ];
+                    static_for<CQ>([&](auto Q_) {
+                        static_for<4>([&](auto KK) {
+                            constexpr int q_ = Q_, kk = KK, c = AS::live(4 * q_ + kk);
+                            xc[q_][kk] = xr[c >> 2][c & 3];
+                        });
+                    });
+                    gen_layer_res<CQ, HQ, AS, 0>(xc, a, bimg, wres);
+                } else {
+                    gen_layer_res<FQ, HQ, AS, 0>(xr, a, bimg, wres);
+                }
+            } else {
+                layer_first(xr, a);
+            }
             // x of this tile is dead: fetch the next tile's rows into the same registers
             if constexpr (XPREF && !(BNN_GEN_ABLATE & 4)) {
                 const int tn = 4 * (it + 1) + ph0;
                 gen_load_row<FQ, xq_mask_of<AS>::value>(sysp + (int64_t)(tn < T ? tn : T - 1) * F, xr);
                 asm volatile("" ::: "memory");
             }
+            if constexpr (NWR > 0) {
+                static_for<AS::n_feat - 1>([&](auto LI_) {   // ping-pong between the two register arrays; layer l reads a for odd l
+                    constexpr int l_ = LI_ + 1;
+                    if constexpr (l_ % 2 == 1) gen_layer_res<HQ, HQ, AS, l_>(a, b, bimg, wres);
+                    else gen_layer_res<HQ, HQ, AS, l_>(b, a, bimg, wres);
+                });
+                if (tv && !(BNN_GEN_ABLATE & 2)) {
+                    if constexpr (AS::n_feat % 2 == 0) pool(b, rcn);
+                    else pool(a, rcn);
+                }
+            } else {
             // the remaining Linear modules of feature_nn, ping-pong between the two register arrays
             int l = 1;
             for (; l + 1 < G.n_feat; l += 2) {
@@ -611,6 +695,7 @@ DEVINL void generic_body(const GenParams& P, float* lds) {
                 if (BNN_GEN_ABLATE & 2) asm volatile("" :: "v"(b[0]), "v"(b[HQ - 4]));
             } else if (tv) {
                 pool(a, rcn);
+            }
             }
         }
 

@@ -116,7 +116,10 @@ def _move(src, dst):
     os.replace(part, dst)   # atomic: concurrent ranks compiling the same form race to the same bytes
 
 
-VARIANTS = (N.SPEC_POOL_REGS, N.SPEC_BLOCK_MAJOR)   # the candidates per wave count (flags 0 -- input-quad-major layers with the pool in
+VARIANTS = (N.SPEC_POOL_REGS, N.SPEC_BLOCK_MAJOR)   # the candidates per wave count.  Not searched: flags 0 (input-quad-major layers with the
+# pool in LDS rows) never beat POOL_REGS where both compiled; POOL_REGS | RESIDENT (feature_nn's weights in VGPRs across the tiles)
+# ties the streamed form on the pretrained shapes and loses elsewhere (profiles/r04_spec_tuning.jsonl, candidates with flags 5).
+# BNN_SPEC_FORCE_FLAGS=<n> builds any of them. (flags 0 -- input-quad-major layers with the pool in
                                                      # LDS rows -- never beat POOL_REGS where both compiled: BNN_SPEC_FORCE_FLAGS=0 still builds it)
 
 

@@ -92,6 +92,8 @@ int bnn_plan_destroy(bnn_plan* plan);
                                 compiles, looks at the code object's scratch size and falls back (specialize.py does) */
 #define BNN_SPEC_BLOCK_MAJOR 2 /* flags: the ahead-of-time form's block-major layer routine (fewest registers: the widest networks) instead of
                                   the input-quad-major one with its one-step-ahead weight reads */
+#define BNN_SPEC_RESIDENT 4 /* flags: feature_nn's weight registers stay in VGPRs across the tiles (networks of at most 112 such registers,
+                               e.g. the pretrained shapes' 74); LDS layout unchanged */
 int bnn_spec_source(const bnn_arch* arch, int32_t w8, int32_t noisy, int32_t flags, char* buf, size_t cap);
 int bnn_plan_attach_spec(bnn_plan* plan, int32_t noisy, int32_t w8, int32_t flags, const void* image, size_t bytes);
 int bnn_plan_spec_attached(const bnn_plan* plan, int32_t noisy); /* 1 / 0 */

@@ -71,6 +71,11 @@ def test_compile_cache_and_resource_report(N, tmp_path, monkeypatch):
     a = arch(N)
     cands = S.candidates(a, False)                         # every (waves, variant) form the builder accepts, compiled side by side
     assert {(i["w8"], i["flags"]) for _, i in cands} == {(w, f) for w in (True, False) for f in S.VARIANTS}
+    assert "n_wres = " in N.spec_source(a, False, True, N.SPEC_POOL_REGS | N.SPEC_RESIDENT)   # (measured, not searched: weights resident in VGPRs)
+    with pytest.raises(N.NativeError):
+        N.spec_source(arch(N, 80, 20, 1, 1), False, True, N.SPEC_POOL_REGS | N.SPEC_RESIDENT)   # 160 weight registers: not offered
+    with pytest.raises(N.NativeError):
+        N.spec_source(a, False, True, N.SPEC_BLOCK_MAJOR | N.SPEC_RESIDENT)
     image, info = S.best_variant(a, False)                 # no GPU here: the static ranking -- eight waves, pool in registers, no scratch
     assert b"bnn_spec_forward" in image and info["scratch"] == 0 and info["w8"] is True and info["flags"] == N.SPEC_POOL_REGS
     assert 0 < info["vgpr"] <= 256 and 0 < info["lds"] <= 160 * 1024
