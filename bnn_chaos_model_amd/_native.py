@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("BNN_CHAOS_SO") or os.path.join(_HERE, "csrc", "libbnn_chaos_hip.so")  # override: A/B builds
 
 BNN_OK = 0
-ABI_VERSION = 3  # include/bnn_chaos_hip.h: BNN_ABI_VERSION
+ABI_VERSION = 4  # include/bnn_chaos_hip.h: BNN_ABI_VERSION
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_RANGE = -1, -2, -3, -4, -5
 
 
@@ -24,7 +24,8 @@ class BnnArch(C.Structure):
 
 class BnnGrid(C.Structure):
     _fields_ = [("B", C.c_int64), ("T", C.c_int32), ("J", C.c_int32), ("nchunks", C.c_int32),
-                ("systems_per_block", C.c_int32), ("noisy", C.c_int32), ("engine", C.c_int32), ("chunk_B", C.c_int64), ("chunk_off", C.c_int64)]
+                ("systems_per_block", C.c_int32), ("noisy", C.c_int32), ("engine", C.c_int32), ("chunk_B", C.c_int64), ("chunk_off", C.c_int64),
+                ("nonfinite", C.c_void_p)]   # device record of bnn_nonfinite_scan_f32 for this call's x, or NULL = x is assumed finite
 
 
 class BnnStats(C.Structure):
@@ -88,6 +89,10 @@ def lib():
     L.bnn_plan_attach_spec.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t]
     L.bnn_plan_spec_attached.argtypes = [_vp, C.c_int32]
     L.bnn_spec_embedded_source.argtypes = [C.c_char_p, C.c_size_t]
+    L.bnn_gen_params_bytes.restype = C.c_size_t
+    L.bnn_nonfinite_record_bytes.argtypes = [C.c_int64]
+    L.bnn_nonfinite_record_bytes.restype = C.c_size_t
+    L.bnn_nonfinite_scan_f32.argtypes = [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp]
     L.bnn_feature_nn_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, _vp, _vp]
     L.bnn_forward_lowp_f32.argtypes = [_vp, C.POINTER(BnnGrid), _vp, _vp, _vp, C.c_uint64, C.c_int64, C.c_int64, C.c_int32,
                                        _vp, _vp, _vp, _vp]
@@ -127,7 +132,7 @@ EXPORTS = ("bnn_abi_version", "bnn_last_error", "bnn_device_count", "bnn_param_c
            "bnn_moments_f64", "bnn_truncnorm_f32", "bnn_prior_resample_f32", "bnn_regress_f32", "bnn_group_min_f32", "bnn_quantiles_f32", "bnn_feature_pack_f64", "bnn_philox_normal_f32", "bnn_philox_raw_u32",
            "bnn_prior_table_f32", "bnn_stats_draw_f32", "bnn_multiswag_stats_f32", "bnn_sketch_bins", "bnn_sketch_update_u32",
            "bnn_sketch_quantiles_f32", "bnn_forward_lowp_f32", "bnn_multiswag_moments_f64", "bnn_multiswag_bands_f32", "bnn_feature_nn_f32", "bnn_spec_source", "bnn_plan_attach_spec",
-           "bnn_plan_spec_attached", "bnn_spec_embedded_source")
+           "bnn_plan_spec_attached", "bnn_spec_embedded_source", "bnn_gen_params_bytes", "bnn_nonfinite_record_bytes", "bnn_nonfinite_scan_f32")
 
 
 def check(rc):

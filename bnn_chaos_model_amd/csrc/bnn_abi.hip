@@ -88,12 +88,12 @@ __global__ __launch_bounds__(128) void bnn_regress_kernel(RegressParams p) {
     for (int n = 0; n < H; ++n) {
         float acc = w[Y::B4 - Y::W4 + n];
         for (int i = 0; i < SM; ++i) { int k = p.ord[0][i]; acc = fmaf(w[n * SM + k], av[k], acc); }
-        hv[n] = fmaxf(acc, 0.0f);
+        hv[n] = relu_ieee(acc);
     }
     for (int n = 0; n < H; ++n) {
         float acc = w[Y::B5 - Y::W4 + n];
         for (int i = 0; i < H; ++i) { int k = p.ord[1][i]; acc = fmaf(w[Y::W5 - Y::W4 + n * H + k], hv[k], acc); }
-        av[n] = fmaxf(acc, 0.0f);
+        av[n] = relu_ieee(acc);
     }
     float r[2];
     for (int n = 0; n < 2; ++n) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void bnn_regress_generic_kernel(GenRegressParam
             float acc = wj[ly.off_b + n];
             const float* wr = wj + ly.off_w + (int64_t)n * ly.K;
             for (int k = 0; k < ly.K; ++k) acc = fmaf(wr[k], cur[k], acc);
-            nxt[n] = ly.relu ? fmaxf(acc, 0.0f) : acc;
+            nxt[n] = ly.relu ? relu_ieee(acc) : acc;
         }
         float* t = cur; cur = nxt; nxt = t;
     }
@@ -709,6 +709,28 @@ int bnn_plan_spec_attached(const bnn_plan* pl, int32_t noisy) {
     return pl->spec_fn[noisy] ? 1 : 0;
 }
 
+size_t bnn_gen_params_bytes(void) { return sizeof(GenParams); }
+
+size_t bnn_nonfinite_record_bytes(int64_t B) { return sizeof(int32_t) * (size_t)(4 + (B > 0 ? B : 0)); }
+
+int bnn_nonfinite_scan_f32(const bnn_plan* pl, const float* x, int64_t B, int32_t T, void* record, void* stream) {
+    if (!pl) return fail(BNN_ERR_INVALID, "plan is NULL");
+    if (B < 0 || T < 1) return fail(BNN_ERR_INVALID, "bad B/T");
+    if (!record) return fail(BNN_ERR_INVALID, "record is NULL");
+    if (B >= (1LL << 30)) return fail(BNN_ERR_RANGE, "the scan record indexes at most 2^30 systems per call: shard the batch");
+    if (B > 0 && !x) return fail(BNN_ERR_INVALID, "x is NULL");
+    hipError_t e;
+    if (B == 0) e = hipMemsetAsync(record, 0, 4 * sizeof(int32_t), (hipStream_t)stream);
+    else {
+        // a masked column holds NaN after `x - mask` whichever non-finite value it had; fix_megno zeroes the MEGNO column whatever the
+        // mask says (:488-491) and summarises the raw one (:480-484): non-finite there is NaN in the summary either way
+        const uint64_t mask = pl->arch.zero_mask | (pl->megno ? (1ull << MEGNO_COL) : 0ull);
+        e = launch_nonfinite_scan(x, B, (int64_t)T * pl->arch.n_features, pl->arch.n_features, mask, static_cast<int32_t*>(record), (hipStream_t)stream);
+    }
+    if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("non-finite scan: ") + hipGetErrorString(e));
+    return 0;
+}
+
 // natural order of the generic engine: the live inputs ascending (layer 0 drops the masked columns unless `noisy`)
 static int natural_order(const GenArch& g, uint64_t zero_mask, int layer, int noisy, int32_t* host_order, int cap) {
     if (layer < 0 || layer >= g.n_feat + g.n_reg) return fail(BNN_ERR_INVALID, "layer index beyond the network's Linear modules");
@@ -822,42 +844,57 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     if (nblk > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "grid too large; split the draws");
     static_assert(Lay<true>::NF2 * 64 <= FLAT_LDS, "regress_nn fragments overwrite the flat vector in place");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e;
-    if (generic) {
-        GenParams P{};
-        P.f = p;
-        P.g = pl->d_gen;
-        int cnt[4];
-        for (int q = 0; q < 4; ++q) cnt[q] = q < g->T ? (g->T - q + 3) / 4 : 0;   // timesteps t = q, q + 4, ... below T
-        P.m01 = gen_merge_consts(cnt[0], cnt[1]);
-        P.m23 = gen_merge_consts(cnt[2], cnt[3]);
-        P.m0123 = gen_merge_consts(cnt[0] + cnt[1], cnt[2] + cnt[3]);
-        P.noisy = noisy ? 1 : 0;
-        if (spec_emb) {
-            e = launch_fwd_v50spec(noisy, (unsigned)nblk, st, P);
-            if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("embedded specialised forward kernel launch: ") + hipGetErrorString(e));
+    auto launch = [&]() -> int {
+        hipError_t e;
+        if (generic) {
+            GenParams P{};
+            P.f = p;
+            P.g = pl->d_gen;
+            int cnt[4];
+            for (int q = 0; q < 4; ++q) cnt[q] = q < g->T ? (g->T - q + 3) / 4 : 0;   // timesteps t = q, q + 4, ... below T
+            P.m01 = gen_merge_consts(cnt[0], cnt[1]);
+            P.m23 = gen_merge_consts(cnt[2], cnt[3]);
+            P.m0123 = gen_merge_consts(cnt[0] + cnt[1], cnt[2] + cnt[3]);
+            P.noisy = noisy ? 1 : 0;
+            if (spec_emb) {
+                e = launch_fwd_v50spec(noisy, (unsigned)nblk, st, P);
+                if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("embedded specialised forward kernel launch: ") + hipGetErrorString(e));
+                return 0;
+            }
+            if (spec_mod) {
+                size_t psz = sizeof(P);
+                void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &P, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz, HIP_LAUNCH_PARAM_END};
+                e = hipModuleLaunchKernel(pl->spec_fn[noisy ? 1 : 0], (unsigned)nblk, 1, 1, 64u * pl->spec_gen[noisy ? 1 : 0].nwaves, 1, 1, 0, st, nullptr, cfg);
+                if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("specialised forward kernel launch: ") + hipGetErrorString(e));
+                return 0;
+            }
+            e = launch_fwd_generic(pl->gen, (unsigned)nblk, st, P);
+            if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("generic forward kernel launch: ") + hipGetErrorString(e));
             return 0;
         }
-        if (spec_mod) {
-            size_t psz = sizeof(P);
-            void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &P, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz, HIP_LAUNCH_PARAM_END};
-            e = hipModuleLaunchKernel(pl->spec_fn[noisy ? 1 : 0], (unsigned)nblk, 1, 1, 64u * pl->spec_gen[noisy ? 1 : 0].nwaves, 1, 1, 0, st, nullptr, cfg);
-            if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("specialised forward kernel launch: ") + hipGetErrorString(e));
-            return 0;
-        }
-        e = launch_fwd_generic(pl->gen, (unsigned)nblk, st, P);
-        if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("generic forward kernel launch: ") + hipGetErrorString(e));
+        const bool k31 = pl->tab[0].kin4 == 31;
+        if (pl->megno && (lowp || p.sink)) return fail(BNN_ERR_UNSUPPORTED, "fix_megno: the reduced-precision and fused-statistics forms are not built");
+        if (pl->megno) e = launch_fwd_megno(k31, fused, noisy, (unsigned)nblk, st, p);
+        else if (lowp) e = launch_fwd_lowp(lowp, (unsigned)nblk, st, p);
+        else if (p.sink) e = launch_fwd_stats(k31, (unsigned)nblk, st, p);
+        else if (noisy) e = launch_fwd_noisy((unsigned)nblk, st, p);
+        else if (k31) e = launch_fwd_k31(fused, (unsigned)nblk, st, p);
+        else e = launch_fwd_k41(fused, (unsigned)nblk, st, p);
+        if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("forward kernel launch: ") + hipGetErrorString(e));
         return 0;
-    }
-    const bool k31 = pl->tab[0].kin4 == 31;
-    if (pl->megno && (lowp || p.sink)) return fail(BNN_ERR_UNSUPPORTED, "fix_megno: the reduced-precision and fused-statistics forms are not built");
-    if (pl->megno) e = launch_fwd_megno(k31, fused, noisy, (unsigned)nblk, st, p);
-    else if (lowp) e = launch_fwd_lowp(lowp, (unsigned)nblk, st, p);
-    else if (p.sink) e = launch_fwd_stats(k31, (unsigned)nblk, st, p);
-    else if (noisy) e = launch_fwd_noisy((unsigned)nblk, st, p);
-    else if (k31) e = launch_fwd_k31(fused, (unsigned)nblk, st, p);
-    else e = launch_fwd_k41(fused, (unsigned)nblk, st, p);
-    if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("forward kernel launch: ") + hipGetErrorString(e));
+    };
+    int rc = launch();
+    if (rc || !g->nonfinite) return rc;
+    // the systems the scan listed (non-finite inputs) are re-evaluated the reference's way and overwrite what the kernel above wrote for
+    // them (bnn_nonfinite.hip); with an empty list the launch leaves at once
+    NfxParams q{};
+    q.f = p;
+    q.g = pl->d_gen;
+    q.rec = static_cast<const int32_t*>(g->nonfinite);
+    q.noisy = noisy ? 1 : 0;
+    q.shortcut = (p.summary || p.latents) ? 0 : 1;
+    hipError_t e = launch_nonfinite_fixup(pl->gen, q, st);
+    if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("non-finite fix-up kernel launch: ") + hipGetErrorString(e));
     return 0;
 }
 
@@ -1053,11 +1090,7 @@ int bnn_quantiles_f32(const float* samples, int64_t R, int64_t B, const double* 
     }
     int npad = 2;
     while (npad < R) npad <<= 1;
-    static bool attr_set[MAX_DEVICES];
-    if (!attr_set[current_device_slot()]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_quantiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_set[current_device_slot()] = true;
-    }
+    allow_big_lds<&bnn_quantiles_kernel>();
     if (2 * B > 0x7fffffffLL) return fail(BNN_ERR_RANGE, "too many systems for one launch");
     hipLaunchKernelGGL(bnn_quantiles_kernel, dim3((unsigned)(2 * B)), dim3(256), (size_t)npad * sizeof(float), (hipStream_t)stream, samples, R,
                        B, npad, qp, out);

@@ -189,6 +189,19 @@ DEVINL f32x4 relu4(f32x4 v) {
     return o;
 }
 
+// nn.ReLU with torch.relu's treatment of non-finite values: NaN is not <= 0 and stays NaN (whatever its sign bit -- the integer max
+// above turns a NaN with the sign bit set into 0), -inf becomes 0, +inf stays.  Two instructions instead of one: used where the count
+// does not matter and a non-finite value can arise from FINITE inputs -- regress_nn, behind a pool whose variance overflowed (the
+// reference returns NaN there, tests/golden/make_golden_nonfinite.py system 19).  Finite values: the same bits as relu1.
+DEVINL float relu_ieee(float v) { return v <= 0.0f ? 0.0f : v; }
+template <int NLIVE = 4>
+DEVINL f32x4 relu4_ieee(f32x4 v) {
+    f32x4 o = v;
+#pragma unroll
+    for (int i = 0; i < NLIVE; ++i) o[i] = relu_ieee(v[i]);
+    return o;
+}
+
 template <int CTRL>
 DEVINL float quad_perm(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
@@ -248,7 +261,7 @@ DEVINL f32x4 regress16(const float (&skeep)[Lay<MEGNO>::NK4], const float* f2fra
     for (int ks = 0; ks < Y::NK4; ++ks)
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) a4[mt] = mfma(W2f(Y::F_L4 + ks * 3 + mt), skeep[ks], a4[mt]);
-    a4[0] = relu4(a4[0]); a4[1] = relu4(a4[1]); a4[2] = relu4<2>(a4[2]);
+    a4[0] = relu4_ieee(a4[0]); a4[1] = relu4_ieee(a4[1]); a4[2] = relu4_ieee<2>(a4[2]);
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
         a5[mt] = (f32x4){W2f(Y::F_B5 + mt * 4), W2f(Y::F_B5 + 1 + mt * 4), W2f(Y::F_B5 + 2 + mt * 4), W2f(Y::F_B5 + 3 + mt * 4)};
@@ -256,7 +269,7 @@ DEVINL f32x4 regress16(const float (&skeep)[Lay<MEGNO>::NK4], const float* f2fra
     for (int ks = 0; ks < NKH; ++ks)
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) a5[mt] = mfma(W2f(Y::F_L5 + ks * 3 + mt), a4[ks >> 2][ks & 3], a5[mt]);
-    a5[0] = relu4(a5[0]); a5[1] = relu4(a5[1]); a5[2] = relu4<2>(a5[2]);
+    a5[0] = relu4_ieee(a5[0]); a5[1] = relu4_ieee(a5[1]); a5[2] = relu4_ieee<2>(a5[2]);
     a6 = (f32x4){W2f(Y::F_B6), W2f(Y::F_B6 + 1), W2f(Y::F_B6 + 2), W2f(Y::F_B6 + 3)};
 #pragma unroll
     for (int ks = 0; ks < NKH; ++ks) a6 = mfma(W2f(Y::F_L6 + ks), a5[ks >> 2][ks & 3], a6);

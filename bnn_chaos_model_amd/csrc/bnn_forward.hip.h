@@ -505,13 +505,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
 
 template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false, bool XNOISE = false>
 inline hipError_t launch_forward_form(unsigned nblk, hipStream_t st, const FwdParams& p) {
-    static bool attr_set[MAX_DEVICES];  // the attribute belongs to the (function, device) pair
-    const int slot = current_device_slot();
-    if (!attr_set[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO, XNOISE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[slot] = true;
-    }
+    allow_big_lds<&bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO, XNOISE>>();   // once per (function, device), thread-safe
     hipLaunchKernelGGL((bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO, XNOISE>), dim3(nblk), dim3(256), fwd_lds_bytes<KIN>(), st, p);
     return hipGetLastError();
 }

@@ -65,6 +65,19 @@ DEVINL f32x4 relu_lim4(f32x4 v, int lim) {
     for (int i = 0; i < 4; ++i) o[i] = relu_lim1(v[i], lim);
     return o;
 }
+// regress_nn (once per 16 systems): torch.relu's treatment of non-finite values (relu_ieee, bnn_common.hip.h) -- a pool that overflowed on
+// finite inputs hands regress_nn inf / NaN, and the reference's answer is NaN.  IEEE = false: feature_nn's hot loop, one v_max_i32.
+template <bool IEEE>
+DEVINL f32x4 relu_sel4(f32x4 v, int lim) {
+    if constexpr (IEEE) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = lim == 0 ? relu_ieee(v[i]) : v[i];
+        return o;
+    } else {
+        return relu_lim4(v, lim);
+    }
+}
 
 // Register layout of an activation vector (so that every array index is a compile-time constant AND no select is ever needed):
 // a layer writes its FULL output blocks (16 neurons = 4 quads each) to quads 4 nb .. 4 nb + 3 and its LAST block -- whatever its index,
@@ -75,7 +88,7 @@ DEVINL f32x4 relu_lim4(f32x4 v, int lim) {
 // One output block: 4 kk x NG MFMAs per input quad -- input 4 kq + kk into neuron group q (bias first, then inputs ascending) --
 // accumulating straight into the block's output registers out[BASE .. BASE + 3].  The weight registers are requested a chunk of up to 16
 // at a time (one ds_read_b32 each, all of a chunk in flight together).
-template <int NG, int BASE, int NQI, int NQO>
+template <int NG, int BASE, bool IEEE, int NQI, int NQO>
 DEVINL void gen_block(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], int in_nfull, int ntail, const float* wp, const f32x4* bq, int lim) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) out[BASE + q] = bq[q];
@@ -118,7 +131,7 @@ DEVINL void gen_block(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], int in_nfull, i
         return true;
     });
 #pragma unroll
-    for (int q = 0; q < 4; ++q) out[BASE + q] = relu_lim4(out[BASE + q], lim);
+    for (int q = 0; q < 4; ++q) out[BASE + q] = relu_sel4<IEEE>(out[BASE + q], lim);
 }
 
 // One Linear (+ ReLU) for the wave's 64 rows; weight register (nb, kq) = LDS image entry [(wreg0 + nb * nkq + kq) * 64 + lane].
@@ -146,16 +159,16 @@ DEVINL void gen_layer(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLayer 
     static_while<NQO / 4 - 1>([&](auto NB) {   // the full blocks, at their natural quads
         constexpr int nb = NB;
         if (nb >= nblk - 1) return false;
-        gen_block<4, 4 * nb>(in, out, in_nfull, ntail, wsrc(nb), bq + 4 * nb, lim);
+        gen_block<4, 4 * nb, !TRIM>(in, out, in_nfull, ntail, wsrc(nb), bq + 4 * nb, lim);
         return true;
     });
     const float* wl = wsrc(nblk - 1);          // the last block, at the array's last four quads
     const f32x4* bl = bq + 4 * (nblk - 1);
     const int ng = TRIM ? ly.ng_last : 4;
-    if (ng == 4) gen_block<4, NQO - 4>(in, out, in_nfull, ntail, wl, bl, lim);
-    else if (ng == 3) gen_block<3, NQO - 4>(in, out, in_nfull, ntail, wl, bl, lim);
-    else if (ng == 2) gen_block<2, NQO - 4>(in, out, in_nfull, ntail, wl, bl, lim);
-    else gen_block<1, NQO - 4>(in, out, in_nfull, ntail, wl, bl, lim);
+    if (ng == 4) gen_block<4, NQO - 4, !TRIM>(in, out, in_nfull, ntail, wl, bl, lim);
+    else if (ng == 3) gen_block<3, NQO - 4, !TRIM>(in, out, in_nfull, ntail, wl, bl, lim);
+    else if (ng == 2) gen_block<2, NQO - 4, !TRIM>(in, out, in_nfull, ntail, wl, bl, lim);
+    else gen_block<1, NQO - 4, !TRIM>(in, out, in_nfull, ntail, wl, bl, lim);
 }
 
 // The same Linear, INPUT-QUAD-MAJOR (the specialised forms: every count below is a compile-time constant there, the early exits fold
@@ -261,11 +274,11 @@ DEVINL void gen_layer_kq(const f32x4 (&in)[NQI], f32x4 (&out)[NQO], const GenLay
         constexpr int nb = NBI;
         if (nb >= nblk - 1) return false;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) out[4 * nb + q] = relu_lim4(out[4 * nb + q], lim);
+        for (int q = 0; q < 4; ++q) out[4 * nb + q] = relu_sel4<!TRIM>(out[4 * nb + q], lim);
         return true;
     });
 #pragma unroll
-    for (int q = 0; q < 4; ++q) out[NQO - 4 + q] = relu_lim4(out[NQO - 4 + q], lim);
+    for (int q = 0; q < 4; ++q) out[NQO - 4 + q] = relu_sel4<!TRIM>(out[NQO - 4 + q], lim);
 }
 
 // feature_nn layer LI of a specialised form whose weight registers STAY IN VGPRs across the tiles (policies with n_wres > 0: networks
@@ -860,13 +873,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void bnn_forward_generic_kernel(
 
 template <int FQ, int HQ, bool W8>
 inline hipError_t launch_generic_form(unsigned nblk, hipStream_t st, const GenParams& P, int nwaves, size_t lds_bytes) {
-    static bool attr_set[MAX_DEVICES];  // the attribute belongs to the (function, device) pair
-    const int slot = current_device_slot();
-    if (!attr_set[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_generic_kernel<FQ, HQ, W8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set[slot] = true;
-    }
+    allow_big_lds<&bnn_forward_generic_kernel<FQ, HQ, W8>>();   // once per (function, device), thread-safe
     hipLaunchKernelGGL((bnn_forward_generic_kernel<FQ, HQ, W8>), dim3(nblk), dim3(64 * nwaves), lds_bytes, st, P);
     return hipGetLastError();
 }

@@ -8,11 +8,14 @@
 //   bnn_fwd_lowp.hip    reduced-precision forward kernels (bf16 / half matrix pipe; opt-in, configs[4])
 //   bnn_fwd_generic.hip, bnn_fwd_generic82.hip   generic forward engine: the network built from hparams (any hidden / latent / depth; 41 resp. 82 features), any T
 //   bnn_generic.cpp     host: descriptor of that engine (layers, LDS image, register bucket)
+//   bnn_nonfinite.hip   non-finite inputs the reference's way: the once-per-call scan of x and the exact re-evaluation of the listed systems
 //   bnn_abi.hip         extern "C" entry points of include/bnn_chaos_hip.h + the small kernels (SWAG draw, moments, regress_nn,
 //                       statistics epilogue, feature packing, Philox fills)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <mutex>
 
 #include "bnn_generic.h"
 #include "bnn_layout.h"
@@ -76,6 +79,17 @@ struct GenParams {
     int32_t noisy;              // forward(noisy_val=True): input + summary noise, masked columns keep their weights
 };
 
+// exact re-evaluation of the systems a non-finite scan listed (bnn_nonfinite.hip): the forward's own parameter block (inputs, noise,
+// outputs, chunk geometry) + the plan's descriptor + the scan record
+struct NfxParams {
+    FwdParams f;
+    const GenArch* g;       // the plan's ahead-of-time descriptor (every column, every layer at its natural shape)
+    const int32_t* rec;     // [0] = listed systems, [1] = of which certainly NaN, [4 + i] = (system << 1) | certain
+    int32_t noisy;          // forward(noisy_val=True)
+    int32_t shortcut;       // 1: "certainly NaN" systems are answered without the evaluation (no summary / latents output was asked for)
+    int32_t maxw;           // widest activation vector of feature_nn (incl. the input row): LDS rows of the kernel
+};
+
 constexpr int RCP_N = 4096;  // supports T up to 16384 timesteps
 
 // Each returns hipGetLastError() after the launch.  grid = (draw, block-of-systems) pairs, 256 threads.
@@ -89,11 +103,25 @@ hipError_t launch_fwd_megno(bool k31, bool fused, bool noisy, unsigned nblk, hip
 hipError_t launch_fwd_generic(const GenArch& g, unsigned nblk, hipStream_t st, const GenParams& P);  // any hparams network, any T >= 2
 hipError_t launch_fwd_v50spec(bool noisy, unsigned nblk, hipStream_t st, const GenParams& P);          // the pretrained network's specialised forms (generated unit)
 
+// bnn_nonfinite.hip: rec = the caller's record (int32 [4 + B]); per = T * n_features floats per system
+hipError_t launch_nonfinite_scan(const float* x, int64_t B, int64_t per, int F, uint64_t zero_mask, int32_t* rec, hipStream_t st);
+hipError_t launch_nonfinite_fixup(const GenArch& g, NfxParams& q, hipStream_t st);
+
 constexpr int MAX_DEVICES = 64;
 inline int current_device_slot() {
     int dev = 0;
     (void)hipGetDevice(&dev);
     return (dev >= 0 && dev < MAX_DEVICES) ? dev : 0;
+}
+
+// Kernels that take more than 64 KB of dynamic LDS need the attribute set once per (function, device): call this in front of the launch.
+// (std::call_once: concurrent first launches from several host threads are safe.)
+template <auto Kernel>
+inline void allow_big_lds() {
+    static std::once_flag once[MAX_DEVICES];
+    std::call_once(once[current_device_slot()], [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
 }
 
 }  // namespace bnn

@@ -504,13 +504,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_lowp_kernel(const FwdParam
 
 template <int NS, bool H>
 inline hipError_t launch_lowp_form(unsigned nblk, hipStream_t st, const FwdParams& p) {
-    static bool attr_set[MAX_DEVICES];
-    const int slot = current_device_slot();
-    if (!attr_set[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bnn_forward_lowp_kernel<NS, H>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set[slot] = true;
-    }
+    allow_big_lds<&bnn_forward_lowp_kernel<NS, H>>();   // once per (function, device), thread-safe
     hipLaunchKernelGGL((bnn_forward_lowp_kernel<NS, H>), dim3(nblk), dim3(256), lowp_lds_bytes(), st, p);
     return hipGetLastError();
 }

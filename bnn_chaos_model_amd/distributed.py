@@ -95,7 +95,7 @@ class MultiSwagSharded:
         self.devset = None
         if devices is not None:
             from .multidevice import DeviceSet
-            self.devset = DeviceSet(None if devices == "all" else devices)
+            self.devset = DeviceSet(devices)
         self.plan = None if self.devset else self._plan_on(None)
         self.group = group
         self.draws_per_launch = int(draws_per_launch)
@@ -121,9 +121,10 @@ class MultiSwagSharded:
         if x.shape[0] != B_total:
             raise ValueError("with devices=..., x is the WHOLE batch")
         states = ds.replicate("state", self.state)
+        xs = ds.stage(x, group=group)    # every device's rows on their way before the first launch (pinned / threaded: multidevice.py)
 
         def shard(i, dev, lo, hi):
-            return per_shard(x[lo:hi].detach().to(dev, torch.float32).contiguous(), states[i], self._plan_on(dev), lo)
+            return per_shard(xs[i], states[i], self._plan_on(dev), lo)
 
         return ds.gather_rows(ds.run(B_total, shard, group=group))
 

@@ -100,10 +100,38 @@ def _f32(t, name):
 ENGINES = {"auto": 0, "generic": 1, "spec": 2}
 
 
-def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto", chunk_B=0, chunk_off=0):
+def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto", chunk_B=0, chunk_off=0, nonfinite=None):
     """chunk_B / chunk_off: the batch is sharded over devices and this call holds rows [chunk_off, chunk_off + B) of its chunk_B
-    systems; the draws' chunks (torch.chunk) partition the whole batch (bnn_grid in include/bnn_chaos_hip.h)."""
-    return N.BnnGrid(int(B), int(T), int(J), int(nchunks), int(spb), int(bool(noisy)), ENGINES[engine], int(chunk_B or 0), int(chunk_off))
+    systems; the draws' chunks (torch.chunk) partition the whole batch (bnn_grid in include/bnn_chaos_hip.h).
+    nonfinite: the scan record of this call's x (nonfinite_scan) or None = x is assumed finite."""
+    g = N.BnnGrid(int(B), int(T), int(J), int(nchunks), int(spb), int(bool(noisy)), ENGINES[engine], int(chunk_B or 0), int(chunk_off),
+                  None if nonfinite is None else nonfinite.data_ptr())
+    g._keepalive = nonfinite
+    return g
+
+
+@_on_device_of(0)
+def nonfinite_scan(x, plan=None):
+    """One streaming pass over x [B,T,F] -> the record (int32 [4 + B], on x's device) of the systems that hold NaN / +-inf anywhere:
+    [0] = how many, [1] = of which certainly NaN whatever the weights (a NaN anywhere, or +-inf in a masked column: the reference's
+    `x - mask`, spock_reg_model.py:452-478), [4 + i] = (system << 1) | certain.  Hand it to any op below as `nonfinite=` -- the listed
+    systems then get what the reference returns (NaN, or the exact IEEE evaluation where an infinity dies in a ReLU) -- or let the op
+    make it (the default; `assume_finite=True` skips it).  The record can serve any number of calls on the same x."""
+    plan = plan or get_plan()
+    x = _f32(x, "x")
+    _check_x(x, plan)
+    B, T, _ = x.shape
+    rec = torch.empty((4 + B,), dtype=torch.int32, device=x.device)
+    N.check(N.lib().bnn_nonfinite_scan_f32(plan.handle, N.ptr(x), B, T, N.ptr(rec), N.stream_ptr()))
+    return rec
+
+
+def _nonfinite_record(x, plan, assume_finite, nonfinite):
+    if nonfinite is not None:
+        if nonfinite.dtype != torch.int32 or nonfinite.numel() != 4 + x.shape[0] or nonfinite.device != x.device or not nonfinite.is_contiguous():
+            raise ValueError(f"nonfinite must be the int32 record [4 + {x.shape[0]}] of nonfinite_scan(x) on x's device")
+        return nonfinite
+    return None if assume_finite else nonfinite_scan(x, plan)
 
 
 @_on_device_of(0)
@@ -144,8 +172,13 @@ def half_range_exceeded(x, zero_mask=V50_ZERO_MASK):
 
 @_on_device_of(0)
 def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0, draw_id0=0, system_id0=0, plan=None,
-            debug=False, systems_per_block=0, noisy=False, precision="f32", engine="auto", chunk_B=0, chunk_off=0):
+            debug=False, systems_per_block=0, noisy=False, precision="f32", engine="auto", chunk_B=0, chunk_off=0, assume_finite=False,
+            nonfinite=None):
     """VarModel.forward (spock_reg_model.py:486-528) for materialised weight vectors W[J,d] -> out[J/nchunks,B,2].
+
+    Non-finite inputs: by default x is scanned once (nonfinite_scan: one streaming pass) and the systems holding NaN / +-inf get the
+    reference's result (`x - mask`, :452-478; NaN-propagating nn.ReLU); assume_finite=True skips the scan (x is known to be clean:
+    the kernels alone are exact on finite data only), nonfinite= takes a record made earlier for the same x.
 
     eps [R,B,2,20] = the two randn_like of compute_summary_stats (:426-427) or None (Philox);
     eps_in [R,B,T,41] + eps_sum [R,B,40] switch on noisy_val=True (:444-450); noisy=True with no noise tensors at all
@@ -179,7 +212,7 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
     out = torch.empty((R, B, 2), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, SM), dtype=torch.float32, device=x.device) if debug else None
-    g = _grid(B, T, J, nchunks, systems_per_block, noisy, engine, chunk_B, chunk_off)
+    g = _grid(B, T, J, nchunks, systems_per_block, noisy, engine, chunk_B, chunk_off, _nonfinite_record(x, plan, assume_finite, nonfinite))
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
     if precision != "f32":
@@ -195,7 +228,7 @@ def forward(x, W, eps=None, eps_in=None, eps_sum=None, nchunks=1, philox_seed=0,
 
 
 @_on_device_of(0)
-def feature_latents(x, W, eps_in=None, noisy=False, philox_seed=0, draw_id0=0, system_id0=0, plan=None):
+def feature_latents(x, W, eps_in=None, noisy=False, philox_seed=0, draw_id0=0, system_id0=0, plan=None, assume_finite=False, nonfinite=None):
     """feature_nn alone -> the per-timestep latents [J, B, T, latent] that compute_summary_stats leaves in self.latents
     (spock_reg_model.py:417, 433): masks applied, optional input noise (explicit eps_in [J,B,T,F], or noisy=True for in-kernel Philox)."""
     plan = plan or get_plan()
@@ -208,7 +241,7 @@ def feature_latents(x, W, eps_in=None, noisy=False, philox_seed=0, draw_id0=0, s
     if eps_in is not None and tuple(eps_in.shape) != (J, B, T, NF):
         raise ValueError(f"eps_in must be [{J},{B},{T},{NF}]")
     lat = torch.empty((J, B, T, plan.latent), dtype=torch.float32, device=x.device)
-    g = _grid(B, T, J, 1, 0, noisy)
+    g = _grid(B, T, J, 1, 0, noisy, nonfinite=_nonfinite_record(x, plan, assume_finite, nonfinite))
     N.check(N.lib().bnn_feature_nn_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(W), N.ptr(eps_in), int(philox_seed), int(draw_id0), int(system_id0),
                                        N.ptr(lat), N.stream_ptr()))
     return lat
@@ -246,18 +279,20 @@ def _workspace(J, d, device):
 @_on_device_of(0)
 def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nchunks=1, scale=0.5, philox_seed=0,
               draw_id0=0, system_id0=0, plan=None, debug=False, systems_per_block=0, out=None, single_launch=None, precision="f32",
-              engine="auto", chunk_B=0, chunk_off=0):
+              engine="auto", chunk_B=0, chunk_off=0, assume_finite=False, nonfinite=None):
     """Fused SWAGModel.forward_swag_fast (spock_reg_model.py:878-908) over the MC loop of
     figures/multiswag_5_planet.py:295-298 -> out[J/nchunks, B, 2].
 
     single_launch: True = every workgroup samples its draw in its prologue (no scratch memory); False = draws are
     sampled once into a [J,d] workspace allocated for this call and read by the forward kernel of the same call (same
-    bits, faster when a draw serves many workgroups).  None = choose by chunk size."""
+    bits, faster when a draw serves many workgroups).  None = choose by chunk size.
+    assume_finite / nonfinite: see forward()."""
     plan = plan or get_plan()
     if precision != "f32":  # opt-in reduced precision: exact fp32 draw, then the bf16-pipe forward (same noise streams)
         W = swag_draw(w_avg, w2_avg, pre_D, seed_idx, z1, z2, scale=scale, philox_seed=philox_seed, draw_id0=draw_id0, plan=plan)
         res = forward(x, W, eps=eps, nchunks=nchunks, philox_seed=philox_seed, draw_id0=draw_id0, system_id0=system_id0, plan=plan,
-                      debug=debug, systems_per_block=systems_per_block, precision=precision, chunk_B=chunk_B, chunk_off=chunk_off)
+                      debug=debug, systems_per_block=systems_per_block, precision=precision, chunk_B=chunk_B, chunk_off=chunk_off,
+                      assume_finite=assume_finite, nonfinite=nonfinite)
         if out is not None and not debug:
             out.copy_(res)
             return out
@@ -284,7 +319,8 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
         raise ValueError("out has the wrong shape/dtype")
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, plan.summary_width), dtype=torch.float32, device=x.device) if debug else None
-    g = _grid(B, T, J, nchunks, systems_per_block, engine=engine, chunk_B=chunk_B, chunk_off=chunk_off)
+    g = _grid(B, T, J, nchunks, systems_per_block, engine=engine, chunk_B=chunk_B, chunk_off=chunk_off,
+              nonfinite=_nonfinite_record(x, plan, assume_finite, nonfinite))
     if not fused_draw_available(plan, T, K) or engine != "auto":
         if single_launch:
             raise NotImplementedError("single_launch (in-prologue draw) exists for the pretrained network at T % 4 == 0, K <= 32 only")
@@ -419,7 +455,8 @@ def stats_draw(musd, st=None, philox_seed=0, row_id0=0, system_id0=0):
 
 @_on_device_of(0)
 def multiswag_stats(x, w_avg, w2_avg, pre_D, seed_idx, st=None, z1=None, z2=None, eps=None, nchunks=1, scale=0.5, philox_seed=0,
-                    draw_id0=0, system_id0=0, plan=None, systems_per_block=0, out=None, chunk_B=0, chunk_off=0):
+                    draw_id0=0, system_id0=0, plan=None, systems_per_block=0, out=None, chunk_B=0, chunk_off=0, assume_finite=False,
+                    nonfinite=None):
     """multiswag with the statistics epilogue fused into the kernel's tail -> t [J/nchunks, B]: (mu, std) never reach memory.
     Bit-identical to stats_draw(multiswag(...), row_id0=draw_id0 // nchunks, system_id0=system_id0)."""
     plan = plan or get_plan()
@@ -442,7 +479,7 @@ def multiswag_stats(x, w_avg, w2_avg, pre_D, seed_idx, st=None, z1=None, z2=None
         out = torch.empty((R, B), dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != (R, B) or out.dtype != torch.float32 or not out.is_contiguous():
         raise ValueError("out has the wrong shape/dtype")
-    g = _grid(B, T, J, nchunks, systems_per_block, chunk_B=chunk_B, chunk_off=chunk_off)
+    g = _grid(B, T, J, nchunks, systems_per_block, chunk_B=chunk_B, chunk_off=chunk_off, nonfinite=_nonfinite_record(x, plan, assume_finite, nonfinite))
     ws = _workspace(max(J, 1), d, x.device)
     N.check(N.lib().bnn_multiswag_stats_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
                                             N.ptr(seed_idx), N.ptr(z1), N.ptr(z2), N.ptr(eps), float(scale), int(philox_seed),
@@ -525,7 +562,7 @@ def _slab_common(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, draws_per_launch, d
 
 @_on_device_of(0)
 def multiswag_moments(x, w_avg, w2_avg, pre_D, seed_idx, nchunks=1, scale=0.5, philox_seed=0, draw_id0=0, system_id0=0,
-                      draws_per_launch=256, plan=None, chunk_B=0, chunk_off=0):
+                      draws_per_launch=256, plan=None, chunk_B=0, chunk_off=0, assume_finite=False, nonfinite=None):
     """Predictive moments of the whole grid -> float64 [B,4] (sum mu, sum mu^2, sum std, sum std^2 over the output rows), the
     draws evaluated `draws_per_launch` at a time inside ONE native call (bnn_multiswag_moments_f64): [J,B,2] never exists."""
     plan, x, w_avg, w2_avg, pre_D, S, d, K, seed_idx, J, dpl = _slab_common(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, draws_per_launch, draw_id0, plan)
@@ -533,7 +570,7 @@ def multiswag_moments(x, w_avg, w2_avg, pre_D, seed_idx, nchunks=1, scale=0.5, p
     mom = torch.empty((B, 4), dtype=torch.float64, device=x.device)
     ws = _workspace(dpl, d, x.device)
     outw = torch.empty((dpl // nchunks, B, 2), dtype=torch.float32, device=x.device)
-    g = _grid(B, T, J, nchunks, 0, chunk_B=chunk_B, chunk_off=chunk_off)
+    g = _grid(B, T, J, nchunks, 0, chunk_B=chunk_B, chunk_off=chunk_off, nonfinite=_nonfinite_record(x, plan, assume_finite, nonfinite))   # ONE scan for all slabs
     N.check(N.lib().bnn_multiswag_moments_f64(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
                                               N.ptr(seed_idx), float(scale), int(philox_seed), int(draw_id0), int(system_id0), dpl,
                                               N.ptr(ws), N.ptr(outw), N.ptr(mom), N.stream_ptr()))
@@ -544,7 +581,7 @@ def multiswag_moments(x, w_avg, w2_avg, pre_D, seed_idx, nchunks=1, scale=0.5, p
 
 @_on_device_of(0)
 def multiswag_bands(x, w_avg, w2_avg, pre_D, seed_idx, sketch, st=None, nchunks=1, scale=0.5, philox_seed=0, draw_id0=0,
-                    system_id0=0, draws_per_launch=256, plan=None, chunk_B=0, chunk_off=0):
+                    system_id0=0, draws_per_launch=256, plan=None, chunk_B=0, chunk_off=0, assume_finite=False, nonfinite=None):
     """The whole grid streamed into `sketch` (a QuantileSketch over x's systems) inside ONE native call
     (bnn_multiswag_bands_f32): statistics epilogue in the forward tail, min over the sketch's group, histogram update."""
     plan, x, w_avg, w2_avg, pre_D, S, d, K, seed_idx, J, dpl = _slab_common(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, draws_per_launch, draw_id0, plan)
@@ -554,7 +591,7 @@ def multiswag_bands(x, w_avg, w2_avg, pre_D, seed_idx, sketch, st=None, nchunks=
     st = st or stats_params(device=x.device)
     ws = _workspace(dpl, d, x.device)
     tw = torch.empty((dpl // nchunks, B), dtype=torch.float32, device=x.device)
-    g = _grid(B, T, J, nchunks, 0, chunk_B=chunk_B, chunk_off=chunk_off)
+    g = _grid(B, T, J, nchunks, 0, chunk_B=chunk_B, chunk_off=chunk_off, nonfinite=_nonfinite_record(x, plan, assume_finite, nonfinite))
     N.check(N.lib().bnn_multiswag_bands_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
                                             N.ptr(seed_idx), float(scale), int(philox_seed), int(draw_id0), int(system_id0), dpl,
                                             N.ptr(ws), N.ptr(tw), C.byref(st), sketch.group, C.byref(sketch.spec), N.ptr(sketch.hist),

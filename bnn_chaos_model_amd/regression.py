@@ -34,13 +34,52 @@ def pack_features(tseries, mass, ssX=None):
     return ops.feature_pack(tseries, mass, mean=ssX.mean_, scale=ssX.scale_)
 
 
+def draw_reference_noise(samples, parts, S, d, K, latent, noise_dev, eps_dev):
+    """The generator draws of the scripts' MC loop (figures/multiswag_5_planet.py:295-298 around regression.py:74-92), in the
+    reference's order, for `samples` x len(parts) calls of sample_full_swag: per call np.random.randint(0, S) (regression.py:78),
+    randn((1, d)), randn((K, 1)) (spock_reg_model.py:830-831) and the two randn_like of the chunk's [n, latent] pool
+    (:426-427).  Every draw lands in its row of a preallocated tensor (normal_() on a contiguous view: the same generator consumption as a
+    fresh tensor of that shape, no temporary, no per-draw copy) -> seed_idx [J] int32 (numpy), z1 [J, d], z2 [J, K] on noise_dev,
+    eps [samples, 2, B, latent] on eps_dev -- kind-major, so that a chunk's rows are one contiguous block; the kernels take
+    eps.permute(0, 2, 1, 3)."""
+    nch = len(parts)
+    J = samples * nch
+    B = sum(len(pp) for pp in parts)
+    seed_idx = np.empty(J, np.int32)
+    z1 = torch.empty((J, 1, d), device=noise_dev)
+    z2 = torch.empty((J, K, 1), device=noise_dev)
+    eps = torch.empty((samples, 2, B, latent), device=eps_dev)
+    # views made once (one unbind / narrow each), filled with Tensor.normal_() -- what torch.randn(shape) is underneath: an empty tensor
+    # of that shape + normal_() -- so the generator is consumed exactly as by the reference's calls
+    z1v, z2v = z1.unbind(0), z2.unbind(0)
+    lo, ev = 0, []
+    for pp in parts:
+        ev.append([(eps[s_, 0, lo:lo + len(pp)], eps[s_, 1, lo:lo + len(pp)]) for s_ in range(samples)])
+        lo += len(pp)
+    randint = np.random.randint
+    for e in range(J):
+        s_, c_ = divmod(e, nch)
+        seed_idx[e] = randint(0, S)                                     # regression.py:78
+        z1v[e].normal_()                                                # spock_reg_model.py:830  randn((1, d))
+        z2v[e].normal_()                                                # :831                    randn((K, 1))
+        e1, e2 = ev[c_][s_]
+        e1.normal_()                                                    # :426  randn_like([n, latent])
+        e2.normal_()                                                    # :427
+    return seed_idx, z1.view(J, d), z2.view(J, K), eps
+
+
 class FeatureRegressor(object):
-    def __init__(self, cuda=False, filebase="long_zero_megno_with_angles_power_v14_*_output.pkl", sort=False):
+    def __init__(self, cuda=False, filebase="long_zero_megno_with_angles_power_v14_*_output.pkl", sort=False, devices=None):
         """filebase is resolved like the reference (relative to this file's directory + '/../'); absolute globs work too.
-        The reference's ensemble order is the unsorted glob order (regression.py:45); sort=True makes it deterministic."""
+        The reference's ensemble order is the unsorted glob order (regression.py:45); sort=True makes it deterministic.
+        devices (not in the reference): the GPUs the batched drivers below use when their own `devices` argument is None -- None = the
+        current device, "all" = every visible GPU from this one process (multidevice.py; BNN_CHAOS_DEVICES=all in the environment
+        does the same for a script that cannot be edited), an int or a list."""
         super(FeatureRegressor, self).__init__()
         pwd = os.path.dirname(__file__)
         self.cuda = cuda
+        self.devices = devices
+        self.last_run = None
         pattern = filebase if os.path.isabs(filebase) else pwd + "/../" + filebase
         names = glob.glob(pattern)
         if sort:
@@ -61,9 +100,12 @@ class FeatureRegressor(object):
         return self
 
     def device_set(self, devices=None):
-        """devices: None = every visible GPU (an unchanged single-process script then uses the whole node); an int n = the first n;
-        a list of indices / torch.devices = exactly those (a device may be named several times: logical shards on one card)."""
-        key = None if devices is None else (devices if isinstance(devices, int) else tuple(str(d) for d in devices))
+        """devices: None = the constructor's `devices` (default: the CURRENT device -- a script that chose a GPU, or a rank of a
+        process-per-GPU launch, keeps it); "all" = every visible GPU from this one process; an int n = the first n; a list of indices /
+        torch.devices = exactly those (a device may be named several times: logical shards on one card)."""
+        if devices is None:
+            devices = self.devices
+        key = (None, torch.cuda.current_device()) if devices is None else (devices if isinstance(devices, (int, str)) else tuple(str(d) for d in devices))
         if key not in self._device_sets:
             self._device_sets[key] = DeviceSet(devices)
         return self._device_sets[key]
@@ -135,7 +177,7 @@ class FeatureRegressor(object):
         return self._stacked
 
     def sample_full_swag_many(self, X, samples, chunks=1, rng="torch", philox_seed=0, draw_id0=0, system_id0=0,
-                              scale=0.5, out=None, precision="f32", devices=None):
+                              scale=0.5, out=None, precision="f32", devices=None, assume_finite=False):
         """The whole MC loop in one launch per device:
 
             torch.cat([torch.cat([self.sample_full_swag(Xpart) for Xpart in torch.chunk(X, chunks)])[None]
@@ -144,9 +186,11 @@ class FeatureRegressor(object):
         -> [samples, B, 2].  rng="torch" consumes numpy's and torch's global generators exactly as that loop does
         (one randint + randn((1,d)) + randn((K,1)) + 2 randn_like([Bc,latent]) per chunk per sample);
         rng="philox" draws the seed picks from numpy and everything else in-kernel.
-        devices: None = every visible GPU of this process (the systems are sharded over them, the ensemble and the draws replicated;
-        the chunks stay those of the whole batch, so the result does not depend on the device list: multidevice.py); an int or a
-        list picks devices.
+        devices: None = the current device (or the constructor's `devices`); "all" = every visible GPU of this process (the systems
+        are sharded over them, the ensemble and the draws replicated; the chunks stay those of the whole batch, so the result does not
+        depend on the device list: multidevice.py); an int or a list picks devices.  Host-resident X: every device's rows are on their
+        way before the first launch, the PCIe links side by side (DeviceSet.stage); `self.last_run` holds h2d / exchange / devices.
+        assume_finite: False = X is scanned once per shard and systems that hold NaN / +-inf get the reference's result (ops.forward).
         precision: "f32" (the parity path) or an OPT-IN reduced-precision form of ops.forward ("f16x3": fp32-level error at ~1.7x
         the throughput; "bf16", "f16", ...: approximate) -- DESIGN.md section 4.6.  The IEEE-half forms ("f16", "f16x3") require
         |X| < 65 504 in the live columns: rows beyond that (e.g. the script's constant-4 fill of unstable systems,
@@ -175,38 +219,32 @@ class FeatureRegressor(object):
                               "the outputs of those rows are wrong (finite); use 'bf16x6' or 'f32' for them", RuntimeWarning, stacklevel=2)
         g0 = ds.devices[0]
         noise_dev = g0 if self.cuda else torch.device("cpu")
-        seed_idx = np.empty(J, np.int32)
+        xs = ds.stage(X)            # every device's rows are on their way before the generators are even touched
         z1 = z2 = eps = None
         if rng == "torch":
-            z1 = torch.empty((J, d), device=noise_dev)
-            z2 = torch.empty((J, K), device=noise_dev)
-            eps = torch.empty((samples, B, 2, LAT), device=X.device)
-            for e in range(J):
-                s_, c_ = divmod(e, nch)
-                seed_idx[e] = np.random.randint(0, S)                               # regression.py:78
-                z1[e] = torch.randn((1, d), device=noise_dev)[0]                    # spock_reg_model.py:830
-                z2[e] = torch.randn((K, 1), device=noise_dev)[:, 0]                 # :831
-                n = len(parts[c_])
-                lo = c_ * csz
-                eps[s_, lo:lo + n, 0] = torch.randn(n, LAT, device=X.device)        # :426
-                eps[s_, lo:lo + n, 1] = torch.randn(n, LAT, device=X.device)        # :427
+            seed_idx, z1, z2, eps = draw_reference_noise(samples, parts, S, d, K, LAT, noise_dev, X.device)
         elif rng == "philox":
+            seed_idx = np.empty(J, np.int32)
             for e in range(J):
                 seed_idx[e] = np.random.randint(0, S)
         else:
             raise ValueError("rng must be 'torch' or 'philox'")
         seed_t = torch.as_tensor(seed_idx)
+        rep = {}    # the draws' normals: ONE copy per distinct device (logical shards on one card share it)
 
         def shard(i, dev, lo, hi):
             wa, w2, pd = state[i]
-            xg = X[lo:hi].detach().to(dev, torch.float32).contiguous()
-            kw = dict(nchunks=nch, scale=scale, plan=m0._plan(device=dev), precision=precision, chunk_B=B, chunk_off=lo)
+            kw = dict(nchunks=nch, scale=scale, plan=m0._plan(device=dev), precision=precision, chunk_B=B, chunk_off=lo,
+                      assume_finite=assume_finite)
             if rng == "torch":
-                return ops.multiswag(xg, wa, w2, pd, seed_t, z1.to(dev).contiguous(), z2.to(dev).contiguous(),
-                                     eps[:, lo:hi].to(dev).contiguous(), **kw)
-            return ops.multiswag(xg, wa, w2, pd, seed_t, philox_seed=philox_seed, draw_id0=draw_id0, system_id0=system_id0 + lo, **kw)
+                if dev not in rep:
+                    rep[dev] = (z1.to(dev).contiguous(), z2.to(dev).contiguous())
+                e_dev = eps[:, :, lo:hi].to(dev).permute(0, 2, 1, 3).contiguous()     # [samples, 2, n, L] -> the kernels' [samples, n, 2, L]
+                return ops.multiswag(xs[i], wa, w2, pd, seed_t, rep[dev][0], rep[dev][1], e_dev, **kw)
+            return ops.multiswag(xs[i], wa, w2, pd, seed_t, philox_seed=philox_seed, draw_id0=draw_id0, system_id0=system_id0 + lo, **kw)
 
         res = [r for r in ds.run(B, shard) if r is not None]
+        self.last_run = {"devices": [str(dv) for dv in ds.devices], "exchange": "concatenation of the shards' rows", "h2d": ds.h2d_ms}
         target = out.device if out is not None else X.device
         nb = torch.device(target).type == "cuda"   # (a non-blocking copy to HOST memory would return before the data has landed)
         res = res[0].to(target) if len(res) == 1 else torch.cat([r.to(target, non_blocking=nb) for r in res], 1)
@@ -216,7 +254,7 @@ class FeatureRegressor(object):
         return res
 
     def predictive_bands(self, X, samples, chunks=1, trios=1, q=(50.0, 84.0, 16.0, 97.5, 2.5), philox_seed=0, system_id0=0,
-                         samples_per_launch=64, scale=0.5, stats=None, segments=None, devices=None):
+                         samples_per_launch=64, scale=0.5, stats=None, segments=None, devices=None, assume_finite=False):
         """Everything figures/multiswag_5_planet.py does between the features and the `cleaned` table (:295-298, 388-428,
         484-489), streamed: the MC loop (one random ensemble member + one weight draw per chunk per sample), the truncated-normal
         draw, the prior resampling past 9, the min over `trios` consecutive rows and, per simulation, the percentiles `q`
@@ -224,9 +262,10 @@ class FeatureRegressor(object):
         `samples_per_launch` samples: the epilogue runs in the forward kernel's tail, a quantile sketch (ops.QuantileSketch,
         one bin width of error) collects the draws.  Seed picks come from numpy's generator (regression.py:78, one per chunk per
         sample, in the reference's order); all other noise is in-kernel Philox keyed by (philox_seed, sample, row).
-        devices: as in sample_full_swag_many -- None = every visible GPU: WHOLE simulations are sharded over them, each device
-        streams its shard into its own sketch, and ONE exchange assembles the [simulations, len(q) + 1] table on the first device.
-        Returns {"percentiles": [B / trios, len(q)], "average": [B / trios]} on the GPU."""
+        devices: as in sample_full_swag_many -- with several, WHOLE simulations are sharded over them, each device streams its shard
+        into its own sketch, and ONE exchange assembles the [simulations, len(q) + 1] table on the first device.
+        Returns {"percentiles": [B / trios, len(q)], "average": [B / trios]} on the GPU, plus "exchange" (which exchange ran) and
+        "h2d" (a callable: the staging's copy time, DeviceSet.h2d_ms)."""
         self._check_X(X)
         if stats is not None and len(self.device_set(devices)) > 1:
             raise ValueError("an explicit `stats` block lives on one device; leave it None when several devices are used")
@@ -238,20 +277,21 @@ class FeatureRegressor(object):
         nch = len(torch.chunk(torch.arange(B), chunks)) if B else 1
         seed_idx = torch.as_tensor(np.array([np.random.randint(0, S) for _ in range(samples * nch)], np.int32))   # one pick per chunk per sample
         sketches = [None] * len(ds)
+        xs = ds.stage(X, group=trios)     # every device's rows on their way before the first launch
 
         def shard(i, dev, lo, hi):
             wa, w2, pd = state[i]
-            xg = X[lo:hi].detach().to(dev, torch.float32).contiguous()
             sk = ops.QuantileSketch(hi - lo, group=trios, segments=segments, device=dev)
             st = stats or ops.stats_params(device=dev)
-            ops.multiswag_bands(xg, wa, w2, pd, seed_idx, sk, st=st, nchunks=nch, scale=scale, philox_seed=philox_seed,
+            ops.multiswag_bands(xs[i], wa, w2, pd, seed_idx, sk, st=st, nchunks=nch, scale=scale, philox_seed=philox_seed,
                                 system_id0=system_id0 + lo, draws_per_launch=samples_per_launch * nch, plan=m0._plan(device=dev),
-                                chunk_B=B, chunk_off=lo)
+                                chunk_B=B, chunk_off=lo, assume_finite=assume_finite)
             sketches[i] = sk
             return torch.cat([sk.percentiles(q), sk.mean().float()[:, None]], 1)
 
         table = ds.gather_rows(ds.run(B, shard, group=trios))
         nq = len(tuple(q))
         live = [sk for sk in sketches if sk is not None]
+        self.last_run = {"devices": [str(dv) for dv in ds.devices], "exchange": ds.last_exchange, "h2d": ds.h2d_ms}
         return {"percentiles": table[:, :nq], "average": table[:, nq], "sketch": live[0] if len(live) == 1 else live,
-                "exchange": ds.last_exchange}
+                "exchange": ds.last_exchange, "h2d": ds.h2d_ms}

@@ -185,16 +185,23 @@ class VarModel:
         self.rng = "torch"
         self.philox_seed = 0
         self._philox_calls = 0
+        # Non-finite inputs (not a reference attribute).  False: every call scans x once and systems that hold NaN / +-inf get what the
+        # reference returns for them -- NaN through `x - mask` (:452-478) and the NaN-propagating nn.ReLU, or the exact IEEE value
+        # where an infinity dies in a ReLU (ops.nonfinite_scan).  True: x is known to be clean and the scan is skipped.
+        self.assume_finite = False
 
     # forward()'s side effect `self._cur_summary = summary_stats` (:512): the kernels do not write the summary unless asked, so it is
-    # produced on demand by re-running the last forward with its debug output (same weights, same noise).  `latents` (:433) and
-    # `_summary_kl` (:515-520) are read by the out-of-scope feature_importance.py / the training loss only and stay None / 0.
+    # produced on demand by re-running the last forward with its debug output (same weights, same noise, the Philox seed of THAT call).
+    # `_summary_kl` (:515-520) is read by the training loss only and stays 0.  The records behind the two lazy side effects hold the
+    # call's x on the GPU: when the caller's x already was a contiguous float32 GPU tensor that is the caller's own storage, by
+    # reference -- mutate it in place before reading `_cur_summary` / `latents` and they follow the new values (the reference computes
+    # both at forward time).  Reading either once caches it.
     @property
     def _cur_summary(self):
         if self._cur_summary_cache is None and self._last_forward is not None:
-            xg, Wg, eps, eps_in, eps_sum, noisy, did, plan = self._last_forward
-            _, _, summ = ops.forward(xg, Wg, eps=eps, eps_in=eps_in, eps_sum=eps_sum, philox_seed=self.philox_seed, draw_id0=did, plan=plan,
-                                     debug=True, noisy=noisy)
+            xg, Wg, eps, eps_in, eps_sum, noisy, did, plan, seed = self._last_forward
+            _, _, summ = ops.forward(xg, Wg, eps=eps, eps_in=eps_in, eps_sum=eps_sum, philox_seed=seed, draw_id0=did, plan=plan,
+                                     debug=True, noisy=noisy, assume_finite=self.assume_finite)
             self._cur_summary_cache = summ[0]
         return self._cur_summary_cache
 
@@ -203,10 +210,11 @@ class VarModel:
         """compute_summary_stats' side effect `self.latents = feature_nn(x)` [B,T,latent] (:417, :433) of the last forward / of the
         last compute_summary_stats call, produced on demand (same weights, same masks, same input noise)."""
         if self._latents_cache is None and self._last_latents_args is not None:
-            xg, Wg, eps_in, noisy, did, plan = self._last_latents_args
-            if callable(Wg):   # after forward_swag_fast: the weights its fused kernel drew (materialised on demand, like flatten())
-                Wg = Wg()[None].to(xg.device)
-            self._latents_cache = ops.feature_latents(xg, Wg, eps_in=eps_in, noisy=noisy, philox_seed=self.philox_seed, draw_id0=did, plan=plan)[0]
+            xg, Wg, eps_in, noisy, did, plan, seed = self._last_latents_args
+            if callable(Wg):   # after forward_swag_fast: the weights its fused kernel drew, re-drawn on demand from the call's own normals
+                Wg = Wg()[None].to(xg.device)   # (a closure over the draw, not over the module: load() / sample_weights() since do not matter)
+            self._latents_cache = ops.feature_latents(xg, Wg, eps_in=eps_in, noisy=noisy, philox_seed=seed, draw_id0=did, plan=plan,
+                                                      assume_finite=self.assume_finite)[0]
         return self._latents_cache
 
     @latents.setter
@@ -229,10 +237,7 @@ class VarModel:
 
     @_w.setter
     def _w(self, v):
-        la = getattr(self, "_last_latents_args", None)
-        if la is not None and callable(la[1]) and self._latents_cache is None:   # latents of the weights being replaced: evaluate now
-            _ = self.latents
-        self._pending_draw = None
+        self._pending_draw = None   # (a pending `latents` record keeps its own closure over the draw: nothing is evaluated here)
         self._w_store = v
 
     def to(self, device):
@@ -378,20 +383,21 @@ class VarModel:
         else:
             did = self._next_philox_id()
         Wg = W.to(g)
+        seed = int(self.philox_seed)
         if record:   # what the lazily evaluated side effect (_cur_summary, :512) needs to re-run this forward with its debug outputs
-            self._last_forward = (xg, Wg, eps, eps_in, eps_sum, noisy, did, plan)
+            self._last_forward = (xg, Wg, eps, eps_in, eps_sum, noisy, did, plan, seed)
             self._cur_summary_cache = None
-        self._last_latents_args = (xg, Wg, eps_in, noisy, did, plan)   # self.latents (:433): set by every compute_summary_stats
+        self._last_latents_args = (xg, Wg, eps_in, noisy, did, plan, seed)   # self.latents (:433): set by every compute_summary_stats
         self._latents_cache = None
         if want_debug or plan is not self._plan():   # debug outputs / a plan other than the model's own (compute_summary_stats): direct
-            res = ops.forward(xg, Wg, eps=eps, eps_in=eps_in, eps_sum=eps_sum, philox_seed=self.philox_seed, draw_id0=did, plan=plan,
-                              debug=want_debug, noisy=noisy)
+            res = ops.forward(xg, Wg, eps=eps, eps_in=eps_in, eps_sum=eps_sum, philox_seed=seed, draw_id0=did, plan=plan,
+                              debug=want_debug, noisy=noisy, assume_finite=self.assume_finite)
             if want_debug:
                 return tuple(r[0].to(dev_in) for r in res)
             return res[0].to(dev_in)
         mask, lowest, net = self._op_args()
         with torch.cuda.device(g):
-            res = self._tops().forward(xg, Wg, eps, eps_in, eps_sum, 1, bool(noisy), int(self.philox_seed), int(did), 0, mask, lowest, net)
+            res = self._tops().forward(xg, Wg, eps, eps_in, eps_sum, 1, bool(noisy), seed, int(did), 0, mask, lowest, net, bool(self.assume_finite))
         return res[0].to(dev_in)
 
     # ---- reference API -----------------------------------------------------------------------------------------
@@ -438,7 +444,7 @@ class VarModel:
             xg = x.detach().to(g, torch.float32).contiguous()
             W = self._w[None].to(g).expand(samples, -1).contiguous()
             out = ops.forward(xg, W, philox_seed=self.philox_seed, draw_id0=self._next_philox_id(samples), plan=self._plan(),
-                              noisy=True).cpu().numpy()                                    # [samples, B, 2]
+                              noisy=True, assume_finite=self.assume_finite).cpu().numpy()   # [samples, B, 2]
             all_samp = [out[s, :, 0] + np.random.randn(out.shape[1]) * out[s, :, 1] for s in range(samples)]
             return np.average(all_samp, axis=0)
         self.cpu()  # the reference forces CPU here, so its noise comes from the CPU generators
@@ -520,19 +526,22 @@ class SWAGModel(VarModel):
             z1g, z2g = z1.to(g).contiguous(), z2.reshape(1, -1).to(g).contiguous()
             mask, lowest, net = self._op_args()
             with torch.cuda.device(g):
-                out = self._tops().multiswag(xg, wa, w2, pd, idx, z1g, z2g, eps, 1, float(scale), 0, 0, 0, mask, lowest, net)
+                out = self._tops().multiswag(xg, wa, w2, pd, idx, z1g, z2g, eps, 1, float(scale), 0, 0, 0, mask, lowest, net,
+                                             bool(self.assume_finite))
             # the reference leaves the sampled weights loaded in the module (:838)
             plan = self._plan()
-            self._pending_draw = lambda: ops.swag_draw(wa, w2, pd, idx, z1g, z2g, scale=scale, plan=plan)[0]
+            draw = lambda: ops.swag_draw(wa, w2, pd, idx, z1g, z2g, scale=scale, plan=plan)[0]
         else:
             did, seed, plan = self._next_philox_id(), self.philox_seed, self._plan()
             mask, lowest, net = self._op_args()
             with torch.cuda.device(g):
-                out = self._tops().multiswag(xg, wa, w2, pd, idx, None, None, None, 1, float(scale), int(seed), int(did), 0, mask, lowest, net)
-            self._pending_draw = lambda: ops.swag_draw(wa, w2, pd, idx, scale=scale, philox_seed=seed, draw_id0=did, plan=plan)[0]
+                out = self._tops().multiswag(xg, wa, w2, pd, idx, None, None, None, 1, float(scale), int(seed), int(did), 0, mask, lowest, net,
+                                             bool(self.assume_finite))
+            draw = lambda: ops.swag_draw(wa, w2, pd, idx, scale=scale, philox_seed=seed, draw_id0=did, plan=plan)[0]
+        self._pending_draw = draw
         self._last_forward = None          # (_cur_summary belongs to forward(); forward_swag_fast does not set it, :878-908)
         self._cur_summary_cache = None
-        self._last_latents_args = (xg, self.flatten, None, False, 0, plan)   # its compute_summary_stats call (:893) sets self.latents
+        self._last_latents_args = (xg, draw, None, False, 0, plan, 0)   # its compute_summary_stats call (:893) sets self.latents
         self._latents_cache = None
         return out[0].to(dev_in)
 

@@ -6,7 +6,10 @@ bnn_chaos_model_amd.ops (ctypes -> C ABI -> HIP kernels) with shape-only fake im
 called from torch code, traced by torch.export / captured in HIP graphs by the caller, and show up by name in profiles.
 The module surface routes through them: VarModel.forward, SWAGModel.sample_weights and SWAGModel.forward_swag_fast
 (spock_reg_model.py) call torch.ops.bnn_chaos.forward / swag_draw / multiswag.  The network (`net` = [n_features, hidden, latent,
-depth_in, depth_out, fix_megno]; None = the pretrained ensemble's), its column mask and its clamp floor select the plan.
+depth_in, depth_out, fix_megno]; None = the pretrained ensemble's), its column mask and its clamp floor select the plan -- for all five
+ops: a checkpoint built with other hparams (spock_reg_model.py:343-362) goes through every one of them.
+assume_finite (the four ops that read x): False = scan x once and give systems that hold NaN / +-inf the reference's result
+(ops.nonfinite_scan); True = x is known to be clean.
 """
 from typing import List, Optional
 
@@ -41,14 +44,16 @@ def _(w_avg, w2_avg, pre_D, seed_idx, z1, z2, scale, philox_seed, draw_id0, zero
 @torch.library.custom_op(f"{LIB}::forward", mutates_args=())
 def forward(x: torch.Tensor, W: torch.Tensor, eps: Optional[torch.Tensor], eps_in: Optional[torch.Tensor],
             eps_sum: Optional[torch.Tensor], nchunks: int, noisy: bool, philox_seed: int, draw_id0: int,
-            system_id0: int, zero_mask: int = ops.V50_ZERO_MASK, lowest_std: float = 0.5, net: Optional[List[int]] = None) -> torch.Tensor:
+            system_id0: int, zero_mask: int = ops.V50_ZERO_MASK, lowest_std: float = 0.5, net: Optional[List[int]] = None,
+            assume_finite: bool = False) -> torch.Tensor:
     """VarModel.forward (spock_reg_model.py:486-528) for materialised weights -> [J/nchunks, B, 2]."""
     return ops.forward(x, W, eps, eps_in, eps_sum, nchunks=nchunks, noisy=noisy, philox_seed=philox_seed, draw_id0=draw_id0,
-                       system_id0=system_id0, plan=_plan(zero_mask, lowest_std, net))
+                       system_id0=system_id0, plan=_plan(zero_mask, lowest_std, net), assume_finite=assume_finite)
 
 
 @forward.register_fake
-def _(x, W, eps, eps_in, eps_sum, nchunks, noisy, philox_seed, draw_id0, system_id0, zero_mask=ops.V50_ZERO_MASK, lowest_std=0.5, net=None):
+def _(x, W, eps, eps_in, eps_sum, nchunks, noisy, philox_seed, draw_id0, system_id0, zero_mask=ops.V50_ZERO_MASK, lowest_std=0.5, net=None,
+      assume_finite=False):
     return x.new_empty((W.shape[0] // nchunks, x.shape[0], 2))
 
 
@@ -56,42 +61,48 @@ def _(x, W, eps, eps_in, eps_sum, nchunks, noisy, philox_seed, draw_id0, system_
 def multiswag(x: torch.Tensor, w_avg: torch.Tensor, w2_avg: torch.Tensor, pre_D: torch.Tensor, seed_idx: torch.Tensor,
               z1: Optional[torch.Tensor], z2: Optional[torch.Tensor], eps: Optional[torch.Tensor], nchunks: int, scale: float,
               philox_seed: int, draw_id0: int, system_id0: int, zero_mask: int = ops.V50_ZERO_MASK, lowest_std: float = 0.5,
-              net: Optional[List[int]] = None) -> torch.Tensor:
+              net: Optional[List[int]] = None, assume_finite: bool = False) -> torch.Tensor:
     """Fused forward_swag_fast over the MC loop (spock_reg_model.py:878-908, figures/multiswag_5_planet.py:295-298)."""
     return ops.multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1, z2, eps, nchunks=nchunks, scale=scale, philox_seed=philox_seed,
-                         draw_id0=draw_id0, system_id0=system_id0, plan=_plan(zero_mask, lowest_std, net))
+                         draw_id0=draw_id0, system_id0=system_id0, plan=_plan(zero_mask, lowest_std, net), assume_finite=assume_finite)
 
 
 @multiswag.register_fake
 def _(x, w_avg, w2_avg, pre_D, seed_idx, z1, z2, eps, nchunks, scale, philox_seed, draw_id0, system_id0, zero_mask=ops.V50_ZERO_MASK,
-      lowest_std=0.5, net=None):
+      lowest_std=0.5, net=None, assume_finite=False):
     return x.new_empty((seed_idx.numel() // nchunks, x.shape[0], 2))
 
 
 @torch.library.custom_op(f"{LIB}::multiswag_moments", mutates_args=())
 def multiswag_moments(x: torch.Tensor, w_avg: torch.Tensor, w2_avg: torch.Tensor, pre_D: torch.Tensor, seed_idx: torch.Tensor,
-                      scale: float, philox_seed: int, draw_id0: int, system_id0: int, draws_per_launch: int) -> torch.Tensor:
+                      scale: float, philox_seed: int, draw_id0: int, system_id0: int, draws_per_launch: int,
+                      zero_mask: int = ops.V50_ZERO_MASK, lowest_std: float = 0.5, net: Optional[List[int]] = None,
+                      assume_finite: bool = False) -> torch.Tensor:
     """Predictive moments of the dense (systems x draws) grid -> float64 [B, 4] (sum mu, sum mu^2, sum std, sum std^2), the draws
     evaluated in slabs of `draws_per_launch` so that [J,B,2] is never materialised (the multi-GPU gather payload):
     the native slab driver bnn_multiswag_moments_f64, one C-ABI call."""
     return ops.multiswag_moments(x, w_avg, w2_avg, pre_D, seed_idx, scale=scale, philox_seed=philox_seed, draw_id0=draw_id0,
-                                 system_id0=system_id0, draws_per_launch=draws_per_launch)
+                                 system_id0=system_id0, draws_per_launch=draws_per_launch, plan=_plan(zero_mask, lowest_std, net),
+                                 assume_finite=assume_finite)
 
 
 @multiswag_moments.register_fake
-def _(x, w_avg, w2_avg, pre_D, seed_idx, scale, philox_seed, draw_id0, system_id0, draws_per_launch):
+def _(x, w_avg, w2_avg, pre_D, seed_idx, scale, philox_seed, draw_id0, system_id0, draws_per_launch, zero_mask=ops.V50_ZERO_MASK,
+      lowest_std=0.5, net=None, assume_finite=False):
     return x.new_empty((x.shape[0], 4), dtype=torch.float64)
 
 
 @torch.library.custom_op(f"{LIB}::multiswag_stats", mutates_args=())
 def multiswag_stats(x: torch.Tensor, w_avg: torch.Tensor, w2_avg: torch.Tensor, pre_D: torch.Tensor, seed_idx: torch.Tensor,
-                    nchunks: int, scale: float, philox_seed: int, draw_id0: int, system_id0: int) -> torch.Tensor:
+                    nchunks: int, scale: float, philox_seed: int, draw_id0: int, system_id0: int, zero_mask: int = ops.V50_ZERO_MASK,
+                    lowest_std: float = 0.5, net: Optional[List[int]] = None, assume_finite: bool = False) -> torch.Tensor:
     """multiswag with the scripts' statistics epilogue (truncated-normal draw at 4, prior resampling at 9;
     figures/multiswag_5_planet.py:388-422) fused into the kernel tail -> t [J/nchunks, B]."""
     return ops.multiswag_stats(x, w_avg, w2_avg, pre_D, seed_idx, nchunks=nchunks, scale=scale, philox_seed=philox_seed,
-                               draw_id0=draw_id0, system_id0=system_id0)
+                               draw_id0=draw_id0, system_id0=system_id0, plan=_plan(zero_mask, lowest_std, net), assume_finite=assume_finite)
 
 
 @multiswag_stats.register_fake
-def _(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, scale, philox_seed, draw_id0, system_id0):
+def _(x, w_avg, w2_avg, pre_D, seed_idx, nchunks, scale, philox_seed, draw_id0, system_id0, zero_mask=ops.V50_ZERO_MASK, lowest_std=0.5,
+      net=None, assume_finite=False):
     return x.new_empty((seed_idx.numel() // nchunks, x.shape[0]))

@@ -33,7 +33,9 @@ extern "C" {
  * table; bnn_arch.reserved became fix_megno; bnn_build_flags() names the build; bnn_feature_nn_f32 (the latents side effect);
  * bnn_spec_source / bnn_plan_attach_spec / bnn_plan_spec_attached / bnn_spec_embedded_source (specialised forms of the generic engine);
  * bnn_grid.engine = 2. */
-#define BNN_ABI_VERSION 3
+/* v4: non-finite inputs the reference's way -- bnn_nonfinite_record_bytes / bnn_nonfinite_scan_f32 and bnn_grid.nonfinite (the struct grew
+ * by one pointer); bnn_gen_params_bytes (layout check for code objects compiled at run time). */
+#define BNN_ABI_VERSION 4
 
 enum bnn_status {
     BNN_OK = 0,
@@ -101,6 +103,9 @@ int bnn_plan_spec_attached(const bnn_plan* plan, int32_t noisy); /* 1 / 0 */
  * its ragged series lengths (T % 4 != 0, T < 8 -- everything its register-resident kernels do not take) run on them without any
  * compiler at run time; quiet form under the pretrained column mask, noisy form under any mask. */
 int bnn_spec_embedded_source(char* buf, size_t cap);
+/* sizeof the parameter block a specialised kernel takes by value: a code object compiled against other headers than the library's own
+ * (a stale cache, an A/B build) would read it with another layout -- specialize.py mixes this and bnn_abi_version() into its cache key. */
+size_t bnn_gen_params_bytes(void);
 /* Accumulation order used by the kernels for Linear layer `layer` (0 .. number of Linear modules - 1, feature_nn's first): `order`
  * receives up to `cap` entries (input indices; the accumulator starts at the bias).  The generic engine's order is the natural one
  * (0, 1, 2, ...) for every layer; the v50 kernels permute regress_nn's.
@@ -138,7 +143,25 @@ typedef struct bnn_grid {
     int64_t chunk_off; /* (torch.chunk semantics, chunk size ceil(chunk_B / nchunks)), of which this call holds rows
                           [chunk_off, chunk_off + B); a draw covers the part of its chunk that lies in the shard.  0, 0 = the call
                           holds the whole batch.  Results are then bit-identical to the unsharded call with system_id0 = chunk_off. */
+    const void* nonfinite; /* DEVICE record written by bnn_nonfinite_scan_f32 for THIS call's x, or NULL = x is assumed finite.
+                          With a record every forward entry point returns, for the systems it lists, what the reference returns
+                          (spock_reg_model.py:452-478 x - mask, :301-321 nn.ReLU): see bnn_nonfinite_scan_f32. */
 } bnn_grid;
+
+/* Non-finite inputs.  The reference masks by subtraction (`x = x - mask`, spock_reg_model.py:452-478), so NaN / +-inf in a MASKED column
+ * becomes NaN -- not 0 --, nn.Linear carries it into every neuron and nn.ReLU (:301-321) propagates NaN: the system's (mu, std) is NaN.
+ * In a live column NaN does the same; +-inf becomes +-inf x weight, the ReLU keeps +inf and turns -inf into 0, and the system's outputs
+ * are NaN unless the infinity only ever meets weights of one sign.  The forward kernels are written for finite data (they never read the
+ * columns the pretrained mask drops; their ReLU is an integer max on the bit pattern).  bnn_nonfinite_scan_f32 reads x ONCE (not once per
+ * draw) and writes the list of systems that hold a non-finite value into `record` (int32 [4 + B]: [0] = listed systems, [1] = of which
+ * certainly NaN whatever the weights -- a NaN anywhere or +-inf in a masked column --, [4 + i] = (system << 1) | certain); a forward entry
+ * point whose grid.nonfinite points at the record re-evaluates the listed systems with plain IEEE arithmetic after its kernel (x - x on
+ * the masked columns, NaN-propagating ReLU, natural accumulation order) and overwrites their outputs -- (mu, std), pre_clamp, summary,
+ * latents, or the statistics tail's value.  Enqueue only; the record may be reused for any number of calls on the same x (B, T and the
+ * plan's mask must match).  Finite inputs whose intermediate values overflow fp32 are outside this mechanism: they follow IEEE
+ * arithmetic in the kernels (the reference returns NaN for those as well). */
+size_t bnn_nonfinite_record_bytes(int64_t B);
+int bnn_nonfinite_scan_f32(const bnn_plan* plan, const float* x, int64_t B, int32_t T, void* record, void* stream);
 
 /* SWAGModel.sample_weights (spock_reg_model.py:815-838), J draws at once.
  *   w_avg, w2_avg [S,d]; pre_D [S,d,K]; seed_idx [J] int32 (which ensemble member each draw uses:

@@ -139,7 +139,7 @@ static void linear_row(const REAL* W, const REAL* b, int n_out, int n_in, const 
                 acc = (k < 0) ? FMA(b[j], (REAL)1, acc) : FMA(wr[k], x[k], acc);
             }
         }
-        y[j] = (relu && !(acc > 0)) ? (REAL)0 : acc; /* nn.ReLU */
+        y[j] = (relu && acc <= 0) ? (REAL)0 : acc; /* nn.ReLU: NaN is not <= 0 and stays NaN, -inf becomes 0, +inf stays (torch.relu) */
     }
 }
 
@@ -268,8 +268,9 @@ int FN(forward)(const orc_arch* a, const REAL* x, int64_t B, const REAL* w, cons
                 REAL* cur = buf0;
                 REAL* nxt = buf1;
                 for (int f = 0; f < F; ++f) {
-                    /* zero_megno/mmr/nan/eplusminus: x - mask == 0 on masked columns (:452-478); bits past 63 do not exist */
-                    REAL v = (f < 64 && ((a->zero_mask >> f) & 1)) ? (REAL)0 : xi[f];
+                    /* zero_megno/mmr/nan/eplusminus: `x = x - mask` with mask = x on the masked columns (:452-478): 0 for a finite
+                     * value, NaN for NaN and +-inf (inf - inf) -- evaluated as the reference does; bits past 63 do not exist */
+                    REAL v = (f < 64 && ((a->zero_mask >> f) & 1)) ? (REAL)(xi[f] - xi[f]) : xi[f];
                     if (eps_in) v = v + eps_in[((size_t)b * T + t) * F + f] * in_scale[f]; /* add_input_noise :444-446 */
                     cur[f] = v;
                 }

@@ -25,7 +25,7 @@ def N():
 
 def test_abi_exports_every_declared_symbol(N):
     hdr = open(os.path.join(ROOT, "include", "bnn_chaos_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(bnn_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(bnn_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 14
     lib = C.CDLL(N.SO_PATH)
     for name in declared:

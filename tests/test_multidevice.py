@@ -13,7 +13,7 @@ from conftest import load_golden
 def _cpu_set(n):
     from bnn_chaos_model_amd.multidevice import DeviceSet
     ds = object.__new__(DeviceSet)
-    ds.devices, ds._replicas, ds.last_exchange = [torch.device("cpu")] * n, {}, None
+    ds.devices, ds._replicas, ds.last_exchange, ds.exchange, ds._h2d = [torch.device("cpu")] * n, {}, None, "copies", None
     return ds
 
 
@@ -35,6 +35,74 @@ def test_partition_and_exchange_on_cpu(B, n, group):
     st = ds.replicate("k", (torch.ones(3), torch.arange(4)))
     assert len(st) == n and all(torch.equal(s[0], torch.ones(3)) for s in st)
     assert ds.replicate("k", (torch.ones(3),)) is not st
+    # staging: every shard's rows, in shard order, before anything runs (pageable host source: one host thread per shard)
+    X = torch.arange(B * 6, dtype=torch.float64).reshape(B, 2, 3)
+    xs = ds.stage(X, group=group)
+    assert [x is None for x in xs] == [hi == lo for lo, hi in bounds]
+    assert torch.equal(torch.cat([x for x in xs if x is not None]), X.float()) and all(x.dtype == torch.float32 for x in xs if x is not None)
+    info = ds.h2d_ms()
+    assert info["bytes"] == X.numel() * 8 and info["host_ms"] >= 0.0 and "pageable" in info["mode"]
+
+
+def test_which_devices(monkeypatch):
+    """None = the CURRENT device (a rank of a process-per-GPU launch, or a script that called set_device, keeps its GPU); "all" opts in to
+    every visible GPU -- except under a launcher; BNN_CHAOS_DEVICES stands in for the argument of a script that cannot be edited."""
+    from bnn_chaos_model_amd import multidevice as md
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 5)
+    for k in ("WORLD_SIZE", "LOCAL_RANK", "BNN_CHAOS_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    dev = lambda *i: [torch.device("cuda", j) for j in i]
+    assert md.resolve_devices(None) == dev(5)
+    assert md.resolve_devices("all") == dev(*range(8))
+    assert md.resolve_devices(3) == dev(0, 1, 2)
+    assert md.resolve_devices([2, 2, "cuda:7"]) == dev(2, 2, 7)
+    monkeypatch.setenv("BNN_CHAOS_DEVICES", "all")
+    assert md.resolve_devices(None) == dev(*range(8)) and md.resolve_devices([1]) == dev(1)
+    monkeypatch.setenv("BNN_CHAOS_DEVICES", "1,3")
+    assert md.resolve_devices(None) == dev(1, 3)
+    monkeypatch.setenv("LOCAL_RANK", "5")          # torch.distributed.run: every GPU visible to every rank
+    monkeypatch.setenv("BNN_CHAOS_DEVICES", "all")
+    assert md.resolve_devices(None) == dev(5) and md.resolve_devices("all") == dev(5)
+    monkeypatch.delenv("LOCAL_RANK")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert md.resolve_devices("all") == dev(5)
+    with pytest.raises(ValueError):
+        md.resolve_devices([9])
+    with pytest.raises(ValueError):
+        md.resolve_devices("some")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        md.resolve_devices(None)
+
+
+def test_exchange_choice_and_what_counts_as_rccl_absent(monkeypatch):
+    """Peer copies by default; the RCCL form is opt-in and only RcclUnavailable falls back to the copies -- any other failure raises."""
+    from bnn_chaos_model_amd import multidevice as md
+    ds = _cpu_set(2)
+    rows = [torch.ones(2, 3), torch.zeros(1, 3)]
+    assert ds.gather_rows(rows).shape == (3, 3) and ds.last_exchange == "peer copies"
+    ds.exchange = "rccl"     # CPU tensors / repeated devices: not RCCL's business
+    assert ds.gather_rows(rows).shape == (3, 3) and "more than once" in ds.last_exchange
+
+    class FakeDev(torch.Tensor):
+        pass
+    calls = []
+    def boom(parts):
+        calls.append(len(parts))
+        raise md.RcclUnavailable("not built in")
+    monkeypatch.setattr(md, "_rccl_all_gather", boom)
+    # distinct "devices": fake it through the device list check by patching set() semantics is overkill -- call the branch directly
+    class P:   # minimal stand-in for two tensors on two GPUs
+        def __init__(self, t, i):
+            self.t, self.device, self.shape, self.is_cuda = t, f"cuda:{i}", t.shape, True
+        def to(self, d, non_blocking=False):
+            return self.t
+    out = ds.gather_rows([P(rows[0], 0), P(rows[1], 1)])
+    assert calls == [2] and out.shape == (3, 3) and "unavailable" in ds.last_exchange
+    monkeypatch.setattr(md, "_rccl_all_gather", lambda parts: (_ for _ in ()).throw(ValueError("a real bug")))
+    with pytest.raises(ValueError, match="a real bug"):
+        ds.gather_rows([P(rows[0], 0), P(rows[1], 1)])
 
 
 @pytest.fixture(scope="module")
@@ -57,11 +125,14 @@ def test_logical_shards_reproduce_the_single_shard_result(fr, rng, inputs):
     card == one shard, bit for bit, with the reference's RNG order and with in-kernel Philox; likewise the default (all visible)."""
     X = torch.tensor(np.tile(inputs["slow"], (3, 1, 1))[:77])
     outs = {}
-    for name, devs in (("one", [0]), ("three", [0, 0, 0]), ("seven", [0] * 7), ("default", None)):
+    for name, devs in (("one", [0]), ("three", [0, 0, 0]), ("seven", [0] * 7), ("default", None), ("all", "all")):
         np.random.seed(5); torch.manual_seed(5)
         outs[name] = fr.sample_full_swag_many(X, samples=4, chunks=10, rng=rng, philox_seed=17, draw_id0=40, system_id0=1000, devices=devs)
         assert outs[name].shape == (4, 77, 2) and outs[name].device == X.device
     assert torch.equal(outs["one"], outs["three"]) and torch.equal(outs["one"], outs["seven"]) and torch.equal(outs["one"], outs["default"])
+    assert torch.equal(outs["one"], outs["all"])
+    info = fr.last_run["h2d"]()
+    assert info["ms"] >= 0.0 and info["bytes"] == X.numel() * 4 and fr.last_run["devices"] == ["cuda:0"]
     # and the single-shard result is the loop of the reference's script (chunk by chunk through sample_full_swag), same seeds
     if rng == "torch":
         np.random.seed(5); torch.manual_seed(5)
