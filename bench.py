@@ -21,6 +21,12 @@ the timed region.  Default workload = BASELINE.json configs[2], the largest sing
 the pretrained ensemble's, and every series length T % 4 != 0, runs on); --net 64,16,1,1 benches another hparams-built network
 (hidden, latent, depth in, depth out[, features 41|82]) on a seeded synthetic ensemble.  Neither is a BASELINE configuration.
 
+--single-process --gpus N drives the N GPUs from THIS process instead (multidevice.DeviceSet: one shard of the systems resident on
+every device, launches enqueued device after device, ONE exchange of the per-system moments onto the first device) -- the route an
+unchanged single-process evaluation script takes with devices="all"; same JSON schema, config.launcher = "single-process".
+
+--assume-finite skips the once-per-step scan of x for NaN / +-inf (the product default scans: ops.nonfinite_scan); the line says which.
+
 --gpus N > 1 from a plain invocation launches N rank processes itself (a torch.distributed.run child, started BEFORE this
 process touches the GPU); under torch.distributed.run (WORLD_SIZE set) it is a rank.  One rank per GPU over RCCL: systems
 are sharded over ranks (weak scaling: the workload's systems are per GPU), every rank evaluates the same draws on its shard,
@@ -281,6 +287,11 @@ def parse(argv=None):
     ap.add_argument("--timesteps", type=int, default=100, help="series length T (100 = every BASELINE config; others: the ragged lengths of the reference's "
                     "`augment`, which the generic engine / its specialised forms take)")
     ap.add_argument("--net", default="", help="hidden,latent,in,out[,features]: another hparams-built network on a synthetic ensemble (generic engine)")
+    ap.add_argument("--assume-finite", action="store_true", help="skip the once-per-step scan of x for NaN / +-inf (default: scan, as the module surface does)")
+    ap.add_argument("--single-process", action="store_true", help="drive the --gpus N devices from this one process (multidevice.DeviceSet) instead of N ranks")
+    ap.add_argument("--h2d-probe-gb", type=float, default=1.0, help="--single-process: GB per device staged from host memory (pinned, then pageable) "
+                    "outside the timed region, to report the PCIe-inclusive rate; 0 = skip")
+    ap.add_argument("--no-clock-sample", action="store_true", help="skip the sclk / power sample taken under load after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-systems", type=int, default=8192, help="systems of the batch the CPU baselines are timed on")
     ap.add_argument("--allow-gloo", action="store_true", help="accept a gloo moments gather when RCCL cannot start (the line says degraded)")
@@ -300,8 +311,156 @@ def parse(argv=None):
     return args
 
 
+def clock_sample_under_load(dev_index, enqueue_steps, n_steps=2, period_s=0.02):
+    """sclk / socket power of the device WHILE it runs `n_steps` more (untimed) steps of the same workload, read through amdsmi -- taken
+    right after the timed region, never inside it.  The same library measures 549-599 ms per configs[2] step from box to box (the chip is
+    power-limited under this kernel and holds 2.26-2.34 GHz): with the held clock in the line a swing reads as "box", not "regression".
+    Returns None when amdsmi is not there or the device cannot be matched."""
+    import torch
+    try:
+        import amdsmi
+        amdsmi.amdsmi_init()
+        handles = amdsmi.amdsmi_get_processor_handles()
+        p = torch.cuda.get_device_properties(dev_index)
+        want = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", -1), getattr(p, "pci_device_id", 0))
+        h = None
+        for cand in handles:
+            if str(amdsmi.amdsmi_get_gpu_device_bdf(cand)).lower().startswith(want):
+                h = cand
+        if h is None and len(handles) == 1:
+            h = handles[0]
+        if h is None:
+            return None
+        read = lambda: (float(amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)["clk"]),
+                        float(amdsmi.amdsmi_get_power_info(h)["current_socket_power"]))
+        read()
+    except Exception:
+        return None
+    done = torch.cuda.Event()
+    enqueue_steps(n_steps)           # asynchronous: the host is free to poll while the GPU works
+    done.record()
+    clk, pw = [], []
+    t_end = time.perf_counter() + 60.0
+    while not done.query() and time.perf_counter() < t_end:
+        try:
+            c, w = read()
+            clk.append(c); pw.append(w)
+        except Exception:
+            break
+        time.sleep(period_s)
+    torch.cuda.synchronize()
+    if len(clk) < 3:
+        return None
+    clk, pw = clk[1:], pw[1:]        # (the first read may still show the idle clock)
+    return {"sclk_mhz_mean": sum(clk) / len(clk), "sclk_mhz_min": min(clk), "sclk_mhz_max": max(clk), "power_w_mean": sum(pw) / len(pw),
+            "power_w_max": max(pw), "reads": len(clk),
+            "source": f"amdsmi (gfx clock, current socket power) polled every {int(period_s * 1e3)} ms during {n_steps} extra untimed steps right after the timed region"}
+
+
+def main_single_process(args):
+    """--single-process --gpus N: the N devices driven from this one process (multidevice.DeviceSet), one shard of B systems resident
+    per device (weak scaling, like the rank-per-GPU form), every device evaluating the same draws, ONE exchange of [B, 4] float64
+    moments onto the first device.  Dense fp32 workloads with kept samples (c3, c2, tiny)."""
+    import torch
+    from bnn_chaos_model_amd import ops
+    from bnn_chaos_model_amd.multidevice import DeviceSet
+    wl = dict(WORKLOADS[args.workload])
+    if wl.get("chunks", 1) != 1 or wl.get("slab") or wl.get("noisy") or args.net or args.precision != "f32" or args.engine != "auto":
+        sys.exit("--single-process runs the dense fp32 workloads (c3, c2, tiny)")
+    if args.systems:
+        wl["systems"] = args.systems
+    if args.samples:
+        wl["samples"] = args.samples
+    B, S, M = wl["systems"], wl["seeds"], wl["samples"]
+    J = wl.get("draws", S * M)
+    n = args.gpus
+    # BNN_BENCH_REHEARSE=1: every logical shard on cuda:0 -- exercises this code path on a one-GPU box
+    devs = [0] * n if os.environ.get("BNN_BENCH_REHEARSE") == "1" else list(range(n))
+    ds = DeviceSet(devs)
+    plans = [ops.get_plan(device=d) for d in ds.devices]
+    xs, outs, seeds = [], [], []
+    ens_host = synthetic_ensemble(S, "cpu")
+    state = ds.replicate("ensemble", ens_host)
+    for i, d in enumerate(ds.devices):
+        with torch.cuda.device(d):
+            xs.append(synthetic_x(B, d, seed=123 + i))
+            outs.append(torch.empty((J, B, 2), dtype=torch.float32, device=d))
+            seeds.append((torch.arange(J, dtype=torch.int32) % S).to(d))
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ds.devices] for _ in range(args.steps)]
+
+    def step(k, timed):
+        def shard(i, d, lo, hi):
+            if timed:
+                ev[k][i][0].record()
+            wa, w2, pd = state[i]
+            o = ops.multiswag(xs[i], wa, w2, pd, seeds[i], philox_seed=99, draw_id0=0, system_id0=lo, plan=plans[i], out=outs[i],
+                              assume_finite=args.assume_finite)
+            m = ops.moments(o)
+            if timed:
+                ev[k][i][1].record()
+            return m
+        return ds.gather_rows(ds.run(n * B, shard))
+
+    def fence():
+        for d in ds.devices:
+            torch.cuda.synchronize(d)
+
+    for _ in range(args.warmup):
+        step(0, False)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        res = step(k, True)
+    fence()
+    dt = time.perf_counter() - t0
+    assert res.shape == (n * B, 4)
+    kern = [sum(ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(args.steps)) / args.steps for i in range(len(ds))]
+    value = n * B * J * args.steps / dt
+    ach = B * J * ALG_FLOP_PER_EVAL / (max(kern) * 1e-3) / 1e12
+    exe = B * J * EXEC_FLOP_PER_EVAL[31] / (max(kern) * 1e-3) / 1e12
+    h2d = None
+    if args.h2d_probe_gb > 0:   # the PCIe-inclusive side of the route: rows of a host-resident batch onto every device at once (DeviceSet.stage)
+        rows = max(n, int(args.h2d_probe_gb * 1e9 / (100 * 41 * 4))) * n
+        h2d = {}
+        for mode in ("pinned", "pageable"):
+            hx = torch.empty((rows, 100, 41), dtype=torch.float32, pin_memory=(mode == "pinned"))
+            hx.normal_()
+            fence()
+            t1 = time.perf_counter()
+            shards = ds.stage(hx)
+            fence()
+            wall = (time.perf_counter() - t1) * 1e3
+            info = ds.h2d_ms()
+            h2d[mode] = {"bytes_per_device": hx.numel() * 4 // n, "wall_ms": wall, "slowest_device_ms": info["ms"], "mode": info["mode"],
+                         "aggregate_GBs": hx.numel() * 4 / wall / 1e6}
+            del shards, hx
+    clock = None if args.no_clock_sample else clock_sample_under_load(ds.devices[0].index, lambda k: [step(0, False) for _ in range(k)])
+    res = {
+        "metric": "system x MC-sample forward evals/sec", "value": value, "unit": "evals/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["name"], "launcher": "single-process", "systems_per_gpu": B, "seeds": S, "mc_samples": M, "draws": J, "chunks": 1,
+                   "timesteps": 100, "features": 41, "kernel": "multiswag, draw-once workspace + forward, one shard per device from one process",
+                   "noise": "in-kernel Philox4x32-10", "library": library_id(), "devices": [str(d) for d in ds.devices],
+                   "finite_check": "assumed finite (--assume-finite)" if args.assume_finite else "x scanned once per step per device (ops.nonfinite_scan)",
+                   "sharding": f"systems over {n} device(s) of one process, {ds.last_exchange} of moments [systems, 4] float64 onto the first device",
+                   "exchange": ds.last_exchange, "gather_bytes_per_rank": B * 4 * 8, "kernel_ms_min": min(kern), "kernel_ms_max": max(kern),
+                   "h2d_probe": h2d,
+                   "timing_note": "ms_per_step = wall clock of the whole step (launches on every device + the exchange), fenced by a synchronize of "
+                                  "every device on both sides; kernel_ms_* = HIP events around a device's launches (min / max over devices)"},
+        "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "traffic_measured_in_run": False, "achieved_executed": exe, "frac_executed": exe / PEAK_F32_MFMA_TFLOPS, "kernel_ms": max(kern),
+                     "note": "per device (the slowest one's launches); see the rank-per-GPU line for the counter-based figures"},
+    }
+    if clock:
+        res["clock"] = clock
+        res["roofline"]["frac_at_held_clock"] = exe * 1e12 / (clock["sclk_mhz_mean"] * 1e6 * 1024 * 64)
+    print(json.dumps(res), flush=True)
+
+
 def main():
     args = parse()
+    if args.single_process:
+        return main_single_process(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -418,6 +577,8 @@ def main():
     BANDS_Q = (2.5, 16.0, 50.0, 84.0, 97.5)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]   # behind the non-finite scan of a step, in front of its compute launches
+    fin = dict(assume_finite=True) if args.assume_finite else None            # else: nonfinite=<this step's record>
     gv0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     gv1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     gather_host_ms = []
@@ -444,27 +605,32 @@ def main():
     def step(i, timed):
         if timed:
             ev0[i].record()          # on torch's current stream = the stream the ops launch on (ops.N.stream_ptr())
+        # the product default: x is scanned for NaN / +-inf once per step (one streaming read), and every forward launch below is followed
+        # by the (empty-handed, here) fix-up launch; timed on its own so that roofline.kernel_ms stays the compute launches'
+        fk = fin or dict(nonfinite=ops.nonfinite_scan(x, plan=plan))
+        if timed:
+            evs[i].record()
         if slab and stream_bands:    # c4q: slabs of draws -> statistics epilogue in the forward tail -> quantile sketch, ONE native call
             sketch.hist.zero_(); sketch.mom.zero_(); sketch.count = 0
-            ops.multiswag_bands(x, wa, w2, pd, seed_idx, sketch, st=stats, philox_seed=99, draw_id0=0, system_id0=lo, draws_per_launch=slab, plan=plan)
+            ops.multiswag_bands(x, wa, w2, pd, seed_idx, sketch, st=stats, philox_seed=99, draw_id0=0, system_id0=lo, draws_per_launch=slab, plan=plan, **fk)
             bands = torch.cat([sketch.percentiles(BANDS_Q), sketch.mean().float()[:, None]], 1)   # [B, 6]
             if timed:
                 ev1[i].record()
             return gather(bands, world * B, i, timed)
         if slab:                     # c4: slabs of draws -> float64 moments inside ONE native call
-            mom = ops.multiswag_moments(x, wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, system_id0=lo, draws_per_launch=slab, plan=plan)
+            mom = ops.multiswag_moments(x, wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, system_id0=lo, draws_per_launch=slab, plan=plan, **fk)
             if timed:
                 ev1[i].record()
             return gather(mom, world * B, i, timed)
         if noisy:
-            o = ops.forward(x, W_noisy, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan, noisy=True, systems_per_block=args.spb, engine=args.engine)
+            o = ops.forward(x, W_noisy, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan, noisy=True, systems_per_block=args.spb, engine=args.engine, **fk)
         elif args.unfused:
             W = ops.swag_draw(wa, w2, pd, seed_idx, philox_seed=99, draw_id0=0, plan=plan)
-            o = ops.forward(x, W, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan, systems_per_block=args.spb, engine=args.engine)
+            o = ops.forward(x, W, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan, systems_per_block=args.spb, engine=args.engine, **fk)
         else:
             o = ops.multiswag(x, wa, w2, pd, seed_idx, nchunks=nch, philox_seed=99, draw_id0=0, system_id0=lo, plan=plan,
                               out=None if lowp else out, systems_per_block=args.spb, single_launch=args.single_launch or None,
-                              precision=args.precision, engine=args.engine)
+                              precision=args.precision, engine=args.engine, **fk)
         if timed:
             ev1[i].record()
         if trios > 1:   # c5: what the 5-planet script does with the samples (multiswag_5_planet.py:388-428, 484-489), per simulation
@@ -487,7 +653,12 @@ def main():
         res_last = step(i, True)
     fence()
     dt = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(evs, ev1)) / args.steps    # the compute launches of a step (draw, forward, fix-up, reductions inside it)
+    scan_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, evs)) / args.steps   # the non-finite scan of a step (0 with --assume-finite)
+    clock = None
+    if not args.no_clock_sample and not rehearse:
+        clock = clock_sample_under_load(local_rank, lambda k: [step(0, False) for _ in range(k)], n_steps=2 if not slab else 1)
+        fence()
     if use_dist:
         gather_ms = (sum(a.elapsed_time(b) for a, b in zip(gv0, gv1)) if on_nccl else sum(gather_host_ms)) / args.steps
         cdev = dev if on_nccl else "cpu"
@@ -592,7 +763,11 @@ def main():
                        "features": NF, "kernel": kernel,
                        "noise": ("in-kernel Philox: Philox4x32-7 for the input-noise stream (4 100 of the 4 180 normals of a noisy evaluation), "
                                  "Philox4x32-10 for every other stream" if noisy else "in-kernel Philox4x32-10"),
-                       "library": library_id(),
+                       "library": library_id(), "launcher": "torch.distributed ranks" if use_dist else "one process, one GPU",
+                       "finite_check": ("assumed finite (--assume-finite): no scan" if args.assume_finite else
+                                        "x scanned for NaN / +-inf once per step (bnn_nonfinite_scan_f32: one streaming read), every forward launch "
+                                        "followed by the fix-up launch (the reference's x - mask / NaN-propagating ReLU for the listed systems)"),
+                       "finite_check_ms": scan_ms,
                        "sharding": (f"whole simulations ({trios} trios each) over {world} rank(s), all-gather of {payload}" if trios > 1 else
                                     f"systems over {world} rank(s), all-gather of {payload}"),
                        "collective": (dist.get_backend() if use_dist else "none"), "degraded": degraded, "ranks_seen": ranks_seen,
@@ -607,10 +782,15 @@ def main():
                          "kernel_ms": kern_ms, "flop_per_eval": alg_flop, "flop_per_eval_executed": exe_flop,
                          "note": "frac counts the algorithm's 814 560 flop/eval (SURVEY 8d); frac_executed counts the MACs the kernel issues "
                                  "(the v50 mask drops 10 of 41 input columns); kernel_ms = HIP events around the compute launches of a step "
-                                 "(rank 0); traffic = HBM bytes per launch from separate rocprofv3 PMC passes of this command, null when "
+                                 "(rank 0; the non-finite scan in front of them is config.finite_check_ms and inside ms_per_step); "
+                                 "frac_at_held_clock = executed flop/s over (the sclk held under this load x 1024 SIMDs x 64 flop/clk): what "
+                                 "separates a slow box from a slow kernel; traffic = HBM bytes per launch from separate rocprofv3 PMC passes of this command, null when "
                                  "no such pass is on file for this workload",
                          "hbm_algorithmic_GBs": ach_gbs, "hbm_frac_of_8TBs": ach_gbs / PEAK_HBM_GBS},
         }
+        if clock:
+            res["clock"] = clock
+            res["roofline"]["frac_at_held_clock"] = exe_tflops * 1e12 / (clock["sclk_mhz_mean"] * 1e6 * 1024 * 64)
         if named:
             res["named_config"] = named
         if lowp:   # priced against the bf16 matrix pipe; issued flops = algorithmic x products; these forms are vector-issue bound

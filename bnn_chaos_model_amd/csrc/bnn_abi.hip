@@ -719,14 +719,10 @@ int bnn_nonfinite_scan_f32(const bnn_plan* pl, const float* x, int64_t B, int32_
     if (!record) return fail(BNN_ERR_INVALID, "record is NULL");
     if (B >= (1LL << 30)) return fail(BNN_ERR_RANGE, "the scan record indexes at most 2^30 systems per call: shard the batch");
     if (B > 0 && !x) return fail(BNN_ERR_INVALID, "x is NULL");
-    hipError_t e;
-    if (B == 0) e = hipMemsetAsync(record, 0, 4 * sizeof(int32_t), (hipStream_t)stream);
-    else {
-        // a masked column holds NaN after `x - mask` whichever non-finite value it had; fix_megno zeroes the MEGNO column whatever the
-        // mask says (:488-491) and summarises the raw one (:480-484): non-finite there is NaN in the summary either way
-        const uint64_t mask = pl->arch.zero_mask | (pl->megno ? (1ull << MEGNO_COL) : 0ull);
-        e = launch_nonfinite_scan(x, B, (int64_t)T * pl->arch.n_features, pl->arch.n_features, mask, static_cast<int32_t*>(record), (hipStream_t)stream);
-    }
+    // a masked column holds NaN after `x - mask` whichever non-finite value it had; fix_megno zeroes the MEGNO column whatever the
+    // mask says (:488-491) and summarises the raw one (:480-484): non-finite there is NaN in the summary either way
+    const uint64_t mask = pl->arch.zero_mask | (pl->megno ? (1ull << MEGNO_COL) : 0ull);
+    hipError_t e = launch_nonfinite_scan(x, B, (int64_t)T * pl->arch.n_features, pl->arch.n_features, mask, static_cast<int32_t*>(record), (hipStream_t)stream);
     if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("non-finite scan: ") + hipGetErrorString(e));
     return 0;
 }
@@ -1286,14 +1282,15 @@ int bnn_multiswag_moments_f64(const bnn_plan* plan, const bnn_grid* grid, const 
     if (rc) return rc;
     if (grid->B == 0) return 0;
     if (!moments || !out_workspace || !W_workspace) return fail(BNN_ERR_INVALID, "NULL workspace / moments");
-    HIP_TRY(hipMemsetAsync(moments, 0, sizeof(double) * 4 * (size_t)grid->B, (hipStream_t)stream));
+    // (the first slab overwrites, the others accumulate: no memset node -- see bnn_nonfinite.hip on memset nodes in captured graphs)
+    if (grid->J == 0) HIP_TRY(hipMemsetAsync(moments, 0, sizeof(double) * 4 * (size_t)grid->B, (hipStream_t)stream));
     for (int32_t j0 = 0; j0 < grid->J; j0 += draws_per_launch) {
         bnn_grid g = *grid;
         g.J = grid->J - j0 < draws_per_launch ? grid->J - j0 : draws_per_launch;
         rc = bnn_multiswag_f32(plan, &g, x, w_avg, w2_avg, pre_D, S, K, seed_idx + j0, nullptr, nullptr, nullptr, scale, philox_seed,
                                draw_id0 + j0, system_id0, W_workspace, out_workspace, nullptr, nullptr, stream);
         if (rc) return rc;
-        rc = bnn_moments_f64(out_workspace, g.J / g.nchunks, g.B, moments, 1, stream);
+        rc = bnn_moments_f64(out_workspace, g.J / g.nchunks, g.B, moments, j0 > 0 ? 1 : 0, stream);
         if (rc) return rc;
     }
     return 0;

@@ -65,9 +65,16 @@ __global__ __launch_bounds__(256) void bnn_nonfinite_scan_kernel(const float* __
     }
 }
 
+// The record's header is cleared by a KERNEL, not by hipMemsetAsync: inside a captured HIP graph a memset node in front of the kernels
+// was observed to be skipped on the second replay (ROCm 7.2: the fix-up then read a stale count) -- kernel nodes keep their order.
+__global__ void bnn_nonfinite_reset_kernel(int32_t* __restrict__ rec) {
+    if (threadIdx.x < 4) rec[threadIdx.x] = 0;
+}
+
 hipError_t launch_nonfinite_scan(const float* x, int64_t B, int64_t per, int F, uint64_t zero_mask, int32_t* rec, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(rec, 0, 4 * sizeof(int32_t), st);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bnn_nonfinite_reset_kernel, dim3(1), dim3(64), 0, st, rec);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || B == 0) return e;
     hipLaunchKernelGGL(bnn_nonfinite_scan_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x, B, per, F, zero_mask, rec);
     return hipGetLastError();
 }
