@@ -9,8 +9,9 @@
 //   bnn_fwd_generic.hip, bnn_fwd_generic82.hip   generic forward engine: the network built from hparams (any hidden / latent / depth; 41 resp. 82 features), any T
 //   bnn_generic.cpp     host: descriptor of that engine (layers, LDS image, register bucket)
 //   bnn_nonfinite.hip   non-finite inputs the reference's way: the once-per-call scan of x and the exact re-evaluation of the listed systems
-//   bnn_abi.hip         extern "C" entry points of include/bnn_chaos_hip.h + the small kernels (SWAG draw, moments, regress_nn,
-//                       statistics epilogue, feature packing, Philox fills)
+//   bnn_abi.hip         extern "C" entry points that launch a forward kernel, plans, specialised forms (bnn_abi_common.h lists the C-ABI units)
+//   bnn_ops_draw.hip, bnn_ops_reduce.hip, bnn_ops_stats.hip, bnn_ops_features.hip   the small kernels with their entry points: SWAG draw +
+//                       Philox fills; moments + regress_nn on a summary; statistics epilogue + quantile sketch; feature packing
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

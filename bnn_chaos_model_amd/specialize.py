@@ -26,18 +26,32 @@ SPEC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
 _DEPS = ("bnn_generic.hip.h", "bnn_generic.h", "bnn_common.hip.h", "bnn_stats.hip.h", "bnn_internal.h", "bnn_layout.h")
 
 
+def _private(d):
+    """Code objects are loaded onto the GPU as they are found: the directory they come from must be ours alone (owned by this user, not
+    writable by group or others)."""
+    st = os.stat(d)
+    return st.st_uid == os.getuid() and not (st.st_mode & 0o022)
+
+
 def cache_dir():
-    """BNN_SPEC_CACHE, else csrc/_spec next to the library (in-tree, like the built .so: it travels with the tree), else ~/.cache."""
-    for d in (os.environ.get("BNN_SPEC_CACHE"), os.path.join(CSRC, "_spec"), os.path.join(os.path.expanduser("~"), ".cache", "bnn_chaos_model_amd", "spec")):
+    """BNN_SPEC_CACHE, else csrc/_spec next to the library (in-tree, like the built .so: it travels with the tree), else ~/.cache.
+    Created with mode 0700; a directory somebody else owns or may write to is refused (BNN_SPEC_CACHE) or skipped (the defaults)."""
+    env = os.environ.get("BNN_SPEC_CACHE")
+    for d in (env, os.path.join(CSRC, "_spec"), os.path.join(os.path.expanduser("~"), ".cache", "bnn_chaos_model_amd", "spec")):
         if not d:
             continue
         try:
-            os.makedirs(d, exist_ok=True)
+            os.makedirs(d, mode=0o700, exist_ok=True)
+            if not _private(d):
+                if d == env:
+                    raise RuntimeError(f"BNN_SPEC_CACHE={d} is owned by another user or writable by group / others: code objects are loaded "
+                                       "from there unchecked, so it must be private (chmod go-w, or point it somewhere else)")
+                continue
             if os.access(d, os.W_OK):
                 return d
         except OSError:
             pass
-    raise RuntimeError("no writable cache directory for specialised kernels (set BNN_SPEC_CACHE)")
+    raise RuntimeError("no writable private cache directory for specialised kernels (set BNN_SPEC_CACHE)")
 
 
 def _extra_flags():
@@ -62,13 +76,34 @@ def _compiler_id():
     return _cc_id
 
 
-def _key(src):
-    h = hashlib.sha256(src.encode())
-    h.update(" ".join(SPEC_FLAGS + _extra_flags()).encode())
+def _library_id():
+    """Identity of the LOADED library: a specialised kernel takes the library's GenParams block by value, so a code object compiled
+    against other headers than the .so's own (a stale .so, an A/B build under BNN_CHAOS_SO) would read it with another layout -- a GPU
+    fault, not an error code.  ABI version + sizeof(GenParams) + build flags as the library reports them; and, unless the library is the
+    in-tree one built from exactly the sources next to it (then the headers hashed below ARE its headers), its own source hash / path."""
+    L = N.lib()
+    try:
+        with open(N.SO_PATH + ".srchash") as f:
+            srchash = f.read().strip()
+    except OSError:
+        srchash = "no-srchash"
+    in_tree = not os.environ.get("BNN_CHAOS_SO") and srchash == _build.source_hash()
+    origin = "in-tree" if in_tree else f"{os.path.abspath(N.SO_PATH)}:{srchash}"
+    return f"abi{L.bnn_abi_version()}:genparams{L.bnn_gen_params_bytes()}:{L.bnn_build_flags().decode()}:{origin}"
+
+
+def _hash_deps(h):
     h.update(_compiler_id().encode())
+    h.update(_library_id().encode())
     for name in _DEPS:   # the kernel source the generated file includes
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
+
+
+def _key(src):
+    h = hashlib.sha256(src.encode())
+    h.update(" ".join(SPEC_FLAGS + _extra_flags()).encode())
+    _hash_deps(h)
     return h.hexdigest()[:20]
 
 
@@ -183,7 +218,8 @@ def best_variant(arch, noisy, w8=None, verbose=False, measure=None):
             if verbose:
                 print("candidate failed:", info, e)
     if not timed:
-        return cands[0]
+        raise RuntimeError("none of the network's specialised forms could be loaded and timed on this GPU "
+                           f"({len(cands)} candidate(s)); the plan keeps its ahead-of-time form")
     fastest = min(t[0] for t in timed)
     timed.sort(key=lambda t: (t[0] > 1.03 * fastest, [id(c[0]) for c in cands].index(id(t[1]))))   # within 3 % of the fastest: the static order decides
     info = dict(timed[0][2], tuned_ms=round(timed[0][0] * 1e3, 3),
@@ -215,11 +251,16 @@ def prewarm(archs, noisy=(False, True), w8=(None,), jobs=None):
     return [(j[0], j[2], j[3], i) for j, i in zip(jobs_, infos)]
 
 
-def _measure_on(plan, nz):
-    """Times one attached candidate on a synthetic grid shaped like BASELINE configs[1] cut to 96 draws (10 000 systems x 100 timesteps:
-    1 920 workgroups of up to 512 systems, the last of each draw ragged; in-kernel Philox): seconds."""
+def _measure_on(live_plan, nz):
+    """Times one candidate on a synthetic grid shaped like BASELINE configs[1] cut to 96 draws (10 000 systems x 100 timesteps:
+    1 920 workgroups of up to 512 systems, the last of each draw ragged; in-kernel Philox): seconds.
+    The candidates are attached to a PRIVATE plan of the same network on the same device: the live plan is shared by every model and
+    thread of the process (ops._plans) and keeps launching whatever it had while the tuning runs; only the winner is swapped in."""
     import torch
     from . import ops
+    a = live_plan.arch
+    plan = N.Plan(int(a.zero_mask), float(a.lowest_std), n_features=a.n_features, hidden=a.hidden, latent=a.latent, fix_megno=bool(a.fix_megno),
+                  depth_in=a.depth_in, depth_out=a.depth_out)
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(10000, 100, plan.n_features, generator=g, device="cuda")
     W = torch.randn(96, plan.d, generator=g, device="cuda") * 0.1
@@ -231,7 +272,7 @@ def _measure_on(plan, nz):
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0.record()
             for _ in range(8):
-                ops.forward(x, W, philox_seed=1, plan=plan, noisy=nz, engine="spec")
+                ops.forward(x, W, philox_seed=1, plan=plan, noisy=nz, engine="spec", assume_finite=True)
             t1.record()
             t1.synchronize()
             if rep:
@@ -242,10 +283,8 @@ def _measure_on(plan, nz):
 
 def _choice_path(arch, nz, w8):
     import ctypes as C
-    h = hashlib.sha256(bytes(C.string_at(C.addressof(arch), C.sizeof(arch))) + repr((bool(nz), w8, _compiler_id())).encode())
-    for name in _DEPS:
-        with open(os.path.join(CSRC, name), "rb") as f:
-            h.update(f.read())
+    h = hashlib.sha256(bytes(C.string_at(C.addressof(arch), C.sizeof(arch))) + repr((bool(nz), w8)).encode())
+    _hash_deps(h)
     return os.path.join(cache_dir(), f"choice_{h.hexdigest()[:20]}.json")
 
 

@@ -18,6 +18,7 @@ seed to fp32 rounding.  With `rng = "philox"` the kernels generate counter-based
 (no noise tensors in HBM); set `philox_seed` for reproducibility.
 """
 import random
+import warnings
 from collections import OrderedDict
 from copy import deepcopy as copy  # noqa: F401  (the reference module exports it: spock_reg_model.py, `from copy import deepcopy as copy`)
 
@@ -317,6 +318,17 @@ class VarModel:
         if spec is not None and plan.__dict__.get("_spec_req") != spec and not (plan.v50net and not self.fix_megno):
             ops.specialize(plan, noisy=spec[0], w8=spec[1])   # (the pretrained network has its forms in the library: nothing to compile)
             plan.__dict__["_spec_req"] = spec                  # once per plan
+        elif spec is None and not plan.v50net and not plan.__dict__.get("_warned_generic") and not (plan.spec_attached(False) or plan.spec_attached(True)):
+            # Every shape the reference's CLI defaults produce (parse_swag_args.py:11-16, find_minima.py:33-65: hidden 40, latent 20,
+            # in = out = 1, any mask, --megno) has hand-scheduled kernels in the library.  Other widths / depths run on the ahead-of-time
+            # generic engine -- correct to the same bits, but at 0.3-0.6 of the fp32 matrix roof; say so once, with the way out.
+            plan.__dict__["_warned_generic"] = True
+            a = self._arch
+            warnings.warn(f"bnn_chaos_model_amd: the network hidden={a['hidden']} latent={a['latent']} in={a['depth_in']} out={a['depth_out']} "
+                          f"features={a['n_features']} runs on the ahead-of-time generic forward engine (about 0.3-0.6 of the fp32 matrix "
+                          "roof, against 0.9 for the pretrained shapes).  model.specialize() -- or BNN_AUTO_SPECIALIZE=1 -- compiles this "
+                          "network's own form once (hipcc, ~10 s, cached on disk; 0.73-0.88; bit-identical results).  Without a compiler on "
+                          "the machine the ahead-of-time form is what runs.", GenericEngineWarning, stacklevel=3)
         return plan
 
     @property
@@ -457,6 +469,10 @@ class VarModel:
         return np.average(all_samp, axis=0)
 
 
+class GenericEngineWarning(UserWarning):
+    """A network other than the pretrained shapes is running un-specialised (DESIGN.md sections 4.9 / 4.10)."""
+
+
 class SWAGModel(VarModel):
     """SWAG posterior over the weights (reference :689-908), inference half."""
 
@@ -572,5 +588,5 @@ def load_swag(path):
     return swag_model
 
 
-__all__ = ["EPSILON", "VarModel", "SWAGModel", "StandardScaler", "load_swag", "save_swag", "soft_clamp", "mlp",
+__all__ = ["EPSILON", "VarModel", "SWAGModel", "GenericEngineWarning", "StandardScaler", "load_swag", "save_swag", "soft_clamp", "mlp",
            "AttributeDict", "copy"]

@@ -89,7 +89,9 @@ int bnn_plan_destroy(bnn_plan* plan);
  * of every entry point launches it for that `noisy` form.  w8: 1 = eight waves at 256 registers, 0 = at most four at 512,
  * -1 = the builder's choice -- the same w8 and flags must be given to both calls.  The quiet forms are compiled for the plan's column
  * mask as well (layer 0 multiplies the unmasked columns only).  Results are bit-identical to the ahead-of-time form's
- * (same accumulation order); what changes is the schedule. */
+ * (same accumulation order); what changes is the schedule.  Replacing an attached form synchronises the device first (launches of
+ * the old form may still be queued); callers that tune over several candidates should do so on a plan of their own (specialize.py does)
+ * and attach only the winner to a plan other threads are launching on. */
 #define BNN_SPEC_POOL_REGS 1 /* flags: the pool's Welford state in registers across the tiles (else in LDS); a tuning choice -- the caller
                                 compiles, looks at the code object's scratch size and falls back (specialize.py does) */
 #define BNN_SPEC_BLOCK_MAJOR 2 /* flags: the ahead-of-time form's block-major layer routine (fewest registers: the widest networks) instead of

@@ -3,7 +3,7 @@
 # Appends JSON lines to gpurun_out/r4_spec_bench.jsonl and prints a one-line summary each.
 set -o pipefail
 mkdir -p gpurun_out
-export BNN_SPEC_CACHE=${BNN_SPEC_CACHE:-/tmp/bnn_spec_cache}
+export BNN_SPEC_CACHE=${BNN_SPEC_CACHE:-$R/bnn_chaos_model_amd/csrc/_spec}   # in-tree (private to the checkout), never a predictable world-writable /tmp path
 run() {
   timeout -k 10 400 python bench.py $1 --no-cpu-baseline > gpurun_out/r4_spec_bench.tmp 2> gpurun_out/r4_spec_bench.err || { echo "FAILED: $1"; tail -5 gpurun_out/r4_spec_bench.err; exit 1; }
   python - "$1" <<'PY'

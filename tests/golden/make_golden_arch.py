@@ -35,6 +35,7 @@ CASES = {
     "h48megno": (dict(hidden=48, latent=12, fix_megno=True, fix_megno2=False), dict(), 12),
     "h128l32": (dict(hidden=128, latent=32, lower_std=True), dict(K=6), 8),
     "allcols": (dict(hidden=16, latent=4, include_mmr=True, include_nan=True, include_eplusminus=True, fix_megno2=False), dict(K=5), 8),
+    "lin0out8": (dict(hidden=24, latent=8, **{"in": 0, "out": 8}), dict(K=8), 8),   # regress_nn alone holds 10 of the 11 Linear modules
 }
 
 

@@ -221,6 +221,27 @@ def test_checkpoint_roundtrip_and_reference_file(tmp_path):
         assert it["hparams"].hidden == 40
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference (build container only)")
+def test_save_swag_file_loads_in_the_unmodified_reference(tmp_path):
+    """f3 from the reference's side: a checkpoint written by OUR save_swag (spock_reg_model.py:911-920), read by the REFERENCE's
+    load_swag (:922-967), holds the same tensors / hparams / swa_params / K / c, and one reference forward_swag_fast on it reproduces
+    the reference's own fixture bit for bit (tests/golden/check_save_swag_in_reference.py, run in a subprocess so that the reference
+    module never enters this process)."""
+    import subprocess
+    import sys
+    from bnn_chaos_model_amd import spock_reg_model as srm
+    z = load_golden("swag_v50_12.npz")
+    m = srm.SWAGModel(json.loads(str(z["hparams_json"]))).init_params(json.loads(str(z["swa_params_json"])))
+    m.w_avg, m.w2_avg, m.pre_D = torch.tensor(z["w_avg"]), torch.tensor(z["w2_avg"]), torch.tensor(z["pre_D"])
+    path = str(tmp_path / "steps=300000_v50_12_output.pkl")
+    srm.save_swag(m, path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "check_save_swag_in_reference.py"), path, "12"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["ok"] and all(rep["checks"].values()) and len(rep["checks"]) >= 10
+
+
 def test_constructor_reproduces_reference_side_effects(tmp_path):
     """load_swag -> SWAGModel(hparams): seed_everything(seed) + the reference's module init order (spock_reg_model.py:343-362)."""
     from bnn_chaos_model_amd import checkpoint, spock_reg_model as srm
@@ -448,3 +469,8 @@ def test_headline_kernels_use_no_scratch(N):
     assert sorted(emb) == ["bnn_spec_forward_v50n", "bnn_spec_forward_v50q"]
     for k in emb.values():
         assert k["vgpr"] <= 256 and k["agpr"] == 0 and k["scratch"] == 0 and k["vgpr_spills"] == 0 and 0 < k["lds"] <= 80 * 1024, k
+    # the non-finite scan streams x at the copy rate: few registers (many waves in flight), no scratch; the exact re-evaluation likewise
+    nf = {k["name"]: k for k in ks if "bnn_nonfinite_" in k["name"]}
+    assert sorted(n.split("::")[-1] for n in nf) == ["bnn_nonfinite_fixup_kernel", "bnn_nonfinite_reset_kernel", "bnn_nonfinite_scan_kernel"]
+    assert all(k["scratch"] == 0 and k["vgpr_spills"] == 0 for k in nf.values())
+    assert [k for n, k in nf.items() if n.endswith("scan_kernel")][0]["vgpr"] <= 64

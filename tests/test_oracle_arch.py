@@ -9,7 +9,7 @@ import pytest
 from conftest import close_report, load_golden
 from oracle import oracle as orc
 
-CASES = ("h64l16", "h20l10", "h33l7", "deep22", "deep30", "lin00", "deriv82", "k40", "h48megno", "h128l32", "allcols")
+CASES = ("h64l16", "h20l10", "h33l7", "deep22", "deep30", "lin00", "deriv82", "k40", "h48megno", "h128l32", "allcols", "lin0out8")
 TLENS = (2, 3, 5, 6, 7, 99)
 
 

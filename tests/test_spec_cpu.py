@@ -99,6 +99,39 @@ def test_compile_cache_and_resource_report(N, tmp_path, monkeypatch):
     assert S.rank_static([fake(False, 1, 0, lds=120000, vgpr=250, agpr=200), fake(False, 1, 0, lds=60000, vgpr=170, agpr=50)])[0][1]["lds"] == 60000   # two four-wave workgroups per CU beat one
 
 
+def test_cache_is_private_and_keyed_by_the_loaded_library(N, tmp_path, monkeypatch):
+    """Code objects are loaded from the cache unchecked, and a specialised kernel takes the library's GenParams block by value: the
+    cache directory must be the user's own (not writable by group / others), and the key must name the library the code object was
+    compiled against (ABI version, sizeof(GenParams), the .so's source hash, its build flags)."""
+    import os
+    from bnn_chaos_model_amd import specialize as S
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    monkeypatch.setenv("BNN_SPEC_CACHE", str(shared))
+    with pytest.raises(RuntimeError, match="private"):
+        S.cache_dir()
+    mine = tmp_path / "mine" / "nested"
+    monkeypatch.setenv("BNN_SPEC_CACHE", str(mine))
+    assert S.cache_dir() == str(mine) and (os.stat(mine).st_mode & 0o077) == 0          # created 0700
+    lid = S._library_id()
+    L = N.lib()
+    assert f"abi{L.bnn_abi_version()}" in lid and f"genparams{L.bnn_gen_params_bytes()}" in lid and L.bnn_gen_params_bytes() > 300
+    src = N.spec_source(arch(N), False, True, N.SPEC_POOL_REGS)
+    k0 = S._key(src)
+    monkeypatch.setattr(S, "_library_id", lambda: lid + ":another-build")
+    assert S._key(src) != k0 and S._choice_path(arch(N), False, None) != ""            # another library: another cache entry
+    # a tuning run in which no candidate can be timed raises instead of handing back an untested form
+    monkeypatch.undo()
+    monkeypatch.setenv("BNN_SPEC_CACHE", str(mine))
+    monkeypatch.setattr(S, "candidates", lambda *a, **k: [(b"x", dict(w8=True, flags=1, scratch=0, lds=1, vgpr=1, agpr=0, nwaves=8)),
+                                                           (b"y", dict(w8=False, flags=1, scratch=0, lds=1, vgpr=1, agpr=0, nwaves=4))])
+    def boom(image, info):
+        raise RuntimeError("does not load")
+    with pytest.raises(RuntimeError, match="could be loaded and timed"):
+        S.best_variant(arch(N), False, measure=boom)
+
+
 def test_embedded_unit_matches_its_generator(N):
     """csrc/bnn_fwd_v50spec.hip (the pretrained network's two specialised forms, compiled into the library) is generated text: the
     committed file must be what the library's generator writes today (scripts/regen_embedded.py rewrites it)."""
