@@ -87,7 +87,7 @@ json.dump(acc, open(os.path.join(dst, "r05_issue_accounting.json"), "w"), indent
 
 dom = [k for k in out if "forward_kernel" in k]
 traffic = {}
-old = os.path.join("profiles", "pmc_traffic.json")
+old = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "profiles", "pmc_traffic.json")
 if os.path.exists(old):
     try:
         traffic = json.load(open(old))
