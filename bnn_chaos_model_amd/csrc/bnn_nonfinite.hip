@@ -90,6 +90,10 @@ DEVINL void nf_merge(float& na, float& ma, float& qa, float nb, float mb, float 
     na = n;
 }
 
+// WLDS: the draw's flat parameter vector sits in LDS (the in-prologue draw has no other place for it: 30 KB, two workgroups per CU);
+// otherwise it is read where it is, W[e] in global memory -- wave-uniform addresses, i.e. SCALAR loads (s_load_dwordx4 through the
+// constant cache and L2), 34 KB of LDS per one-wave workgroup for the pretrained shapes and four of them per CU.
+template <bool WLDS>
 __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams q) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FwdParams& p = q.f;
@@ -134,10 +138,15 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
             continue;
         }
         // the draw's flat parameter vector: materialised (workspace / VarModel.forward), or sampled here like the forward kernel's prologue
-        const float* wv;
+        const float* __restrict__ wv;
         bool bad_seed = false;
-        if (p.W) {
+        if constexpr (!WLDS) {
             wv = p.W + (int64_t)e * d;
+        } else if (p.W) {
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < d; i += 64) flat[i] = p.W[(int64_t)e * d + i];
+            __builtin_amdgcn_wave_barrier();
+            wv = flat;
         } else {
             int s = p.seed_idx[e];
             bad_seed = (s < 0 || s >= p.S);
@@ -191,14 +200,26 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
             }
             float* cur = actA;
             float* nxt = actB;
-            for (int l = 0; l < G.n_feat; ++l) {   // feature_nn (:359, :417): bias, then the inputs ascending
-                const GenLayer ly = G.layer[l];
-                const float* wl = wv + ly.off_w;
-                for (int n = 0; n < ly.N; ++n) {
-                    float acc = wv[ly.off_b + n];
-                    const float* wr = wl + (int64_t)n * ly.K;
-                    for (int k = 0; k < ly.K; ++k) acc = fmaf(wr[k], cur[k * 64 + lane], acc);
-                    nxt[n * 64 + lane] = ly.relu ? relu_ieee(acc) : acc;
+            for (int l = 0; l < G.n_feat; ++l) {   // feature_nn (:359, :417): bias, then the inputs ascending -- four neurons at a time: four
+                const GenLayer ly = G.layer[l];    // independent fmaf chains share one activation read (a lone chain waits out every latency)
+                const int K = ly.K, N = ly.N;
+                for (int n0 = 0; n0 < N; n0 += 4) {
+                    const float* __restrict__ w0 = wv + ly.off_w + (int64_t)n0 * K;
+                    const float* __restrict__ w1 = wv + ly.off_w + (int64_t)(n0 + 1 < N ? n0 + 1 : N - 1) * K;
+                    const float* __restrict__ w2 = wv + ly.off_w + (int64_t)(n0 + 2 < N ? n0 + 2 : N - 1) * K;
+                    const float* __restrict__ w3 = wv + ly.off_w + (int64_t)(n0 + 3 < N ? n0 + 3 : N - 1) * K;
+                    float a0 = wv[ly.off_b + n0], a1 = wv[ly.off_b + (n0 + 1 < N ? n0 + 1 : N - 1)], a2 = wv[ly.off_b + (n0 + 2 < N ? n0 + 2 : N - 1)],
+                          a3 = wv[ly.off_b + (n0 + 3 < N ? n0 + 3 : N - 1)];
+#pragma unroll 4
+                    for (int k = 0; k < K; ++k) {
+                        const float xk = cur[k * 64 + lane];
+                        a0 = fmaf(w0[k], xk, a0); a1 = fmaf(w1[k], xk, a1); a2 = fmaf(w2[k], xk, a2); a3 = fmaf(w3[k], xk, a3);
+                    }
+                    if (ly.relu) { a0 = relu_ieee(a0); a1 = relu_ieee(a1); a2 = relu_ieee(a2); a3 = relu_ieee(a3); }
+                    nxt[n0 * 64 + lane] = a0;
+                    if (n0 + 1 < N) nxt[(n0 + 1) * 64 + lane] = a1;
+                    if (n0 + 2 < N) nxt[(n0 + 2) * 64 + lane] = a2;
+                    if (n0 + 3 < N) nxt[(n0 + 3) * 64 + lane] = a3;
                 }
                 float* tmp = cur; cur = nxt; nxt = tmp;
             }
@@ -270,24 +291,32 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
     }
 }
 
-size_t nonfinite_fixup_lds_bytes(const GenArch& g, bool fused) {
+size_t nonfinite_fixup_lds_bytes(const GenArch& g, bool wlds) {
     int maxw = g.F;
     for (int l = 0; l < g.n_feat; ++l) maxw = g.layer[l].N > maxw ? g.layer[l].N : maxw;
-    return sizeof(float) * ((size_t)2 * maxw * 64 + (size_t)2 * (g.L + 1) * 64 + 3 * 128 + 256 + (fused ? (size_t)g.d : 0));
+    return sizeof(float) * ((size_t)2 * maxw * 64 + (size_t)2 * (g.L + 1) * 64 + 3 * 128 + 256 + (wlds ? (size_t)g.d : 0));
 }
 
 hipError_t launch_nonfinite_fixup(const GenArch& g, NfxParams& q, hipStream_t st) {
     int maxw = g.F;
     for (int l = 0; l < g.n_feat; ++l) maxw = g.layer[l].N > maxw ? g.layer[l].N : maxw;
     q.maxw = maxw;
+    // the flat vector in LDS only where there is no other place for it (the in-prologue draw): with W[e] in global memory the 34 KB
+    // workgroup fits four times on a CU and measured 6.9e6 (row, system) evaluations/s against 4.6e6 with the weights in LDS (two
+    // workgroups per CU, LDS-issue bound) -- and 1.7e6 for the first version (one fmaf chain at a time, generic-pointer loads)
     const bool fused = q.f.W == nullptr;
     const size_t lds = nonfinite_fixup_lds_bytes(g, fused);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    allow_big_lds<bnn_nonfinite_fixup_kernel>();
     // the list's length is known on the device only: a fixed grid walks it (every workgroup leaves at once when it is empty)
     const int64_t items = (int64_t)(q.f.J / q.f.nch) * q.f.B;
-    const unsigned nblk = (unsigned)(items < 2048 ? (items > 0 ? items : 1) : 2048);
-    hipLaunchKernelGGL(bnn_nonfinite_fixup_kernel, dim3(nblk), dim3(64), lds, st, q);
+    const unsigned nblk = (unsigned)(items < 4096 ? (items > 0 ? items : 1) : 4096);
+    if (fused) {
+        allow_big_lds<bnn_nonfinite_fixup_kernel<true>>();
+        hipLaunchKernelGGL(bnn_nonfinite_fixup_kernel<true>, dim3(nblk), dim3(64), lds, st, q);
+    } else {
+        allow_big_lds<bnn_nonfinite_fixup_kernel<false>>();
+        hipLaunchKernelGGL(bnn_nonfinite_fixup_kernel<false>, dim3(nblk), dim3(64), lds, st, q);
+    }
     return hipGetLastError();
 }
 
