@@ -207,3 +207,29 @@ def test_another_network_through_the_batched_drivers(tmp_path):
     np.random.seed(5)
     c = fr.predictive_bands(X, samples=32, chunks=5, trios=3, philox_seed=8, samples_per_launch=8, devices=[0, 0])
     assert torch.equal(a["percentiles"], c["percentiles"])
+
+
+@pytest.mark.gpu
+def test_rccl_branch_executes_at_world_size_one():
+    """multidevice._rccl_all_gather -- communicator creation inside the process, the padded all-gather, the trim -- on a one-device list:
+    the code path a multi-GPU node takes with BNN_MULTIDEVICE_EXCHANGE=rccl, executed on the one card this box has.  (Between distinct
+    GPUs it has not run from this environment: the exchange defaults to peer copies.)"""
+    from bnn_chaos_model_amd import multidevice as md
+    rows = torch.arange(28, dtype=torch.float64, device="cuda").reshape(7, 4)
+    try:
+        out = md._rccl_all_gather([rows])
+    except md.RcclUnavailable as e:
+        pytest.skip(f"torch.cuda.nccl is not available in this build: {e}")
+    torch.cuda.synchronize()
+    assert out.shape == (7, 4) and torch.equal(out, rows) and out.device == rows.device
+    # float32 payload (the bands) and a second call on the cached communicator
+    bands = torch.randn(5, 6, device="cuda")
+    assert torch.equal(md._rccl_all_gather([bands]), bands)
+    # through the DeviceSet with the RCCL exchange asked for: one shard needs no exchange; two shards on one card fall back, and say why
+    ds = md.DeviceSet([0], exchange="rccl")
+    assert torch.equal(ds.gather_rows([rows]), rows) and ds.last_exchange == "none (one shard)"
+    ds2 = md.DeviceSet([0, 0], exchange="rccl")
+    got = ds2.gather_rows([rows[:4], rows[4:]])
+    assert torch.equal(got, rows) and "more than once" in ds2.last_exchange
+    with pytest.raises(ValueError):
+        md.DeviceSet([0], exchange="smoke signals")
