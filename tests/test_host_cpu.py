@@ -471,6 +471,7 @@ def test_headline_kernels_use_no_scratch(N):
         assert k["vgpr"] <= 256 and k["agpr"] == 0 and k["scratch"] == 0 and k["vgpr_spills"] == 0 and 0 < k["lds"] <= 80 * 1024, k
     # the non-finite scan streams x at the copy rate: few registers (many waves in flight), no scratch; the exact re-evaluation likewise
     nf = {k["name"]: k for k in ks if "bnn_nonfinite_" in k["name"]}
-    assert sorted(n.split("::")[-1] for n in nf) == ["bnn_nonfinite_fixup_kernel", "bnn_nonfinite_reset_kernel", "bnn_nonfinite_scan_kernel"]
+    assert sorted(n.split("::")[-1] for n in nf) == ["bnn_nonfinite_fixup_kernel<false>", "bnn_nonfinite_fixup_kernel<true>", "bnn_nonfinite_reset_kernel",
+                                                     "bnn_nonfinite_scan_kernel"]
     assert all(k["scratch"] == 0 and k["vgpr_spills"] == 0 for k in nf.values())
     assert [k for n, k in nf.items() if n.endswith("scan_kernel")][0]["vgpr"] <= 64
