@@ -90,6 +90,20 @@ DEVINL void nf_merge(float& na, float& ma, float& qa, float nb, float mb, float 
     na = n;
 }
 
+// Loads through the constant address space: for a wave-uniform address the compiler emits SCALAR loads (s_load_dwordx8 / x16 into SGPRs,
+// which v_fmac reads directly) instead of one vector load per weight and lane.  W[e] was written by an earlier kernel (the draw) or by
+// the caller, never by this one, so the scalar cache's lack of coherence with this kernel's own stores does not matter.
+typedef const float __attribute__((address_space(4))) cfloat4;
+DEVINL const cfloat4* as_constant(const float* p) { return (const cfloat4*)(uintptr_t)p; }
+// the plan's descriptor likewise: every shape, offset and flag it holds is wave-uniform and lands in SGPRs
+typedef const GenArch __attribute__((address_space(4))) GenArch4;
+struct NfLayer { int K, N, off_w, off_b, relu; };
+DEVINL NfLayer nf_layer(const GenArch4* g, int l) {
+    NfLayer y;
+    y.K = g->layer[l].K; y.N = g->layer[l].N; y.off_w = g->layer[l].off_w; y.off_b = g->layer[l].off_b; y.relu = g->layer[l].relu;
+    return y;
+}
+
 // WLDS: the draw's flat parameter vector sits in LDS (the in-prologue draw has no other place for it: 30 KB, two workgroups per CU);
 // otherwise it is read where it is, W[e] in global memory -- wave-uniform addresses, i.e. SCALAR loads (s_load_dwordx4 through the
 // constant cache and L2), 34 KB of LDS per one-wave workgroup for the pretrained shapes and four of them per CU.
@@ -97,10 +111,12 @@ template <bool WLDS>
 __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams q) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FwdParams& p = q.f;
-    const GenArch& G = *q.g;
+    const GenArch4* Gc = (const GenArch4*)(uintptr_t)q.g;
+    struct { int F, L, SM, d, megno, n_feat, n_reg, nin_blocks, off_inlv, off_sumlv; } G = {Gc->F, Gc->L, Gc->SM, Gc->d, Gc->megno, Gc->n_feat, Gc->n_reg,
+                                                                                            Gc->nin_blocks, Gc->off_inlv, Gc->off_sumlv};
     const int lane = threadIdx.x;
     const int F = G.F, L = G.L, SM = G.SM, d = G.d, T = p.T;
-    const int count = q.rec[0];
+    const int count = __builtin_amdgcn_readfirstlane(q.rec[0]);
     const int R = p.J / p.nch;
     const int64_t total = (int64_t)R * count;
     if (total == 0) return;
@@ -117,7 +133,7 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
     const float qnan = __builtin_nanf("");
 
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
-        const int32_t ent = q.rec[4 + (int)(w % count)];
+        const int32_t ent = __builtin_amdgcn_readfirstlane(q.rec[4 + (int)(w % count)]);   // (wave-uniform: keeps the draw's address scalar)
         const int64_t r = w / count, b = ent >> 1;
         const int ch = (int)((p.coff + b) / p.csz);
         const int e = (int)r * p.nch + ch;
@@ -201,16 +217,16 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
             float* cur = actA;
             float* nxt = actB;
             for (int l = 0; l < G.n_feat; ++l) {   // feature_nn (:359, :417): bias, then the inputs ascending -- four neurons at a time: four
-                const GenLayer ly = G.layer[l];    // independent fmaf chains share one activation read (a lone chain waits out every latency)
+                const NfLayer ly = nf_layer(Gc, l);   // independent fmaf chains share one activation read (a lone chain waits out every latency)
                 const int K = ly.K, N = ly.N;
-                for (int n0 = 0; n0 < N; n0 += 4) {
-                    const float* __restrict__ w0 = wv + ly.off_w + (int64_t)n0 * K;
-                    const float* __restrict__ w1 = wv + ly.off_w + (int64_t)(n0 + 1 < N ? n0 + 1 : N - 1) * K;
-                    const float* __restrict__ w2 = wv + ly.off_w + (int64_t)(n0 + 2 < N ? n0 + 2 : N - 1) * K;
-                    const float* __restrict__ w3 = wv + ly.off_w + (int64_t)(n0 + 3 < N ? n0 + 3 : N - 1) * K;
-                    float a0 = wv[ly.off_b + n0], a1 = wv[ly.off_b + (n0 + 1 < N ? n0 + 1 : N - 1)], a2 = wv[ly.off_b + (n0 + 2 < N ? n0 + 2 : N - 1)],
-                          a3 = wv[ly.off_b + (n0 + 3 < N ? n0 + 3 : N - 1)];
-#pragma unroll 4
+                auto four = [&](auto wbase, int n0) {   // wbase: the flat vector through the address space it lives in
+                    const auto w0 = wbase + ly.off_w + (int64_t)n0 * K;
+                    const auto w1 = wbase + ly.off_w + (int64_t)(n0 + 1 < N ? n0 + 1 : N - 1) * K;
+                    const auto w2 = wbase + ly.off_w + (int64_t)(n0 + 2 < N ? n0 + 2 : N - 1) * K;
+                    const auto w3 = wbase + ly.off_w + (int64_t)(n0 + 3 < N ? n0 + 3 : N - 1) * K;
+                    float a0 = wbase[ly.off_b + n0], a1 = wbase[ly.off_b + (n0 + 1 < N ? n0 + 1 : N - 1)],
+                          a2 = wbase[ly.off_b + (n0 + 2 < N ? n0 + 2 : N - 1)], a3 = wbase[ly.off_b + (n0 + 3 < N ? n0 + 3 : N - 1)];
+#pragma unroll 8
                     for (int k = 0; k < K; ++k) {
                         const float xk = cur[k * 64 + lane];
                         a0 = fmaf(w0[k], xk, a0); a1 = fmaf(w1[k], xk, a1); a2 = fmaf(w2[k], xk, a2); a3 = fmaf(w3[k], xk, a3);
@@ -220,6 +236,10 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
                     if (n0 + 1 < N) nxt[(n0 + 1) * 64 + lane] = a1;
                     if (n0 + 2 < N) nxt[(n0 + 2) * 64 + lane] = a2;
                     if (n0 + 3 < N) nxt[(n0 + 3) * 64 + lane] = a3;
+                };
+                for (int n0 = 0; n0 < N; n0 += 4) {
+                    if constexpr (WLDS) four(wv, n0);
+                    else four(as_constant(wv), n0);
                 }
                 float* tmp = cur; cur = nxt; nxt = tmp;
             }
@@ -276,11 +296,17 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
         float* cur = ra;
         float* nxt = rb;
         for (int l = G.n_feat; l < G.n_feat + G.n_reg; ++l) {   // regress_nn (:360, :438): lane = neuron
-            const GenLayer ly = G.layer[l];
+            const NfLayer ly = nf_layer(Gc, l);
             for (int n = lane; n < ly.N; n += 64) {
                 float acc = wv[ly.off_b + n];
-                const float* wr = wv + ly.off_w + (int64_t)n * ly.K;
-                for (int k = 0; k < ly.K; ++k) acc = fmaf(wr[k], cur[k], acc);
+                const float* __restrict__ wr = wv + ly.off_w + (int64_t)n * ly.K;
+                int k = 0;
+#pragma unroll 4
+                for (; k + 4 <= ly.K; k += 4) {   // the lane's weight row, 16 bytes at a time (several loads in flight: a load per fmaf would serialise the chain)
+                    const f32x4 w4 = *reinterpret_cast<const f32x4u*>(wr + k);
+                    acc = fmaf(w4.x, cur[k], acc); acc = fmaf(w4.y, cur[k + 1], acc); acc = fmaf(w4.z, cur[k + 2], acc); acc = fmaf(w4.w, cur[k + 3], acc);
+                }
+                for (; k < ly.K; ++k) acc = fmaf(wr[k], cur[k], acc);
                 nxt[n] = ly.relu ? relu_ieee(acc) : acc;
             }
             __builtin_amdgcn_wave_barrier();
