@@ -153,18 +153,30 @@ __global__ void bnn_sketch_update_kernel(const float* __restrict__ tv, int64_t R
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_sims) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int64_t r = 0; r < R; ++r) {
-        const float* p = tv + r * B + i * group;
-        float v = p[0];
-        for (int j = 1; j < group; ++j) {
-            const float w = p[j];
-            v = (w < v || w != w) ? w : v;  // np.min propagates NaN
+    constexpr int PF = 4;   // rows fetched ahead of their use: the loop is a chain of memory round trips otherwise (R of them per simulation)
+    for (int64_t r0 = 0; r0 < R; r0 += PF) {
+        float vv[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int64_t r = r0 + u < R ? r0 + u : R - 1;
+            const float* p = tv + r * B + i * group;
+            float v = p[0];
+            for (int j = 1; j < group; ++j) {
+                const float w = p[j];
+                v = (w < v || w != w) ? w : v;  // np.min propagates NaN
+            }
+            vv[u] = v;
         }
-        // no-return atomic: fire and forget (a plain load-add-store would chain every draw of the slab behind a memory round trip);
-        // one thread owns the simulation, so there is no contention
-        atomicAdd(&hist[(int64_t)sketch_bin(sk, v) * n_sims + i], 1u);
-        s1 += (double)v;
-        s2 += (double)v * (double)v;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (r0 + u >= R) break;
+            const float v = vv[u];
+            // no-return atomic: fire and forget (a plain load-add-store would chain every draw of the slab behind a memory round trip);
+            // one thread owns the simulation, so there is no contention
+            atomicAdd(&hist[(int64_t)sketch_bin(sk, v) * n_sims + i], 1u);
+            s1 += (double)v;
+            s2 += (double)v * (double)v;
+        }
     }
     mom[2 * i] += s1;
     mom[2 * i + 1] += s2;
@@ -178,7 +190,16 @@ __global__ void bnn_sketch_quantiles_kernel(const uint32_t* __restrict__ hist, i
     if (i >= n_sims) return;
     uint64_t total = 0;
     const int nb = sk.nbins - 1;  // value bins; bin nb counts the NaN draws
-    for (int b = 0; b < nb; ++b) total += hist[(int64_t)b * n_sims + i];
+    // Both passes fetch the counters EIGHT bins ahead of their use: with one load per iteration and a branch on its value each of the 2 x 945
+    // iterations waited out a memory round trip (1.8 ms for 125 000 simulations: latency, not bandwidth).  Same arithmetic, same order.
+    constexpr int PF = 8;
+    for (int b0 = 0; b0 < nb; b0 += PF) {
+        uint32_t v[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) v[j] = hist[(int64_t)(b0 + j < nb ? b0 + j : nb - 1) * n_sims + i];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) total += (b0 + j < nb) ? v[j] : 0u;
+    }
     if (total == 0 || hist[(int64_t)nb * n_sims + i] != 0) {
         for (int k = 0; k < qp.nq; ++k) out[i * qp.nq + k] = __builtin_nanf("");
         return;
@@ -195,24 +216,31 @@ __global__ void bnn_sketch_quantiles_kernel(const uint32_t* __restrict__ hist, i
     }
     uint64_t c = 0;
     int seg = 0, kin = 0;  // position of bin b inside its segment
-    for (int b = 0; b < nb; ++b) {
-        const uint32_t n = hist[(int64_t)b * n_sims + i];
-        double edge, width;
-        if (b == 0) { edge = sk.lo[0]; width = 0.0; }
-        else {
-            while (b >= sk.base[seg] + sk.n[seg]) ++seg;
-            kin = b - sk.base[seg];
-            width = ((double)sk.hi[seg] - (double)sk.lo[seg]) / (double)sk.n[seg];
-            edge = (double)sk.lo[seg] + width * kin;
-        }
-        if (n) {
+    for (int b0 = 0; b0 < nb; b0 += PF) {
+        uint32_t v[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) v[j] = hist[(int64_t)(b0 + j < nb ? b0 + j : nb - 1) * n_sims + i];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int b = b0 + j;
+            if (b >= nb) break;
+            const uint32_t n = v[j];
+            if (!n) continue;   // (an empty bin holds no order statistic; `seg` catches up at the next occupied one)
+            double edge, width;
+            if (b == 0) { edge = sk.lo[0]; width = 0.0; }
+            else {
+                while (b >= sk.base[seg] + sk.n[seg]) ++seg;
+                kin = b - sk.base[seg];
+                width = ((double)sk.hi[seg] - (double)sk.lo[seg]) / (double)sk.n[seg];
+                edge = (double)sk.lo[seg] + width * kin;
+            }
             for (int k = 0; k < qp.nq; ++k) {
                 const int64_t a = klo[k], a1 = (a + 1 < (int64_t)total) ? a + 1 : a;
                 if (a >= (int64_t)c && a < (int64_t)(c + n)) vlo[k] = edge + width * ((double)(a - (int64_t)c) + 0.5) / (double)n;
                 if (a1 >= (int64_t)c && a1 < (int64_t)(c + n)) vhi[k] = edge + width * ((double)(a1 - (int64_t)c) + 0.5) / (double)n;
             }
+            c += n;
         }
-        c += n;
     }
     for (int k = 0; k < qp.nq; ++k) out[i * qp.nq + k] = (float)(vlo[k] + (vhi[k] - vlo[k]) * frac[k]);
 }
