@@ -317,6 +317,7 @@ def clock_sample_under_load(dev_index, enqueue_steps, n_steps=2, period_s=0.02):
     power-limited under this kernel and holds 2.26-2.34 GHz): with the held clock in the line a swing reads as "box", not "regression".
     Returns None when amdsmi is not there or the device cannot be matched."""
     import torch
+    read = None
     try:
         import amdsmi
         amdsmi.amdsmi_init()
@@ -329,19 +330,20 @@ def clock_sample_under_load(dev_index, enqueue_steps, n_steps=2, period_s=0.02):
                 h = cand
         if h is None and len(handles) == 1:
             h = handles[0]
-        if h is None:
-            return None
-        read = lambda: (float(amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)["clk"]),
-                        float(amdsmi.amdsmi_get_power_info(h)["current_socket_power"]))
-        read()
+        if h is not None:
+            read = lambda: (float(amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)["clk"]),
+                            float(amdsmi.amdsmi_get_power_info(h)["current_socket_power"]))
+            read()
     except Exception:
-        return None
+        read = None
+    # EVERY caller enqueues the extra steps, whether or not it can read the counters: under torch.distributed the steps hold a collective,
+    # and a rank that skipped them (amdsmi missing on it alone) would leave the others waiting
     done = torch.cuda.Event()
     enqueue_steps(n_steps)           # asynchronous: the host is free to poll while the GPU works
     done.record()
     clk, pw = [], []
     t_end = time.perf_counter() + 60.0
-    while not done.query() and time.perf_counter() < t_end:
+    while read is not None and not done.query() and time.perf_counter() < t_end:
         try:
             c, w = read()
             clk.append(c); pw.append(w)
