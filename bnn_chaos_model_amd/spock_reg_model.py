@@ -222,6 +222,13 @@ class VarModel:
     def latents(self, v):
         self._latents_cache, self._last_latents_args = v, None
 
+    def drop_records(self):
+        """Not in the reference: let go of what the two lazy side effects keep alive -- the last call's x on the GPU, its noise tensors
+        (forward(noisy_val=True): an x-sized eps_in) and weights.  `_cur_summary` / `latents` read None afterwards, until the next call."""
+        self._last_forward = self._last_latents_args = None
+        self._cur_summary_cache = self._latents_cache = None
+        return self
+
     # ---- nn.Module-like conveniences used by the evaluation scripts --------------------------------------------
     @property
     def device(self):
