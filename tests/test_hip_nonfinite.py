@@ -291,3 +291,52 @@ def test_scan_at_scale_costs_one_pass_over_x(ops, swag_states):
     nan_rows = torch.isnan(got).any(0).any(-1).cpu()
     certain = torch.isnan(vals) | torch.tensor([(ops.V50_ZERO_MASK >> int(c)) & 1 == 1 for c in cols])
     assert nan_rows[planted[certain]].all() and not nan_rows[keep].any()
+
+
+@pytest.mark.parametrize("net", ("v50", "dead"))
+@pytest.mark.parametrize("noisy", (False, True))
+def test_random_damage_against_the_oracle(net, noisy, ops, orc, z, swag_states):
+    """256 systems, each with 0-3 random damages (NaN / +inf / -inf at a random timestep and column) -- and, for the `dead` network, extra
+    +inf on its dead column --, explicit noise: the HIP path against the oracle (which follows the reference, tests/test_oracle_nonfinite.py):
+    the same NaN pattern in (mu, std), 1e-5 where finite; systems without damage bit-identical to a run on the clean batch."""
+    rng = np.random.default_rng(11 + int(noisy))
+    B = 256
+    base = np.tile(load_golden("inputs.npz")["x_slow"], (8, 1, 1))[:B].copy()
+    base += 0.01 * rng.standard_normal(base.shape).astype(np.float32)
+    x = base.copy()
+    hurt = set()
+    vals = (np.nan, np.inf, -np.inf)
+    for b in range(B):
+        for _ in range(int(rng.integers(0, 4)) if b % 3 else 0):
+            x[b, int(rng.integers(0, 100)), int(rng.integers(0, 41))] = vals[int(rng.integers(0, 3))]
+            hurt.add(b)
+    if net == "dead":
+        plan, arch = dead_plan(ops, orc, z)
+        w = z["dead_swagfast_w"]
+        col = int(z["dead_col"])
+        for b in range(1, B, 7):      # +inf on the dead column only: dies in the ReLU (unless the system is otherwise damaged)
+            x[b, int(rng.integers(0, 100)), col] = np.inf
+            hurt.add(b)
+    else:
+        plan, arch = ops.get_plan(), orc.make_arch(T=100)
+        w = z["v50_0_swagfast_w"]
+    L, SM = arch.latent, 2 * arch.latent
+    e1, e2 = rng.standard_normal((B, L), dtype=np.float32), rng.standard_normal((B, L), dtype=np.float32)
+    kw, okw = {}, {}
+    if noisy:
+        e_in, e_sum = rng.standard_normal((B, 100, 41), dtype=np.float32), rng.standard_normal((B, SM), dtype=np.float32)
+        kw, okw = dict(eps_in=dev(e_in[None]), eps_sum=dev(e_sum[None])), dict(eps_in=e_in, eps_sum=e_sum)
+    eps = dev(np.stack([e1, e2], 1)[None])
+    W = dev(w[None])
+    got = ops.forward(dev(x), W, eps=eps, plan=plan, **kw)[0].cpu().numpy()
+    want = orc.forward(x, w, e1, e2, arch=arch, **okw)
+    same_nan_close_elsewhere(got, want, rtol=2e-5 if noisy else 1e-5)
+    clean = ops.forward(dev(base), W, eps=eps, plan=plan, assume_finite=True, **kw)[0].cpu().numpy()
+    keep = np.array([b for b in range(B) if b not in hurt])
+    assert np.array_equal(got[keep], clean[keep])
+    nan_rows = np.isnan(got).any(1)
+    assert not nan_rows[keep].any() and nan_rows.sum() >= len(hurt) // 2
+    if net == "dead":   # some of the +inf-on-the-dead-column systems stay finite (those with no other damage): the exact route's work
+        only_dead = [b for b in range(1, B, 7) if b % 3 == 0 or np.isfinite(np.delete(x[b], col, axis=1)).all()]
+        finite_dead = [b for b in only_dead if np.isfinite(want[b]).all()]
+        assert len(finite_dead) >= 3 and np.isfinite(got[finite_dead]).all()
