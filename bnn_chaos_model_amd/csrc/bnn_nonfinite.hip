@@ -13,7 +13,7 @@
 //      overwrites their outputs.  "Certainly NaN" systems are answered without the evaluation unless a side-effect output (summary,
 //      latents) was asked for.  An infinity in a live column is NOT certain: where it meets weights of one sign only it dies in the
 //      ReLU and the reference's outputs stay finite (tests/golden/make_golden_nonfinite.py, the `dead` network).
-// One wave per (output row, listed system); the network is read from the plan's descriptor (any hparams-built network, either engine).
+// One four-wave workgroup per (output row, listed system); the network is read from the plan's descriptor (any hparams-built network, either engine).
 #include "bnn_common.hip.h"
 #include "bnn_stats.hip.h"
 
@@ -104,23 +104,27 @@ DEVINL NfLayer nf_layer(const GenArch4* g, int l) {
     return y;
 }
 
-// WLDS: the draw's flat parameter vector sits in LDS (the in-prologue draw has no other place for it: 30 KB, two workgroups per CU);
-// otherwise it is read where it is, W[e] in global memory -- wave-uniform addresses, i.e. SCALAR loads (s_load_dwordx4 through the
-// constant cache and L2), 34 KB of LDS per one-wave workgroup for the pretrained shapes and four of them per CU.
+// One WORKGROUP of four waves per (output row, listed system): lane = timestep as before, the four waves split every layer's neurons
+// (and the input columns, the latents of the pool) between them and meet at a barrier per layer -- the LDS rows (34 KB for the pretrained
+// shapes) are then shared by four waves instead of one: sixteen waves per CU instead of four, and a quarter of the dependent fmaf
+// chains per wave.
+// WLDS: the draw's flat parameter vector sits in LDS (the in-prologue draw has no other place for it: 30 KB more); otherwise it is read
+// where it is, W[e] in global memory -- wave-uniform addresses through the constant address space, i.e. SCALAR loads.
 template <bool WLDS>
-__global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams q) {
+__global__ __launch_bounds__(256) void bnn_nonfinite_fixup_kernel(const NfxParams q) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FwdParams& p = q.f;
     const GenArch4* Gc = (const GenArch4*)(uintptr_t)q.g;
     struct { int F, L, SM, d, megno, n_feat, n_reg, nin_blocks, off_inlv, off_sumlv; } G = {Gc->F, Gc->L, Gc->SM, Gc->d, Gc->megno, Gc->n_feat, Gc->n_reg,
                                                                                             Gc->nin_blocks, Gc->off_inlv, Gc->off_sumlv};
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int F = G.F, L = G.L, SM = G.SM, d = G.d, T = p.T;
     const int count = __builtin_amdgcn_readfirstlane(q.rec[0]);
     const int R = p.J / p.nch;
     const int64_t total = (int64_t)R * count;
     if (total == 0) return;
-    float* actA = lds;                           // [maxw][64] activations of the wave's 64 timesteps, lane-minor
+    float* actA = lds;                           // [maxw][64] activations of the 64 timesteps of a pass, lane-minor
     float* actB = actA + (size_t)q.maxw * 64;
     float* pm = actB + (size_t)q.maxw * 64;      // [L + 1][64] per-lane Welford means (row L: the raw MEGNO column)
     float* pq = pm + (size_t)(L + 1) * 64;       // [L + 1][64] ... M2
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
         const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + b;
         const int64_t ob = r * p.B + b;
         auto emit = [&](float r0, float r1, bool nan_out) {
-            if (lane != 0) return;
+            if (tid != 0) return;
             f32x2 ms = soft_clamp2(r0, r1, p.std_lo, p.std_span);
             if (nan_out) ms.x = ms.y = qnan;
             if (p.sink) p.sink[ob] = stats_draw(p.st, ms.x, ms.y, grow, gsys, p.seed);
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
                 if (p.pre_clamp) *reinterpret_cast<f32x2*>(p.pre_clamp + ob * 2) = (f32x2){nan_out ? qnan : r0, nan_out ? qnan : r1};
             }
         };
-        if ((ent & 1) && q.shortcut) {   // NaN whatever the weights
+        if ((ent & 1) && q.shortcut) {   // NaN whatever the weights (uniform over the workgroup: no barrier is skipped by part of it)
             emit(qnan, qnan, true);
             continue;
         }
@@ -159,29 +163,26 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
         if constexpr (!WLDS) {
             wv = p.W + (int64_t)e * d;
         } else if (p.W) {
-            __builtin_amdgcn_wave_barrier();
-            for (int i = lane; i < d; i += 64) flat[i] = p.W[(int64_t)e * d + i];
-            __builtin_amdgcn_wave_barrier();
+            for (int i = tid; i < d; i += 256) flat[i] = p.W[(int64_t)e * d + i];
             wv = flat;
         } else {
             int s = p.seed_idx[e];
             bad_seed = (s < 0 || s >= p.S);
             if (bad_seed) s = 0;
             const int K = p.K;
-            __builtin_amdgcn_wave_barrier();
-            for (int k = lane; k < K; k += 64) zsh[k] = p.z2 ? p.z2[(int64_t)e * K + k] : philox_z(TAG_Z2, p.draw_id0 + e, k, p.seed);
-            __builtin_amdgcn_wave_barrier();
+            for (int k = tid; k < K; k += 256) zsh[k] = p.z2 ? p.z2[(int64_t)e * K + k] : philox_z(TAG_Z2, p.draw_id0 + e, k, p.seed);
+            __syncthreads();
             const float* wa = p.w_avg + (int64_t)s * d;
             const float* w2 = p.w2_avg + (int64_t)s * d;
             const float* pd = p.pre_D + (int64_t)s * d * K;
-            for (int i = lane; i < d; i += 64) {
+            for (int i = tid; i < d; i += 256) {
                 const float z1v = p.z1 ? p.z1[(int64_t)e * d + i] : philox_z(TAG_Z1, p.draw_id0 + e, i, p.seed);
                 flat[i] = draw_row_direct(wa, w2, pd, i, K, zsh, z1v, p.c1, p.c2, p.scale);
             }
-            __builtin_amdgcn_wave_barrier();
             wv = flat;
         }
-        for (int n = 0; n <= L; ++n) { pm[n * 64 + lane] = 0.0f; pq[n * 64 + lane] = 0.0f; }
+        for (int n = wave; n <= L; n += 4) { pm[n * 64 + lane] = 0.0f; pq[n * 64 + lane] = 0.0f; }
+        __syncthreads();
         const float* xs = p.x + b * (int64_t)T * F;
         int npass = 0;
         for (int t0 = 0; t0 < T; t0 += 64, ++npass) {
@@ -190,16 +191,17 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
             const int tc = tv ? t : T - 1;
             const float* xr = xs + (int64_t)tc * F;
             const float rcn = 1.0f / (float)(npass + 1);
-            if (G.megno && tv) {   // summarize_megno (:480-484): the RAW column, before the masks and before any noise
+            if (G.megno && tv && wave == 0) {   // summarize_megno (:480-484): the RAW column, before the masks and before any noise
                 const float xm = xr[MEGNO_COL];
                 const float gm = pm[L * 64 + lane];
                 const float dl = xm - gm, mn = fmaf(dl, rcn, gm);
                 pq[L * 64 + lane] = fmaf(dl, xm - mn, pq[L * 64 + lane]);
                 pm[L * 64 + lane] = mn;
             }
-            // zero_megno / zero_mmr / zero_nan / zero_eplusminus: x - mask (:452-478); then add_input_noise (:444-446)
+            // zero_megno / zero_mmr / zero_nan / zero_eplusminus: x - mask (:452-478); then add_input_noise (:444-446); a wave takes every
+            // fourth block of six columns (one Philox block of the input-noise stream)
             const float* er = (q.noisy && p.eps_in) ? p.eps_in + (ob * T + tc) * (int64_t)F : nullptr;
-            for (int k0 = 0; k0 < F; k0 += NIN_PER_BLOCK) {
+            for (int k0 = NIN_PER_BLOCK * wave; k0 < F; k0 += 4 * NIN_PER_BLOCK) {
                 float n6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                 if (q.noisy && !er) philox_in6(grow, gsys, tc * G.nin_blocks + k0 / NIN_PER_BLOCK, p.seed, n6);
                 for (int j = 0; j < NIN_PER_BLOCK && k0 + j < F; ++j) {
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
                     actA[k * 64 + lane] = v;
                 }
             }
+            __syncthreads();
             float* cur = actA;
             float* nxt = actB;
             for (int l = 0; l < G.n_feat; ++l) {   // feature_nn (:359, :417): bias, then the inputs ascending -- four neurons at a time: four
@@ -237,15 +240,16 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
                     if (n0 + 2 < N) nxt[(n0 + 2) * 64 + lane] = a2;
                     if (n0 + 3 < N) nxt[(n0 + 3) * 64 + lane] = a3;
                 };
-                for (int n0 = 0; n0 < N; n0 += 4) {
+                for (int n0 = 4 * wave; n0 < N; n0 += 16) {   // this wave's neurons
                     if constexpr (WLDS) four(wv, n0);
                     else four(as_constant(wv), n0);
                 }
+                __syncthreads();
                 float* tmp = cur; cur = nxt; nxt = tmp;
             }
-            if (tv) {   // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps t0 + lane
+            if (tv) {   // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps t0 + lane; a wave takes every fourth latent
                 float* lat = p.latents ? p.latents + (ob * T + t) * (int64_t)L : nullptr;
-                for (int n = 0; n < L; ++n) {
+                for (int n = wave; n < L; n += 4) {
                     const float y = cur[n * 64 + lane];
                     if (lat) lat[n] = y;
                     const float m = pm[n * 64 + lane];
@@ -254,10 +258,10 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
                     pm[n * 64 + lane] = mn;
                 }
             }
+            __syncthreads();   // the next pass writes its inputs over rows that may still be read here
         }
-        __builtin_amdgcn_wave_barrier();
-        // merge the 64 partitions (t mod 64) of a latent in partition order; lane n finishes latent n (compute_summary_stats :420-431)
-        for (int n = lane; n <= L; n += 64) {
+        // merge the 64 partitions (t mod 64) of a latent in partition order; thread n finishes latent n (compute_summary_stats :420-431)
+        for (int n = tid; n <= L; n += 256) {
             if (n == L && !G.megno) break;
             float na = 0.0f, ma = 0.0f, qa = 0.0f;
             for (int pp = 0; pp < 64; ++pp) {
@@ -282,8 +286,8 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
                 sum[2 * L + 1] = sqrtf(qa / nm1);
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        for (int n = lane; n < SM; n += 64) {
+        __syncthreads();
+        for (int n = tid; n < SM; n += 256) {
             float s = sum[n];
             if (p.summary) p.summary[ob * SM + n] = s;   // _cur_summary (:512): before the summary noise
             if (q.noisy) {                               // add_summary_noise (:448-450)
@@ -292,28 +296,28 @@ __global__ __launch_bounds__(64) void bnn_nonfinite_fixup_kernel(const NfxParams
             }
             ra[n] = s;
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         float* cur = ra;
         float* nxt = rb;
-        for (int l = G.n_feat; l < G.n_feat + G.n_reg; ++l) {   // regress_nn (:360, :438): lane = neuron
+        for (int l = G.n_feat; l < G.n_feat + G.n_reg; ++l) {   // regress_nn (:360, :438): thread = neuron
             const NfLayer ly = nf_layer(Gc, l);
-            for (int n = lane; n < ly.N; n += 64) {
+            for (int n = tid; n < ly.N; n += 256) {
                 float acc = wv[ly.off_b + n];
                 const float* __restrict__ wr = wv + ly.off_w + (int64_t)n * ly.K;
                 int k = 0;
 #pragma unroll 4
-                for (; k + 4 <= ly.K; k += 4) {   // the lane's weight row, 16 bytes at a time (several loads in flight: a load per fmaf would serialise the chain)
+                for (; k + 4 <= ly.K; k += 4) {   // the thread's weight row, 16 bytes at a time (several loads in flight: a load per fmaf would serialise the chain)
                     const f32x4 w4 = *reinterpret_cast<const f32x4u*>(wr + k);
                     acc = fmaf(w4.x, cur[k], acc); acc = fmaf(w4.y, cur[k + 1], acc); acc = fmaf(w4.z, cur[k + 2], acc); acc = fmaf(w4.w, cur[k + 3], acc);
                 }
                 for (; k < ly.K; ++k) acc = fmaf(wr[k], cur[k], acc);
                 nxt[n] = ly.relu ? relu_ieee(acc) : acc;
             }
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
         emit(cur[0], cur[1], bad_seed);   // predict_instability + soft_clamp (:295-296, :437-442)
-        __builtin_amdgcn_wave_barrier();  // the LDS areas are reused by the next item
+        __syncthreads();  // the LDS areas are reused by the next item
     }
 }
 
@@ -338,10 +342,10 @@ hipError_t launch_nonfinite_fixup(const GenArch& g, NfxParams& q, hipStream_t st
     const unsigned nblk = (unsigned)(items < 4096 ? (items > 0 ? items : 1) : 4096);
     if (fused) {
         allow_big_lds<bnn_nonfinite_fixup_kernel<true>>();
-        hipLaunchKernelGGL(bnn_nonfinite_fixup_kernel<true>, dim3(nblk), dim3(64), lds, st, q);
+        hipLaunchKernelGGL(bnn_nonfinite_fixup_kernel<true>, dim3(nblk), dim3(256), lds, st, q);
     } else {
         allow_big_lds<bnn_nonfinite_fixup_kernel<false>>();
-        hipLaunchKernelGGL(bnn_nonfinite_fixup_kernel<false>, dim3(nblk), dim3(64), lds, st, q);
+        hipLaunchKernelGGL(bnn_nonfinite_fixup_kernel<false>, dim3(nblk), dim3(256), lds, st, q);
     }
     return hipGetLastError();
 }
