@@ -233,3 +233,43 @@ def test_rccl_branch_executes_at_world_size_one():
     assert torch.equal(got, rows) and "more than once" in ds2.last_exchange
     with pytest.raises(ValueError):
         md.DeviceSet([0], exchange="smoke signals")
+
+
+@pytest.mark.gpu
+def test_damaged_systems_through_the_sharded_drivers(fr, inputs):
+    """Non-finite inputs through the batched drivers: every shard scans its own rows (a record per shard, the chunks still those of the
+    whole batch), so logical shards reproduce the single-shard result -- NaN for the damaged systems / simulations, the clean ones bit
+    for bit as on the clean batch."""
+    X = torch.tensor(np.tile(inputs["slow"], (3, 1, 1))[:90].copy())
+    Xb = X.clone()
+    Xb[7, 3, 2] = float("nan")          # masked column: NaN in the reference (x - mask)
+    Xb[33, 50, 12] = float("inf")       # live column
+    Xb[89, 99, 40] = float("-inf")      # masked column, last row of the last shard
+    hurt = [7, 33, 89]
+    keep = [b for b in range(90) if b not in hurt]
+    outs = {}
+    for name, devs in (("one", [0]), ("four", [0, 0, 0, 0])):
+        for rng in ("torch", "philox"):
+            np.random.seed(5); torch.manual_seed(5)
+            outs[name, rng] = fr.sample_full_swag_many(Xb, samples=3, chunks=10, rng=rng, philox_seed=17, devices=devs)
+    for rng in ("torch", "philox"):
+        a, b = outs["one", rng], outs["four", rng]
+        assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))
+        assert torch.isnan(a[:, hurt]).all() and torch.isfinite(a[:, keep]).all()
+        np.random.seed(5); torch.manual_seed(5)
+        clean = fr.sample_full_swag_many(X, samples=3, chunks=10, rng=rng, philox_seed=17, devices=[0], assume_finite=True)
+        assert torch.equal(a[:, keep], clean[:, keep])
+    # the script's own loop, call by call through the surface (default: assume_finite = False), gives the same NaNs
+    np.random.seed(5); torch.manual_seed(5)
+    loop = torch.cat([torch.cat([fr.sample_full_swag(Xp) for Xp in torch.chunk(Xb, 10)])[None] for _ in range(3)])
+    assert torch.equal(torch.nan_to_num(loop, nan=-1.0), torch.nan_to_num(outs["one", "torch"], nan=-1.0))
+    # streamed bands: the simulations (trios) that hold a damaged row get NaN bands, the others the clean batch's
+    res = {}
+    for name, devs, xx, kw in (("bad1", [0], Xb, {}), ("bad3", [0, 0, 0], Xb, {}), ("clean", [0], X, dict(assume_finite=True))):
+        np.random.seed(9)
+        res[name] = fr.predictive_bands(xx, samples=32, chunks=10, trios=3, philox_seed=3, samples_per_launch=8, devices=devs, **kw)
+    sims_hurt = sorted({b // 3 for b in hurt})
+    sims_keep = [s for s in range(30) if s not in sims_hurt]
+    p1, p3, pc = (res[k]["percentiles"] for k in ("bad1", "bad3", "clean"))
+    assert torch.equal(torch.nan_to_num(p1, nan=-1.0), torch.nan_to_num(p3, nan=-1.0))
+    assert torch.isnan(p1[sims_hurt]).all() and torch.equal(p1[sims_keep], pc[sims_keep])
