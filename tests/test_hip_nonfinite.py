@@ -293,7 +293,21 @@ def test_scan_at_scale_costs_one_pass_over_x(ops, swag_states):
     assert nan_rows[planted[certain]].all() and not nan_rows[keep].any()
 
 
-@pytest.mark.parametrize("net", ("v50", "dead"))
+def _arch_case(ops, orc, name):
+    """plan / oracle arch / weights / inputs of a reference-built network of tests/golden/case_arch_<name>.npz (tests/test_hip_arch.py)."""
+    za = load_golden(f"case_arch_{name}.npz")
+    hp = json.loads(str(za["hparams_json"]))
+    for k, v in list(hp.items()):
+        if isinstance(v, str) and v in ("True", "False"):
+            hp[k] = v == "True"
+    mask = ops.zero_mask_from_flags(hp.get("fix_megno", False), hp.get("fix_megno2", False), hp["include_mmr"], hp["include_nan"], hp.get("include_eplusminus", True))
+    kw = dict(n_features=int(za["n_features"]), hidden=hp["hidden"], latent=hp["latent"], depth_in=hp["in"], depth_out=hp["out"])
+    plan = ops.get_plan(mask, 0.5, fix_megno=hp.get("fix_megno", False), **kw)
+    arch = orc.make_arch(T=100, zero_mask=mask, lowest=0.5, fix_megno=hp.get("fix_megno", False), **kw)
+    return plan, arch, za["swagfast_w"], za["x"]
+
+
+@pytest.mark.parametrize("net", ("v50", "dead", "h48megno", "deriv82", "lin0out8"))
 @pytest.mark.parametrize("noisy", (False, True))
 def test_random_damage_against_the_oracle(net, noisy, ops, orc, z, swag_states):
     """256 systems, each with 0-3 random damages (NaN / +inf / -inf at a random timestep and column) -- and, for the `dead` network, extra
@@ -301,16 +315,23 @@ def test_random_damage_against_the_oracle(net, noisy, ops, orc, z, swag_states):
     the same NaN pattern in (mu, std), 1e-5 where finite; systems without damage bit-identical to a run on the clean batch."""
     rng = np.random.default_rng(11 + int(noisy))
     B = 256
-    base = np.tile(load_golden("inputs.npz")["x_slow"], (8, 1, 1))[:B].copy()
+    if net in ("v50", "dead"):
+        base = np.tile(load_golden("inputs.npz")["x_slow"], (8, 1, 1))[:B].copy()
+    else:   # fix_megno (the raw MEGNO column is summarised before it is zeroed), 82 features, a ten-module regress_nn: the generic engine
+        plan, arch, w, xa = _arch_case(ops, orc, net)
+        base = np.tile(xa, (B // xa.shape[0] + 1, 1, 1))[:B].copy()
+    NF = base.shape[2]
     base += 0.01 * rng.standard_normal(base.shape).astype(np.float32)
     x = base.copy()
     hurt = set()
     vals = (np.nan, np.inf, -np.inf)
     for b in range(B):
         for _ in range(int(rng.integers(0, 4)) if b % 3 else 0):
-            x[b, int(rng.integers(0, 100)), int(rng.integers(0, 41))] = vals[int(rng.integers(0, 3))]
+            x[b, int(rng.integers(0, 100)), int(rng.integers(0, NF))] = vals[int(rng.integers(0, 3))]
             hurt.add(b)
-    if net == "dead":
+    if net not in ("v50", "dead"):
+        pass
+    elif net == "dead":
         plan, arch = dead_plan(ops, orc, z)
         w = z["dead_swagfast_w"]
         col = int(z["dead_col"])
@@ -320,11 +341,11 @@ def test_random_damage_against_the_oracle(net, noisy, ops, orc, z, swag_states):
     else:
         plan, arch = ops.get_plan(), orc.make_arch(T=100)
         w = z["v50_0_swagfast_w"]
-    L, SM = arch.latent, 2 * arch.latent
+    L, SM = arch.latent, 2 * arch.latent + 2 * int(arch.fix_megno)
     e1, e2 = rng.standard_normal((B, L), dtype=np.float32), rng.standard_normal((B, L), dtype=np.float32)
     kw, okw = {}, {}
     if noisy:
-        e_in, e_sum = rng.standard_normal((B, 100, 41), dtype=np.float32), rng.standard_normal((B, SM), dtype=np.float32)
+        e_in, e_sum = rng.standard_normal((B, 100, NF), dtype=np.float32), rng.standard_normal((B, SM), dtype=np.float32)
         kw, okw = dict(eps_in=dev(e_in[None]), eps_sum=dev(e_sum[None])), dict(eps_in=e_in, eps_sum=e_sum)
     eps = dev(np.stack([e1, e2], 1)[None])
     W = dev(w[None])
