@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void bnn_nonfinite_fixup_kernel(const NfxParam
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
         const int32_t ent = __builtin_amdgcn_readfirstlane(q.rec[4 + (int)(w % count)]);   // (wave-uniform: keeps the draw's address scalar)
         const int64_t r = w / count, b = ent >> 1;
+        if (b < 0 || b >= p.B) continue;   // (a record made for another batch: never write outside this call's rows; uniform over the workgroup)
         const int ch = (int)((p.coff + b) / p.csz);
         const int e = (int)r * p.nch + ch;
         const int64_t grow = p.row_id0 + r, gsys = p.sys_id0 + b;
