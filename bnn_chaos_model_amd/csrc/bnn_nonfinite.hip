@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void bnn_nonfinite_fixup_kernel(const NfxParam
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int F = G.F, L = G.L, SM = G.SM, d = G.d, T = p.T;
-    const int count = __builtin_amdgcn_readfirstlane(q.rec[0]);
+    int count = __builtin_amdgcn_readfirstlane(q.rec[0]);
+    if (count < 0) count = 0;
+    if ((int64_t)count > p.B) count = (int)p.B;   // (never walk further than a record of this call's batch can be long)
     const int R = p.J / p.nch;
     const int64_t total = (int64_t)R * count;
     if (total == 0) return;
