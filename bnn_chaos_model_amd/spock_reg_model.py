@@ -552,11 +552,23 @@ class SWAGModel(VarModel):
         B = xg.shape[0]
         idx = torch.zeros(1, dtype=torch.int32, device=g)
         if self.rng == "torch":
-            z1, z2 = self._draw_noise()                                  # :830-831
-            e1 = torch.randn(B, self._latent, device=dev_in)             # :426
-            e2 = torch.randn(B, self._latent, device=dev_in)             # :427
-            eps = torch.stack([e1, e2], dim=1)[None].to(g).contiguous()
-            z1g, z2g = z1.to(g).contiguous(), z2.reshape(1, -1).to(g).contiguous()
+            L_, d_ = self._latent, self.w_avg.shape[0]
+            if self._device.type == "cpu" and dev_in.type == "cpu":
+                # the reference's four draws, in its order (:830-831, :426-427), each straight into its slice of ONE host buffer
+                # (normal_() on a contiguous view consumes the generator exactly like torch.randn of that shape) -> one copy to the GPU
+                buf = torch.empty(d_ + self.K + 2 * B * L_)
+                z1v, z2v = buf[:d_].view(1, d_), buf[d_:d_ + self.K].view(self.K, 1)
+                ev = buf[d_ + self.K:].view(2, B, L_)
+                z1v.normal_(); z2v.normal_(); ev[0].normal_(); ev[1].normal_()
+                bg = buf.to(g)
+                z1g, z2g = bg[:d_].view(1, d_), bg[d_:d_ + self.K].view(1, self.K)
+                eps = bg[d_ + self.K:].view(2, B, L_).permute(1, 0, 2).contiguous()[None]
+            else:
+                z1, z2 = self._draw_noise()                                  # :830-831
+                e1 = torch.randn(B, L_, device=dev_in)                       # :426
+                e2 = torch.randn(B, L_, device=dev_in)                       # :427
+                eps = torch.stack([e1, e2], dim=1)[None].to(g).contiguous()
+                z1g, z2g = z1.to(g).contiguous(), z2.reshape(1, -1).to(g).contiguous()
             mask, lowest, net = self._op_args()
             with torch.cuda.device(g):
                 out = self._tops().multiswag(xg, wa, w2, pd, idx, z1g, z2g, eps, 1, float(scale), 0, 0, 0, mask, lowest, net,
