@@ -73,3 +73,30 @@ def test_plain_multi_gpu_invocation_carries_the_named_config():
     nc = r["named_config"]
     assert "configs[3]" in nc["workload"] and nc["draws"] == 3000 and nc["systems_per_gpu"] == 8192 and nc["steps"] == 1
     assert nc["value"] == pytest.approx(2 * 8192 * 3000 / (nc["ms_per_step"] * 1e-3), rel=1e-6)
+
+
+def test_single_process_route_and_the_new_line_fields():
+    """`bench.py --single-process --gpus 3` (three logical shards on the one card): the one-process route of multidevice.DeviceSet with the
+    rank-per-GPU line's schema -- launcher, exchange, per-device kernel times, the staging probe -- and, on the one-GPU default line, the
+    fields round 5 added: the non-finite scan timed on its own, the clock / power held under load, frac_at_held_clock."""
+    env = dict(os.environ, BNN_BENCH_REHEARSE="1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "3", "--workload", "c2", "--systems", "6000", "--samples", "2",
+           "--steps", "2", "--warmup", "1", "--h2d-probe-gb", "0.05"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stderr[-2000:])
+    r = json.loads(lines[0])
+    c = r["config"]
+    assert r["n_gpus"] == 3 and c["launcher"] == "single-process" and c["devices"] == ["cuda:0"] * 3 and c["exchange"] == "peer copies"
+    assert r["scaling"] == "weak" and r["value"] == pytest.approx(3 * 6000 * 60 / (r["ms_per_step"] * 1e-3), rel=1e-6)
+    assert 0 < c["kernel_ms_min"] <= c["kernel_ms_max"] and "scanned" in c["finite_check"]
+    assert set(c["h2d_probe"]) == {"pinned", "pageable"} and c["h2d_probe"]["pinned"]["aggregate_GBs"] > 1.0 and "3 host thread" in c["h2d_probe"]["pageable"]["mode"]
+    # the default one-GPU line (shrunk): scan on, timed on its own; --assume-finite switches it off
+    for flag, want_scan in ((), True), (("--assume-finite",), False):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--systems", "50000", "--samples", "20", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *flag]
+        out = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="4"), cwd=ROOT, capture_output=True, text=True, timeout=600)
+        r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert (r["config"]["finite_check_ms"] > 0.05) == want_scan and ("scanned" in r["config"]["finite_check"]) == want_scan
+        assert r["config"]["launcher"] == "one process, one GPU" and r["roofline"]["kernel_ms"] > 0
+        if "clock" in r:   # (amdsmi is there on the GPU boxes; the field is optional by design)
+            assert 500 < r["clock"]["sclk_mhz_mean"] < 3000 and 0.3 < r["roofline"]["frac_at_held_clock"] < 1.0
