@@ -447,9 +447,19 @@ class VarModel:
 
     def forward(self, x, noisy_val=True):
         """VarModel.forward (:486-528) with the currently loaded weights -> cat(mu, std) [B,2] on x.device."""
-        if self.random_sample:
-            raise NotImplementedError("random_sample (training-time augmentation) is not part of the inference path")
+        if self.random_sample:   # `x = self.augment(x)` (:502-503), behind the column masks and in front of the input noise: the masks are
+            if self.fix_megno:   # per column, so they commute with the choice of timesteps -- the raw MEGNO statistics of fix_megno do not
+                raise NotImplementedError("random_sample with fix_megno: the reference summarises MEGNO over the WHOLE series (:488-491) and "
+                                          "pools the augmented one; not built")
+            x = self.augment(x)
         return self._forward_gpu(x, self._w[None], noisy=bool(noisy_val), record=True)
+
+    def augment(self, x):
+        """"This randomly samples times." (:404-408): a random number (hparams['samp'] .. T) of timesteps, drawn WITH replacement from numpy's
+        global generator -- the same two np.random.randint calls as the reference; the series the kernels then see has that length
+        (any T >= 2 runs: the generic engine / the pretrained network's embedded forms)."""
+        samples = np.random.randint(self.hparams["samp"], x.shape[1] + 1)
+        return x[:, np.random.randint(0, x.shape[1], size=samples)]
 
     def sample(self, x, samples=10):
         """VarModel.sample (:530-545): mean over `samples` noisy forwards of mu + N(0,1)*std -> float64 ndarray [B].
@@ -457,6 +467,13 @@ class VarModel:
         ONE launch (one output row per sample, all noise in-kernel); numpy's randn(B) per sample is drawn as the reference does."""
         x = x.cpu()
         init_device = self._device
+        init_random_sample, self.random_sample = self.random_sample, False   # (:532-535, restored at :543)
+        try:
+            return self._sample(x, samples, init_device)
+        finally:
+            self.random_sample = init_random_sample
+
+    def _sample(self, x, samples, init_device):
         if self.rng == "philox":
             self._check_x(x)
             g = _gpu()

@@ -285,3 +285,23 @@ def test_fix_megno_branch_matches_reference():
     o4 = orc.forward(z["x"], z["swagfast_w"], t[0], t[1], arch=arch, sched=sch)
     nbad, mx = close_report(o4, z["forward_noisy0_out"])
     assert nbad == 0, (nbad, mx)
+
+
+def test_forward_with_random_sample_matches_reference():
+    """VarModel.forward with random_sample = True (`augment`, spock_reg_model.py:404-408, :502-503): the timesteps the reference picked
+    (taped), behind the masks and in front of the noise -- the oracle on x[:, picked] at that series length."""
+    z = load_golden("case_augment.npz")
+    x = z["x"]
+    for i in range(int(z["runs"])):
+        t = [z[f"run{i}_tape_{j:03d}"] for j in range(int(z[f"run{i}_tape_n"]))]
+        n_t, idx = int(t[0]), np.asarray(t[1])
+        assert idx.shape == (n_t,) and 5 <= n_t <= 100 and idx.min() >= 0 and idx.max() < 100
+        xa = np.ascontiguousarray(x[:, idx])
+        arch = orc.make_arch(T=n_t)
+        if int(z[f"run{i}_noisy"]):
+            assert t[2].shape == (16, n_t, 41)     # the input noise has the augmented shape
+            out = orc.forward(xa, z["w"], t[3], t[4], eps_in=t[2], eps_sum=t[5], arch=arch)
+        else:
+            out = orc.forward(xa, z["w"], t[2], t[3], arch=arch)
+        nbad, mx = close_report(out, z[f"run{i}_out"])
+        assert nbad == 0, (i, nbad, mx)

@@ -223,6 +223,33 @@ def test_data_setup_kernel_drop_in():
     assert x.is_cuda and x.dtype == torch.float32 and np.abs(x.cpu().numpy().astype(np.float64) - z["x32"]).max() <= 3e-6
 
 
+def test_forward_with_random_sample_replays_reference_seed(models):
+    """VarModel.forward with random_sample = True (`augment`, :404-408, :502-503): the same np.random.randint calls, the series the reference
+    picked -- its length is whatever came up (85, 15, 27 here: the pretrained network's embedded forms of the generic engine) --, the same
+    numbers under the same seeds; sample() switches the augmentation off for its loop and puts the flag back (:532-543)."""
+    z = load_golden("case_augment.npz")
+    m = models[0]
+    m.load(torch.tensor(z["w"]))
+    x = torch.tensor(z["x"])
+    m.random_sample = True
+    try:
+        for i in range(int(z["runs"])):
+            seed = int(z[f"run{i}_seed"])
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+            out = m(x, noisy_val=bool(int(z[f"run{i}_noisy"])))
+            nbad, mx = close_report(out.numpy(), z[f"run{i}_out"])
+            assert nbad == 0, (i, nbad, mx)
+        np.random.seed(7200)
+        torch.manual_seed(7200)
+        s = m.sample(x, samples=2)
+        assert m.random_sample is True
+        want = z["sample_out"]
+        assert np.abs(s - want).max() <= 2e-5 * np.abs(want).max()
+    finally:
+        m.random_sample = False
+
+
 def test_torch_custom_ops(swag_states, inputs):
     """torch.ops.bnn_chaos.* (torch.library custom ops) give the same bits as the python wrappers; fake impls give shapes."""
     import bnn_chaos_model_amd.torch_ops  # noqa: F401  (registers the ops)
