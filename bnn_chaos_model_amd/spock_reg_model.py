@@ -359,23 +359,45 @@ class VarModel:
         return i
 
     def _masked(self, x):
-        m = self.zero_mask()
-        cols = [c for c in range(min(64, self.n_features)) if (m >> c) & 1]
-        x = x.clone()
-        x[..., cols] = 0
+        """Every mask the flags switch on, as forward() applies them (:488-500)."""
+        if self.fix_megno or self.fix_megno2:
+            x = self.zero_megno(x)
+        if not self.include_mmr:
+            x = self.zero_mmr(x)
+        if not self.include_nan:
+            x = self.zero_nan(x)
+        if not self.include_eplusminus:
+            x = self.zero_eplusminus(x)
         return x
 
+    def _zero(self, x, location):
+        """The reference's masks are subtractions (:452-478): x - mask with mask = x on the masked columns -- 0 for a finite value, NaN for
+        NaN / +-inf.  (Host-side helpers with the reference's names; forward() does the same inside the kernels)"""
+        with torch.no_grad():
+            mask = torch.zeros_like(x)
+            mask[..., location] = x[..., location].clone()
+            return x - mask
+
     def zero_megno(self, x):
-        x = x.clone(); x[..., self.megno_location] = 0; return x
+        return self._zero(x, self.megno_location)
 
     def zero_mmr(self, x):
-        x = x.clone(); x[..., self.mmr_location] = 0; return x
+        return self._zero(x, self.mmr_location)
 
     def zero_nan(self, x):
-        x = x.clone(); x[..., self.nan_location] = 0; return x
+        return self._zero(x, self.nan_location)
 
     def zero_eplusminus(self, x):
-        x = x.clone(); x[..., self.eplusminus_location] = 0; return x
+        return self._zero(x, self.eplusminus_location)
+
+    def summarize_megno(self, x):
+        """[mean_t, std_t] of the raw MEGNO column (:480-484) -> [B, 2]; what fix_megno appends to the summary (the kernels compute it in place)."""
+        col = x[:, :, [self.megno_location]]
+        return torch.cat([torch.mean(col, 1), torch.std(col, 1)], dim=1)
+
+    def set_flag(self, flag_name, value):
+        """(:410-414; this module has no child modules that carry flags)"""
+        setattr(self, flag_name, value)
 
     def _forward_gpu(self, x, W, noisy, want_debug=False, plan=None, record=False):
         """x [B,T,41] on any device, W [1,d] -> (out[B,2] on x.device, pre, summ)."""

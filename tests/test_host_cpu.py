@@ -242,6 +242,31 @@ def test_save_swag_file_loads_in_the_unmodified_reference(tmp_path):
     assert rep["ok"] and all(rep["checks"].values()) and len(rep["checks"]) >= 10
 
 
+def test_mask_helpers_are_the_references_subtractions():
+    """zero_megno / zero_mmr / zero_nan / zero_eplusminus are `x - mask` (spock_reg_model.py:452-478): 0 for finite values, NaN for NaN and
+    +-inf in the masked columns, everything else untouched; summarize_megno (:480-484) and set_flag (:410-414) exist with the reference's
+    meaning.  Host-side torch, no GPU."""
+    from bnn_chaos_model_amd import spock_reg_model as srm
+    z = load_golden("swag_v50_0.npz")
+    m = srm.SWAGModel(json.loads(str(z["hparams_json"]))).init_params(json.loads(str(z["swa_params_json"])))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 7, 41, generator=g)
+    x[0, 1, 3] = float("inf"); x[1, 2, 38] = float("nan"); x[2, 3, 7] = float("-inf"); x[2, 4, 12] = float("inf")
+    for fn, cols in ((m.zero_megno, [7]), (m.zero_mmr, [3, 6]), (m.zero_nan, [38, 39, 40]), (m.zero_eplusminus, [1, 2, 4, 5])):
+        y = fn(x)
+        other = [c for c in range(41) if c not in cols]
+        assert torch.equal(torch.nan_to_num(y[..., other], nan=7.0, posinf=8.0, neginf=9.0), torch.nan_to_num(x[..., other], nan=7.0, posinf=8.0, neginf=9.0))
+        want = x[..., cols] - x[..., cols]
+        assert torch.equal(torch.isnan(y[..., cols]), torch.isnan(want)) and (y[..., cols][~torch.isnan(want)] == 0).all()
+    allm = m._masked(x)
+    assert torch.isnan(allm[0, 1, 3]) and torch.isnan(allm[1, 2, 38]) and torch.isnan(allm[2, 3, 7]) and torch.isinf(allm[2, 4, 12])
+    sm = m.summarize_megno(x[:2])
+    assert sm.shape == (2, 2) and torch.allclose(sm[:, 0], x[:2, :, 7].mean(1)) and torch.allclose(sm[:, 1], x[:2, :, 7].std(1))
+    m.set_flag("random_sample", True)
+    assert m.random_sample is True
+    m.set_flag("random_sample", False)
+
+
 def test_constructor_reproduces_reference_side_effects(tmp_path):
     """load_swag -> SWAGModel(hparams): seed_everything(seed) + the reference's module init order (spock_reg_model.py:343-362)."""
     from bnn_chaos_model_amd import checkpoint, spock_reg_model as srm
