@@ -540,8 +540,9 @@ class SWAGModel(VarModel):
     def _state_gpu(self):
         """(w_avg [1,d], w2_avg [1,d], pre_D [1,d,K]) on the GPU.  The copy is kept while the three attributes stay the same tensor objects at
         the same version (in-place edits and reassignments -- the scripts reassign them with .cuda() / .cpu() copies, regression.py:82-90 --
-        invalidate it): a model whose state lives in host memory (cuda=False) would otherwise send its 0.97 MB across PCIe on every
-        sample_full_swag call (0.27 ms of a 0.45 ms call)."""
+        invalidate it; writes through `.data` bypass torch's version counter and do NOT -- reassign the attribute after such an edit): a
+        model whose state lives in host memory (cuda=False) would otherwise send its 0.97 MB across PCIe on every sample_full_swag call
+        (0.27 ms of a 0.45 ms call)."""
         g = _gpu()
         if self.w_avg is None:
             raise RuntimeError("SWAG state (w_avg, w2_avg, pre_D) is not set")
