@@ -126,7 +126,9 @@ class MultiSwagSharded:
         def shard(i, dev, lo, hi):
             return per_shard(xs[i], states[i], self._plan_on(dev), lo)
 
-        return ds.gather_rows(ds.run(B_total, shard, group=group))
+        parts = ds.run(B_total, shard, group=group)
+        ds.release_sources()   # (a pinned x may be refilled by the caller from here on)
+        return ds.gather_rows(parts)
 
     def predictive_moments(self, x_local, B_total, seed_idx, philox_seed=0, scale=0.5):
         if self.devset is not None:

@@ -109,13 +109,20 @@ class DeviceSet:
     def stage(self, X, group=1, dtype=torch.float32):
         """Rows of X [B, ...] (host or device memory) -> list over devices of this device's rows ON the device (None for an empty
         shard).  A source that is pinned or already on a GPU is copied asynchronously (`non_blocking`), every device's copy issued
-        before this returns; pageable host memory is copied by one host thread per device, concurrently.  See h2d_ms()."""
+        before this returns; pageable host memory is copied by one host thread per device, concurrently.  See h2d_ms().
+
+        Contract for a PINNED host source: the copies may still be in flight when this returns -- the source must stay untouched until
+        release_sources() has returned (the batched drivers call it before they hand control back, so their callers may refill a pinned
+        staging buffer as soon as the driver returns).  Every copy -- and the shard's allocation -- belongs to the stream that is
+        current for its device in the CALLING thread (the worker threads of the pageable path enter it: torch's current stream is
+        thread-local), so kernels the caller then enqueues on that stream are ordered behind the copy and own the same allocator block."""
         bounds = self.bounds(X.shape[0], group)
         X = X.detach()
         on_host = not X.is_cuda
         use_async = X.is_cuda or X.is_pinned()
         shards = [None] * len(self.devices)
         marks = [None] * len(self.devices)
+        caller_streams = [torch.cuda.current_stream(d) if d.type == "cuda" else None for d in self.devices]
         t0 = time.perf_counter()
 
         def copy_one(i):
@@ -125,7 +132,7 @@ class DeviceSet:
             if d.type != "cuda":   # (host-side tests drive the partition logic with CPU "devices")
                 shards[i] = X[lo:hi].to(dtype).contiguous()
                 return
-            with torch.cuda.device(d):
+            with torch.cuda.device(d), torch.cuda.stream(caller_streams[i]):
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
                 shards[i] = X[lo:hi].to(d, dtype, non_blocking=use_async).contiguous()
@@ -140,8 +147,18 @@ class DeviceSet:
             with ThreadPoolExecutor(len(live)) as ex:   # the copy releases the GIL: the devices' links run side by side
                 list(ex.map(copy_one, live))
         self._h2d = {"marks": marks, "host_ms": (time.perf_counter() - t0) * 1e3, "bytes": int(X[0:0].element_size() * X.numel()) if on_host else 0,
-                     "mode": ("device-to-device" if X.is_cuda else "pinned, asynchronous" if use_async else f"pageable, {max(len(live), 1)} host thread(s)")}
+                     "mode": ("device-to-device" if X.is_cuda else "pinned, asynchronous" if use_async else f"pageable, {max(len(live), 1)} host thread(s)"),
+                     "pending_host_source": bool(on_host and use_async)}
         return shards
+
+    def release_sources(self):
+        """Returns once the last stage()'s asynchronous copies out of PINNED host memory have completed (their end events; kernels enqueued
+        behind them are not waited for): from then on the caller may overwrite the source.  No-op for every other kind of source."""
+        if self._h2d and self._h2d.get("pending_host_source"):
+            for m in self._h2d["marks"]:
+                if m is not None:
+                    m[1].synchronize()
+            self._h2d["pending_host_source"] = False
 
     def h2d_ms(self):
         """Copy time of the last stage(): {"ms": slowest device (HIP events around its copy), "host_ms": wall time of the staging call,

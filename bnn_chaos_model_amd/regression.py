@@ -244,6 +244,7 @@ class FeatureRegressor(object):
             return ops.multiswag(xs[i], wa, w2, pd, seed_t, philox_seed=philox_seed, draw_id0=draw_id0, system_id0=system_id0 + lo, **kw)
 
         res = [r for r in ds.run(B, shard) if r is not None]
+        ds.release_sources()   # (a pinned X may be refilled by the caller from here on)
         self.last_run = {"devices": [str(dv) for dv in ds.devices], "exchange": "concatenation of the shards' rows", "h2d": ds.h2d_ms}
         target = out.device if out is not None else X.device
         nb = torch.device(target).type == "cuda"   # (a non-blocking copy to HOST memory would return before the data has landed)
@@ -290,6 +291,7 @@ class FeatureRegressor(object):
             return torch.cat([sk.percentiles(q), sk.mean().float()[:, None]], 1)
 
         table = ds.gather_rows(ds.run(B, shard, group=trios))
+        ds.release_sources()   # (a pinned X may be refilled by the caller from here on)
         nq = len(tuple(q))
         live = [sk for sk in sketches if sk is not None]
         self.last_run = {"devices": [str(dv) for dv in ds.devices], "exchange": ds.last_exchange, "h2d": ds.h2d_ms}

@@ -35,7 +35,8 @@ def _private(d):
 
 def cache_dir():
     """BNN_SPEC_CACHE, else csrc/_spec next to the library (in-tree, like the built .so: it travels with the tree), else ~/.cache.
-    Created with mode 0700; a directory somebody else owns or may write to is refused (BNN_SPEC_CACHE) or skipped (the defaults)."""
+    Created with mode 0700; a directory somebody else owns or may write to is refused (BNN_SPEC_CACHE) or skipped (the defaults); a
+    BNN_SPEC_CACHE that cannot be created or written raises instead of falling through to the defaults."""
     env = os.environ.get("BNN_SPEC_CACHE")
     for d in (env, os.path.join(CSRC, "_spec"), os.path.join(os.path.expanduser("~"), ".cache", "bnn_chaos_model_amd", "spec")):
         if not d:
@@ -49,8 +50,11 @@ def cache_dir():
                 continue
             if os.access(d, os.W_OK):
                 return d
-        except OSError:
-            pass
+            if d == env:
+                raise RuntimeError(f"BNN_SPEC_CACHE={d} is not writable")
+        except OSError as e:
+            if d == env:   # an explicitly named cache that cannot be created is an error, never a silent fall-through to another one
+                raise RuntimeError(f"BNN_SPEC_CACHE={d} cannot be created: {e}") from e
     raise RuntimeError("no writable private cache directory for specialised kernels (set BNN_SPEC_CACHE)")
 
 

@@ -540,20 +540,30 @@ class SWAGModel(VarModel):
     def _state_gpu(self):
         """(w_avg [1,d], w2_avg [1,d], pre_D [1,d,K]) on the GPU.  The copy is kept while the three attributes stay the same tensor objects at
         the same version (in-place edits and reassignments -- the scripts reassign them with .cuda() / .cpu() copies, regression.py:82-90 --
-        invalidate it; writes through `.data` bypass torch's version counter and do NOT -- reassign the attribute after such an edit): a
+        invalidate it, and so does `set_()`: the storage address is part of the key; writes through `.data` bypass torch's version counter and do NOT
+        -- call invalidate_state() or reassign the attribute after such an edit; inference tensors have no version and are never cached): a
         model whose state lives in host memory (cuda=False) would otherwise send its 0.97 MB across PCIe on every sample_full_swag call
         (0.27 ms of a 0.45 ms call)."""
         g = _gpu()
         if self.w_avg is None:
             raise RuntimeError("SWAG state (w_avg, w2_avg, pre_D) is not set")
         src = (self.w_avg, self.w2_avg, self.pre_D)
-        key = tuple((id(t), t._version, t.device) for t in src) + (g,)
+        f = lambda t: t.detach().to(g, torch.float32).contiguous()
+        try:   # (id, version, storage address, device): reassignment, in-place edits and set_() all change the key
+            key = tuple((id(t), t._version, t.data_ptr(), t.device) for t in src) + (g,)
+        except RuntimeError:   # inference tensors (state assigned under torch.inference_mode()) have no version counter: no cache for them
+            self.__dict__.pop("_state_cache", None)
+            return f(src[0])[None], f(src[1])[None], f(src[2])[None]
         hit = self.__dict__.get("_state_cache")
         if hit is None or hit[0] != key:
-            f = lambda t: t.detach().to(g, torch.float32).contiguous()
             hit = (key, src, (f(src[0])[None], f(src[1])[None], f(src[2])[None]))   # (src is held: the ids in the key stay unique)
             self.__dict__["_state_cache"] = hit
         return hit[2]
+
+    def invalidate_state(self):
+        """Drop the cached GPU copy of (w_avg, w2_avg, pre_D): call after editing them through `.data` (the one kind of write the cache key
+        cannot see)."""
+        self.__dict__.pop("_state_cache", None)
 
     def _draw_noise(self):
         """z_1 = randn((1,d)), z_2 = randn((K,1)) on self.device (:830-831)."""

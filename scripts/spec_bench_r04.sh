@@ -2,6 +2,7 @@
 # Specialised-form bench lines (round 4): each network through the ahead-of-time generic engine and through its run-time-compiled form.
 # Appends JSON lines to gpurun_out/r4_spec_bench.jsonl and prints a one-line summary each.
 set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p gpurun_out
 export BNN_SPEC_CACHE=${BNN_SPEC_CACHE:-$R/bnn_chaos_model_amd/csrc/_spec}   # in-tree (private to the checkout), never a predictable world-writable /tmp path
 run() {
