@@ -485,8 +485,9 @@ int bnn_multiswag_moments_f64(const bnn_plan* plan, const bnn_grid* grid, const 
     if (rc) return rc;
     if (grid->B == 0) return 0;
     if (!moments || !out_workspace || !W_workspace) return fail(BNN_ERR_INVALID, "NULL workspace / moments");
-    // (the first slab overwrites, the others accumulate: no memset node -- see bnn_nonfinite.hip on memset nodes in captured graphs)
-    if (grid->J == 0) HIP_TRY(hipMemsetAsync(moments, 0, sizeof(double) * 4 * (size_t)grid->B, (hipStream_t)stream));
+    // (the first slab overwrites, the others accumulate; no draws at all = the moments kernel over zero rows writes the zeros: NO memset node
+    //  anywhere in this library -- a captured hipMemsetAsync replays with a garbage fill value, see bnn_nonfinite.hip)
+    if (grid->J == 0) return bnn_moments_f64(out_workspace, 0, grid->B, moments, 0, stream);
     for (int32_t j0 = 0; j0 < grid->J; j0 += draws_per_launch) {
         bnn_grid g = *grid;
         g.J = grid->J - j0 < draws_per_launch ? grid->J - j0 : draws_per_launch;

@@ -65,15 +65,31 @@ __global__ __launch_bounds__(256) void bnn_nonfinite_scan_kernel(const float* __
     }
 }
 
-// The record's header is cleared by a KERNEL, not by hipMemsetAsync: inside a captured HIP graph a memset node in front of the kernels
-// was observed to be skipped on the second replay (ROCm 7.2: the fix-up then read a stale count) -- kernel nodes keep their order.
+// The record's header is cleared by a KERNEL, never by hipMemsetAsync.  Round 5's first form used hipMemsetAsync(rec, 0, 16) and failed
+// test_hip_graph_capture_and_replay on the SECOND replay: with x finite in both replays, system 0 came back re-evaluated by the fix-up in
+// IEEE order (14 of 40 rows differed in the last bits).  That symptom means the fix-up saw count >= 1 with all-zero entries -- a NON-ZERO
+// HEADER at fix-up time -- which a skipped memset cannot produce (replay 1 left the header 0).  Round 6 established the cause with a probe
+// that holds no code of this library (scripts/dev/graph_nf_probe3.py micro -> profiles/r06_graph_memset_probe.txt): a hipMemsetAsync(ptr,
+// 0, n) captured by torch.cuda.graph writes zeros on the FIRST launch of the graph exec and, on every later launch, a pointer-like 64-bit
+// pattern (0x78a3_d2e0_0000 ...: [-757063680, 30883, ...] as int32) -- for n = 16, 64 and 4096, into ordinary (not graph-pool) memory;
+// with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 every launch writes zeros.  So the memset node is neither skipped nor reordered: the HIP
+// runtime's graph PACKET CAPTURE (torch 2.10.0+rocm7.0's libamdhip64) replays it with a wrong fill VALUE.  The record's storage plays no
+// part (caller-owned record and graph-pool record behave alike, both libraries).  A garbage header whose first word is positive makes
+// the fix-up walk that many "listed systems", whose entries read as zeros = "system 0, not certain": round 5's symptom.  (And with a
+// damaged x the scan's atomic append lands wherever the garbage count points: the probe's one GPU memory fault.)  Kernel nodes replay correctly,
+// and the captured graph of the current route is one dependency chain reset -> scan -> (draw ->) forward -> fix-up (probe `nodes`).
+// Consequence for this library: NO hipMemsetAsync on any stream-ordered path (the moments slab driver likewise).
 __global__ void bnn_nonfinite_reset_kernel(int32_t* __restrict__ rec) {
     if (threadIdx.x < 4) rec[threadIdx.x] = 0;
 }
 
 hipError_t launch_nonfinite_scan(const float* x, int64_t B, int64_t per, int F, uint64_t zero_mask, int32_t* rec, hipStream_t st) {
+#if defined(BNN_NF_HEADER_MEMSET)   // PROBE BUILDS ONLY (scripts/dev/graph_nf_probe3.py): round 5's first form, a memset node in front of the kernels
+    hipError_t e = hipMemsetAsync(rec, 0, 4 * sizeof(int32_t), st);
+#else
     hipLaunchKernelGGL(bnn_nonfinite_reset_kernel, dim3(1), dim3(64), 0, st, rec);
     hipError_t e = hipGetLastError();
+#endif
     if (e != hipSuccess || B == 0) return e;
     hipLaunchKernelGGL(bnn_nonfinite_scan_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x, B, per, F, zero_mask, rec);
     return hipGetLastError();

@@ -110,18 +110,56 @@ def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto", chunk_B=0, chunk_of
     return g
 
 
+_records = {}          # (device index, stream handle) -> int32 buffer, grow-only: the scan records of eager calls
+_RECORDS_PER_DEVICE = 8
+
+
+def _record_buffer(B, device):
+    """Where the default route keeps the scan record [4 + B] of ONE call.
+
+    Eager calls: a buffer owned by this module per (device, stream), sized on first use and grown when a larger batch arrives -- no
+    allocator call per op once it exists.  Calls on one stream are serialised by the stream (the next call's header reset is ordered
+    behind the previous call's fix-up); calls on different streams get different buffers, so concurrent streams never share a record.
+    Under stream capture: a block of the capturing graph's memory pool (torch.empty during capture), because its lifetime must be the
+    GRAPH's -- the pointer is baked into the captured kernel nodes, and two graphs replayed on different streams must not share a
+    record.  A caller who wants the record out of every allocator passes `nonfinite=` (a tensor they own, filled by nonfinite_scan(x,
+    out=...) inside the captured region)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty((4 + B,), dtype=torch.int32, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _records.get(key)
+    if buf is None or buf.numel() < 4 + B:
+        if buf is None and sum(1 for k in _records if k[0] == device.index) >= _RECORDS_PER_DEVICE:
+            _records.pop(next(k for k in _records if k[0] == device.index))    # oldest stream of this device (freeing is stream-ordered: safe)
+        buf = torch.empty((max(4 + B, 4 + 1024),), dtype=torch.int32, device=device)
+        _records[key] = buf
+    return buf[:4 + B]
+
+
 @_on_device_of(0)
-def nonfinite_scan(x, plan=None):
+def nonfinite_scan(x, plan=None, out=None):
     """One streaming pass over x [B,T,F] -> the record (int32 [4 + B], on x's device) of the systems that hold NaN / +-inf anywhere:
     [0] = how many, [1] = of which certainly NaN whatever the weights (a NaN anywhere, or +-inf in a masked column: the reference's
     `x - mask`, spock_reg_model.py:452-478), [4 + i] = (system << 1) | certain.  Hand it to any op below as `nonfinite=` -- the listed
     systems then get what the reference returns (NaN, or the exact IEEE evaluation where an infinity dies in a ReLU) -- or let the op
-    make it (the default; `assume_finite=True` skips it).  The record can serve any number of calls on the same x."""
+    make it (the default; `assume_finite=True` skips it).  The record can serve any number of calls on the same x.
+    out: a caller-owned int32 [4 + B] tensor to fill (e.g. inside a captured HIP graph); default: a fresh tensor."""
     plan = plan or get_plan()
     x = _f32(x, "x")
     _check_x(x, plan)
     B, T, _ = x.shape
-    rec = torch.empty((4 + B,), dtype=torch.int32, device=x.device)
+    if out is None:
+        rec = torch.empty((4 + B,), dtype=torch.int32, device=x.device)
+    else:
+        rec = _nonfinite_record(x, plan, False, out)
+    N.check(N.lib().bnn_nonfinite_scan_f32(plan.handle, N.ptr(x), B, T, N.ptr(rec), N.stream_ptr()))
+    return rec
+
+
+def _scan_into_own_record(x, plan):
+    """The default route's scan: the record lives in this module's per-(device, stream) buffer (_record_buffer)."""
+    B, T, _ = x.shape
+    rec = _record_buffer(B, x.device)
     N.check(N.lib().bnn_nonfinite_scan_f32(plan.handle, N.ptr(x), B, T, N.ptr(rec), N.stream_ptr()))
     return rec
 
@@ -131,7 +169,7 @@ def _nonfinite_record(x, plan, assume_finite, nonfinite):
         if nonfinite.dtype != torch.int32 or nonfinite.numel() != 4 + x.shape[0] or nonfinite.device != x.device or not nonfinite.is_contiguous():
             raise ValueError(f"nonfinite must be the int32 record [4 + {x.shape[0]}] of nonfinite_scan(x) on x's device")
         return nonfinite
-    return None if assume_finite else nonfinite_scan(x, plan)
+    return None if assume_finite else _scan_into_own_record(x, plan)
 
 
 @_on_device_of(0)

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-6 GPU call runner: each step under its own timeout, logs under gpurun_out/; a step that fails an assertion does not stop the
+# call, a step that is KILLED (timeout: 124 / 137) does -- nothing further touches the GPU after that.
+#   scripts/r06_call.sh <step> [<step> ...]      steps: scale probe edges budget gputests bench
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R" || exit 1
+mkdir -p gpurun_out
+VARIANT=$R/bnn_chaos_model_amd/csrc/libbnn_nfmemset.so
+step() {   # step <name> <seconds> <command...>
+  local name=$1 secs=$2; shift 2
+  echo "=== $name: $*" | tee -a gpurun_out/r06_steps.log
+  timeout -k 10 "$secs" "$@" > "gpurun_out/r06_$name.log" 2>&1
+  local rc=$?
+  echo "=== $name: rc=$rc" | tee -a gpurun_out/r06_steps.log
+  tail -n "${TAILN:-12}" "gpurun_out/r06_$name.log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "KILLED: stopping the call" | tee -a gpurun_out/r06_steps.log; exit $rc; fi
+  return 0
+}
+for s in "$@"; do
+  case $s in
+    scale)   step scale_test 900 python -m pytest tests/test_scale_parity.py -x -q -m gpu -s ;;
+    micro)   step probe_micro 200 python scripts/dev/graph_nf_probe3.py micro default
+             DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 step probe_micro_nocapture 200 python scripts/dev/graph_nf_probe3.py micro packet-capture-off ;;
+    # (the product probe with the memset-header library + a damaged x FAULTS the GPU -- garbage header, out-of-bounds append: run once in
+    #  round 6, never again; graph_nf_probe3.py refuses that combination)
+    nodes)   step probe_nodes 300 python scripts/dev/graph_nf_probe3.py nodes ;;
+    edges)   step edges 900 python -m pytest tests/test_hip_edges.py -x -q -m gpu ;;
+    budget)  step budget_${TAG:-x} 600 python scripts/dev/dropin_budget.py "${TAG:-x}" ;;
+    gputests) TAILN=30 step gputests 1100 python -m pytest tests -x -q -m gpu ;;
+    bench)   step bench 600 python bench.py ;;
+    *) echo "unknown step $s"; exit 2 ;;
+  esac
+done

@@ -348,31 +348,83 @@ def test_non_finite_input_gets_the_reference_answer_and_stays_inside_its_own_sys
     assert torch.equal(blind[:, keep + [30]], clean[:, keep + [30]])
 
 
-def test_hip_graph_capture_and_replay(ops, swag_states):
-    """The ops only enqueue work on the current stream (no allocation, no sync once buffers exist): the two-launch
-    multiswag call can be captured in a HIP graph and replayed."""
+@pytest.mark.parametrize("record", ("default route", "caller-owned"))
+def test_hip_graph_capture_and_replay(record, ops, swag_states):
+    """The ops only enqueue work on the current stream -- no synchronisation, and no allocation on REPLAY: the draw workspace and, on the
+    default route, the scan record are allocated while capturing, from the capturing graph's memory pool (ops._record_buffer says why);
+    with `nonfinite=` + nonfinite_scan(out=...) the record is the caller's tensor and no record is allocated at all.  The two-launch
+    multiswag call is captured once and replayed on the same buffers with clean -> damaged -> clean -> damaged inputs (NaN in a masked
+    column: the direct NaN path; +inf in a live column: the exact re-evaluation): every replay must equal the eager call on the same x,
+    i.e. the record's header is rebuilt by every replay -- 0 -> 2 -> 0 -> 2 listed systems -- and never carried over."""
     wa, w2, pd = (dev(a) for a in state(swag_states))
-    x = dev(synth(700, 100, 21))
+    clean = dev(synth(700, 100, 21))
+    bad = clean.clone()
+    bad[5, 3, 3] = float("nan")        # masked column of the v50 mask
+    bad[9, 7, 12] = float("inf")       # live column
+    x = clean.clone()
     idx = torch.zeros(40, dtype=torch.int32, device="cuda")
     out = torch.empty((40, 700, 2), device="cuda")
-    ref_o = ops.multiswag(x, wa, w2, pd, idx, philox_seed=9, single_launch=False).clone()   # also warms plan + workspace
+    kw = dict(philox_seed=9, single_launch=False)
+    want = {"clean": ops.multiswag(clean, wa, w2, pd, idx, **kw).clone(), "bad": ops.multiswag(bad, wa, w2, pd, idx, **kw).clone()}   # also warms plan + buffers
+    assert torch.isfinite(want["clean"]).all() and torch.isnan(want["bad"][:, [5, 9]]).all() and torch.isfinite(want["bad"][:, 10:]).all()
+    rec = torch.full((4 + 700,), 123, dtype=torch.int32, device="cuda") if record == "caller-owned" else None
+
+    def call():
+        if rec is None:
+            ops.multiswag(x, wa, w2, pd, idx, out=out, **kw)
+        else:
+            ops.multiswag(x, wa, w2, pd, idx, out=out, nonfinite=ops.nonfinite_scan(x, out=rec), **kw)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        ops.multiswag(x, wa, w2, pd, idx, philox_seed=9, single_launch=False, out=out)
+        call()
     torch.cuda.current_stream().wait_stream(s)
     with torch.cuda.graph(g):
-        ops.multiswag(x, wa, w2, pd, idx, philox_seed=9, single_launch=False, out=out)
-    out.zero_()
+        call()
+    same = lambda a, b: torch.equal(a.nan_to_num(nan=-7.0), b.nan_to_num(nan=-7.0)) and torch.equal(torch.isnan(a), torch.isnan(b))
+    for it, kind in enumerate(("clean", "bad", "clean", "bad")):
+        x.copy_(clean if kind == "clean" else bad)
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert same(out, want[kind]), (record, it, kind)
+        if rec is not None:
+            assert rec[:2].tolist() == ([0, 0] if kind == "clean" else [2, 1]), (it, kind, rec[:8].tolist())
+    x.copy_(clean).mul_(1.01)  # new inputs in the same buffers, same graph
     g.replay()
     torch.cuda.synchronize()
-    assert torch.equal(out, ref_o)
-    x.mul_(1.01)  # new inputs in the same buffers, same graph
-    g.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(out, ops.multiswag(x, wa, w2, pd, idx, philox_seed=9, single_launch=False))
+    assert torch.equal(out, ops.multiswag(x, wa, w2, pd, idx, **kw))
+
+
+def test_default_route_keeps_its_scan_record_per_stream(ops, swag_states):
+    """Eager calls: the default route's scan record is a module-owned buffer per (device, stream), sized on first use -- the same storage
+    call after call on one stream (no allocator call per op), another buffer on another stream (concurrent streams never share a record),
+    grown for a larger batch; results are those of a caller-owned record."""
+    wa, w2, pd = (dev(a) for a in state(swag_states))
+    x = dev(synth(300, 100, 5))
+    x[7, 1, 2] = float("nan")
+    idx = torch.zeros(3, dtype=torch.int32, device="cuda")
+    cur = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    a = ops.multiswag(x, wa, w2, pd, idx, philox_seed=3)
+    p0 = ops._records[cur].data_ptr()
+    b = ops.multiswag(x, wa, w2, pd, idx, philox_seed=3)
+    assert ops._records[cur].data_ptr() == p0 and torch.equal(a.nan_to_num(nan=-7.0), b.nan_to_num(nan=-7.0)) and torch.isnan(a[:, 7]).all()
+    c = ops.multiswag(x, wa, w2, pd, idx, philox_seed=3, nonfinite=ops.nonfinite_scan(x))
+    assert torch.equal(a.nan_to_num(nan=-7.0), c.nan_to_num(nan=-7.0))
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        d = ops.multiswag(x, wa, w2, pd, idx, philox_seed=3)
+        assert ops._records[(cur[0], s.cuda_stream)].data_ptr() != p0
+    s.synchronize()
+    assert torch.equal(a.nan_to_num(nan=-7.0), d.nan_to_num(nan=-7.0))
+    big = dev(synth(5000, 100, 6))
+    ops.multiswag(big, wa, w2, pd, idx, philox_seed=3)
+    assert ops._records[cur].numel() >= 4 + 5000
+    e = ops.multiswag(x, wa, w2, pd, idx, philox_seed=3)      # the small batch again, in the grown buffer
+    assert torch.equal(a.nan_to_num(nan=-7.0), e.nan_to_num(nan=-7.0))
 
 
 def test_hundred_thousand_draws_in_one_call(ops, swag_states):

@@ -4,10 +4,11 @@
 float64 truth from the reference run in double.  Inputs and normals are NOT stored: tests/golden/scale_recipe.py regenerates
 them bit for bit (integer hash + one IEEE rounding), checked against the fixture's CRC-32s.
 
-BASELINE.json's bar is 1e-5 relative.  At this size it is a STATISTICAL statement: two fp32 evaluations of this network in
-different summation orders sit beyond 1e-5 of each other (and of the truth) a few times per 10^5 outputs -- the reference itself
-does, against its own float64 run.  The tests therefore hold the HIP path to the MEASURED envelope (profiles/r06_scale_parity.json)
-and to the statement that matters: it is no farther from the float64 truth than the reference is."""
+BASELINE.json's bar is 1e-5 relative TO THE REFERENCE.  Measured (profiles/r06_scale_parity.json): 0 of the 522 240 outputs beyond it,
+maximum 6.8e-6 -- the kernels keep the reference's per-output summation order (bias, inputs ascending) in every Linear layer, so the two
+fp32 evaluations differ only in the pool's partitioning and in tanhf / expf.  Against the float64 TRUTH neither is within 1e-5 everywhere:
+the reference misses it 28 times (max 1.84e-5), the HIP path 30 times (max 1.79e-5) -- the fp32 noise floor of this network, the same for
+both.  The tests assert exactly that: no exceedance against the reference, and no farther from the truth than the reference is."""
 import json
 import os
 import sys
@@ -152,9 +153,11 @@ def test_hip_against_the_reference_at_scale(case):
     assert tot("forward_swag_fast", "hip_vs_truth") <= ENVELOPE["beyond_vs_truth"], tot("forward_swag_fast", "hip_vs_truth")
 
 
-# Set from the first measurement on the MI355X (profiles/r06_scale_parity.json); the HIP path is bit-deterministic, so these are loose
-# only against a different compiler's tanhf / expf.
-ENVELOPE = {"max_between_fp32": 1e-4, "max_vs_truth": 1e-4, "p999_between_fp32": 1e-5, "beyond_between_fp32": 400, "beyond_vs_truth": 400}
+# Measured on the MI355X (profiles/r06_scale_parity.json): HIP vs the reference 0 of 522 240 outputs beyond 1e-5, max 6.8e-6, 99.9 % 2.1e-6
+# (59 % of the outputs bit-identical); against the float64 truth the reference has 28 outputs beyond 1e-5 (max 1.84e-5) and the HIP path 30
+# (max 1.79e-5).  So BASELINE's bar -- 1e-5 relative to the reference, NO exceedance -- holds at this size and is what is asserted; the
+# truth-side numbers get the measured envelope with a little room for another compiler's tanhf / expf (the HIP path is bit-deterministic).
+ENVELOPE = {"max_between_fp32": 1e-5, "beyond_between_fp32": 0, "p999_between_fp32": 3e-6, "max_vs_truth": 2.5e-5, "beyond_vs_truth": 40}
 
 
 @pytest.mark.gpu
