@@ -254,6 +254,8 @@ int bnn_fragment_table(const bnn_arch* arch, int noisy, int which, int16_t* host
     return (int)v.size();
 }
 
+constexpr int64_t TSPLIT_MAX_BLOCKS = 256;   // one tile-split workgroup per CU
+
 static int pick_spc(const bnn_grid* g, int64_t csz, bool xcd_order) {
     if (g->systems_per_block > 0) return g->systems_per_block;
     // The per-workgroup prologue (flat vector -> weight registers, regress_nn fragments) is amortised over the block: prefer big
@@ -311,6 +313,13 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     p.xcd_order = (g->nchunks > 1 || (double)g->B * g->T * NF * sizeof(float) > 256.0 * 1024 * 1024) ? 1 : 0;
     const int64_t cseg = p.csz < g->B ? p.csz : g->B;   // the longest stretch of one chunk inside this call's rows
     p.spc = pick_spc(g, cseg, p.xcd_order != 0);
+    // Small grids (the evaluation scripts' per-chunk calls: 15 .. 3 000 rows under one draw) take the TILE-SPLIT form of the pretrained
+    // network's kernel: 16 systems per workgroup, the four waves sharing a batch's tiles (bnn_forward.hip.h, TSPLIT) -- same bits, a
+    // quarter of the time per batch -- as long as every workgroup is resident at once (one per CU: 93 KB of LDS).  An explicit
+    // systems_per_block keeps the plain form (that is also how the tests compare the two).
+    const bool tsplit = !generic && !lowp && !noisy && !p.sink && !pl->megno && pl->tab[0].kin4 == 31 && g->systems_per_block == 0 &&
+                        ((cseg + 15) / 16) * (int64_t)g->J <= TSPLIT_MAX_BLOCKS;
+    if (tsplit) p.spc = 16;
     p.row_id0 = p.draw_id0 / g->nchunks;
     p.tab_f2 = pl->d_f2; p.tab_wr = noisy ? pl->d_f4n : pl->d_f4; p.rcp_tab = pl->d_rcp;
     p.zero_mask = pl->arch.zero_mask;
@@ -354,6 +363,7 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
         else if (lowp) e = launch_fwd_lowp(lowp, (unsigned)nblk, st, p);
         else if (p.sink) e = launch_fwd_stats(k31, (unsigned)nblk, st, p);
         else if (noisy) e = launch_fwd_noisy((unsigned)nblk, st, p);
+        else if (tsplit) e = launch_fwd_small(fused, (unsigned)nblk, st, p);
         else if (k31) e = launch_fwd_k31(fused, (unsigned)nblk, st, p);
         else e = launch_fwd_k41(fused, (unsigned)nblk, st, p);
         if (e != hipSuccess) return fail(BNN_ERR_HIP, std::string("forward kernel launch: ") + hipGetErrorString(e));

@@ -328,10 +328,30 @@ DEVINL float draw_row_direct(const float* __restrict__ w_avg_s, const float* __r
     float w = wa + t1;
     float dot = 0.0f;
     const float* row = pre_D_s + (int64_t)i * K;
+    if (K == 30) {
+        // the reference's rank (run_swag.py:37): a row is 120 bytes -- seven 16-byte loads and one 8-byte load (global loads need dword
+        // alignment only), ALL in flight before the first fmaf: one L2 round trip per element instead of five, and 8 instead of 30
+        // requests per lane at the texture addresser, which is what bounds this loop (64 lanes x 120-byte stride = 60 cache lines per
+        // instruction).  The k-ordered chain below is the same chain: same bits.
+        f32x4 v[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) v[q] = *reinterpret_cast<const f32x4u*>(row + 4 * q);
+        const f32x2 t = *reinterpret_cast<const f32x2u*>(row + 28);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            dot = fmaf(v[q].x - wa, zsh[4 * q], dot);
+            dot = fmaf(v[q].y - wa, zsh[4 * q + 1], dot);
+            dot = fmaf(v[q].z - wa, zsh[4 * q + 2], dot);
+            dot = fmaf(v[q].w - wa, zsh[4 * q + 3], dot);
+        }
+        dot = fmaf(t.x - wa, zsh[28], dot);
+        dot = fmaf(t.y - wa, zsh[29], dot);
+    } else {
 #pragma unroll 6
-    for (int k = 0; k < K; ++k) {
-        float Dk = row[k] - wa;
-        dot = fmaf(Dk, zsh[k], dot);
+        for (int k = 0; k < K; ++k) {
+            float Dk = row[k] - wa;
+            dot = fmaf(Dk, zsh[k], dot);
+        }
     }
     float t2 = (scale * dot) / c2;
     return w + t2;

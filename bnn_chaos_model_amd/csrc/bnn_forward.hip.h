@@ -63,15 +63,23 @@ constexpr int MEGSCR = 32;         // LDS floats per wave: [16 systems][megno me
 constexpr int NSC4 = 96 + 2 * 56;  // LDS floats of the noisy forward: exp(logvar/2) for 41 inputs + 40 summaries (padded to 96), then
                                    // per 6-column noise block, padded to 8: the input scales [7][8] and the column keep-masks [7][8]
 
-template <int KIN>
-constexpr size_t fwd_lds_bytes() { return sizeof(float) * (FLAT_LDS + MAXK + BIAS_PAD + 4 * SCR4 + NSC4 + 4 * MEGSCR); }
+constexpr int YBUF4 = 2 * 4 * 5 * 64;   // TSPLIT: float4 slots of the latent exchange, [buffer][wave][latent group][lane]
+
+template <int KIN, bool TSPLIT = false>
+constexpr size_t fwd_lds_bytes() { return sizeof(float) * (FLAT_LDS + MAXK + BIAS_PAD + 4 * SCR4 + NSC4 + 4 * MEGSCR + (TSPLIT ? 4 * YBUF4 : 0)); }
 
 // MEGNO: hparams['fix_megno'] (spock_reg_model.py:360-362, 480-491, 509-510): the summary gains the time mean and unbiased std of
 // the RAW MEGNO column (read before the masks and before any noise), pooled with the same per-lane Welford + quad merge as the
 // latents; regress_nn.0 takes 42 inputs (an 11th k-step), the flat vector is Lay<true> (d = 7665).
 // XNOISE (noisy forms): the input and summary noise come from explicit tensors (parity mode: the reference's numbers) instead of
 // in-kernel Philox; a template parameter rather than a wave-uniform branch per noise block (7 branches + dead loads per tile).
-template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false, bool XNOISE = false>
+// TSPLIT (small grids: the evaluation scripts' per-chunk calls, 15 .. 3 000 rows under ONE draw -- figures/multiswag_5_planet.py:295-298,
+// figures/main_figures.py:154-156): a workgroup owns 16 systems and its four waves split the TILES between them (wave w takes tiles
+// w, w + 4, ...), so a call whose whole grid is a few hundred wave-batches spreads over four times as many SIMDs and a batch's 25 tiles
+// take 7 rounds instead of 25.  The pool must not change: each round's latents go through LDS to wave 0, which runs the SAME per-lane
+// Welford chain over the tiles in ascending order -- bit-identical outputs to the plain form (tested), which is why this is a launch
+// form and not another engine.  One barrier per round (double-buffered exchange).
+template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false, bool XNOISE = false, bool TSPLIT = false>
 __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) {
     using WRL = WR<KIN>;
     using Y = Lay<MEGNO>;
@@ -81,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     constexpr bool PREF = BNN_BIAS_PREFETCH && KIN == 31 && !MEGNO;   // the other forms have no registers to spare for it
     constexpr bool RBATCH = BNN_RELU_BATCH != 0;
     static_assert(!NOISY || (KIN == F && !FUSED && !STATS), "the noisy forward multiplies all 41 columns and takes materialised weights");
+    static_assert(!TSPLIT || (!NOISY && !MEGNO && !STATS), "the tile-split launch form is built for the quiet forward only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* flat = lds;                 // [FLAT_LDS] flat parameter vector + zero slot, later ...
     float* f2frag = lds;               // ... [NF2][64] regress_nn operands in fragment order
@@ -89,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     float* scr = wl + BIAS_PAD;        // [4][SCR4]
     float* nsc = scr + 4 * SCR4;       // [NSC4] (NOISY only)
     float* megscr = nsc + NSC4;        // [4][MEGSCR] (MEGNO only)
+    f32x4* ybuf = reinterpret_cast<f32x4*>(megscr + 4 * MEGSCR);   // [2][4][5][64] (TSPLIT only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,6 +122,19 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     if (b0 >= b1) return;
 
     // ---- prologue: flat parameter vector of draw e -> LDS -> weight registers, bias image, regress_nn fragments
+    // The gather tables (wave-invariant: 58 + 7 small loads per lane) are requested FIRST, so that they travel while the parameter
+    // vector is copied / sampled -- one memory round trip instead of three in a row (a small grid's whole run time is a few of them).
+    constexpr int NF2 = Y::NF2;
+    constexpr int PER = (NF2 + 3) / 4;
+    int twr[WRL::NR], idx[PER];
+#pragma unroll
+    for (int R = 0; R < WRL::NR; ++R) twr[R] = p.tab_wr[R * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int f = wave + 4 * i;
+        idx[i] = p.tab_f2[(f < NF2 ? f : NF2 - 1) * 64 + lane];
+    }
+    asm volatile("" ::: "memory");
     bool bad_seed = false;
     if constexpr (FUSED) {
         int s = p.seed_idx[e];
@@ -123,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         const float* w2 = p.w2_avg + (int64_t)s * D;
         const float* pd = p.pre_D + (int64_t)s * D * K;
         __syncthreads();
+#pragma unroll 3   // (three elements' loads in flight: the loop is a chain of L2 round trips)
         for (int i = tid; i < D; i += 256) {
             float z1v = p.z1 ? p.z1[(int64_t)e * D + i] : philox_z(TAG_Z1, p.draw_id0 + e, i, p.seed);
             flat[i] = draw_row_direct(wa, w2, pd, i, K, zsh, z1v, p.c1, p.c2, p.scale);
@@ -137,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     // layer's MFMA number m = 16R + a = k * groups + n (bnn_layout.h, WR<KIN>); biases -> a small LDS image
     float wr[WRL::NR];
 #pragma unroll
-    for (int R = 0; R < WRL::NR; ++R) wr[R] = flat[p.tab_wr[R * 64 + lane]];
+    for (int R = 0; R < WRL::NR; ++R) wr[R] = flat[twr[R]];
     if (tid < 2 * H + L) wl[tid] = flat[tid < H ? Y::B1 + tid : tid < 2 * H ? Y::B2 + (tid - H) : Y::B3 + (tid - 2 * H)];
     if constexpr (NOISY) {  // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
         if (tid < F + Y::SM) nsc[tid] = expf(flat[Y::INLV + tid] / 2.0f);
@@ -148,17 +172,9 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
             nsc[96 + 56 + tid] = (live && !((p.zero_mask >> col) & 1ull)) ? 1.0f : 0.0f;
         }
     }
-    {   // regress_nn operands replace the flat vector in place: gather to registers, barrier, write.  All table entries are
-        // fetched first (branch-free, clamped), so the 25 global loads are in flight together.
-        constexpr int NF2 = Y::NF2;
-        constexpr int PER = (NF2 + 3) / 4;
-        int idx[PER];
+    {   // regress_nn operands replace the flat vector in place: gather to registers, barrier, write (table entries: fetched at the top,
+        // branch-free, clamped).
         float tmp[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int f = wave + 4 * i;
-            idx[i] = p.tab_f2[(f < NF2 ? f : NF2 - 1) * 64 + lane];
-        }
 #pragma unroll
         for (int i = 0; i < PER; ++i) tmp[i] = flat[idx[i]];
         __syncthreads();
@@ -180,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     float* epsscr = scr + wave * SCR4;
     float* sumscr = epsscr + 16 * S2;
 
-    for (int64_t wb0 = b0 + (int64_t)wave * 16; wb0 < b1; wb0 += 64) {
+    for (int64_t wb0 = b0 + (TSPLIT ? 0 : (int64_t)wave * 16); wb0 < b1; wb0 += (TSPLIT ? 16 : 64)) {
+        if constexpr (TSPLIT) __syncthreads();   // (wave 0 may still be in the previous batch's tail, reading the exchange buffer)
         const int64_t sys0 = wb0 + sl0;
         const bool valid0 = sys0 < b1;
         const int64_t sysc0 = valid0 ? sys0 : b1 - 1;
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         for (int n = 0; n < 5; ++n) { mean[n] = (f32x4){0, 0, 0, 0}; m2[n] = (f32x4){0, 0, 0, 0}; }
 
         float xv[KIN];
-        load_row<KIN>(rowp, xv);
+        load_row<KIN>(rowp + (TSPLIT ? (int64_t)(wave < ntiles ? wave : 0) * 4 * F : 0), xv);   // this wave's first tile
         float xmeg = 0.0f, gmean = 0.0f, gm2 = 0.0f;   // MEGNO: the raw column 7 of this lane's row, its running mean and M2
         if constexpr (MEGNO) xmeg = rowp[MEGNO_COL];
         asm volatile("" ::: "memory");
@@ -218,7 +235,8 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
             if constexpr (RBATCH) __builtin_amdgcn_sched_barrier(0);
         };
         if constexpr (PREF) bias10(h, bq1);
-        for (int it = 0; it < ntiles; ++it) {
+        // one tile of feature_nn: rows of tile `it` (in xv) -> latents y; fetches tile `it_next`'s rows into xv behind feature_nn.0
+        auto tile = [&](const int it, const int it_next) {
             if constexpr (MEGNO) {   // summarize_megno (:480-484): Welford over the lane's timesteps, like the latents below
                 const float rcm = p.rcp_tab[it];
                 const float dl = xmeg - gmean;
@@ -293,8 +311,8 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
             // x of this tile is dead: fetch the next tile's rows into the same registers, one tile of work to land.  All nine loads in
             // ONE burst: spread over the MFMAs of feature_nn.2 (one per 20 or 36) the kernel measured 14-20 % SLOWER
             // (profiles/r03_ab_variants.txt).
-            load_row<KIN>(rowp + (int64_t)((it + 1 < ntiles) ? it + 1 : it) * 4 * F, xv);
-            if constexpr (MEGNO) xmeg = rowp[(int64_t)((it + 1 < ntiles) ? it + 1 : it) * 4 * F + MEGNO_COL];
+            load_row<KIN>(rowp + (int64_t)it_next * 4 * F, xv);
+            if constexpr (MEGNO) xmeg = rowp[(int64_t)it_next * 4 * F + MEGNO_COL];
             asm volatile("" ::: "memory");
 #endif
             // feature_nn.2 + ReLU: MFMA m = k * 10 + n
@@ -319,22 +337,50 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                 constexpr int m = M, k = m / 5, n = m % 5;
                 y[n] = mfma4b<(m & 15)>(wr[WRL::R1 + WRL::R2 + (m >> 4)], h2[k >> 2][k & 3], y[n]);
             });
-            // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps
+        };
+        // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps, tile `it` = its (it + 1)-th
+        auto pool = [&](const int it, const f32x4 (&yy)[5]) {
 #if BNN_ABLATE & 2
 #pragma unroll
-            for (int n = 0; n < 5; ++n) asm volatile("" : : "v"(y[n]));   // the latents stay computed, nothing consumes them
+            for (int n = 0; n < 5; ++n) asm volatile("" : : "v"(yy[n]));   // the latents stay computed, nothing consumes them
 #else
             const float rcn = p.rcp_tab[it];
 #pragma unroll
             for (int n = 0; n < 5; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float dl = y[n][i] - mean[n][i];
+                    float dl = yy[n][i] - mean[n][i];
                     float mn = fmaf(dl, rcn, mean[n][i]);
-                    m2[n][i] = fmaf(dl, y[n][i] - mn, m2[n][i]);
+                    m2[n][i] = fmaf(dl, yy[n][i] - mn, m2[n][i]);
                     mean[n][i] = mn;
                 }
 #endif
+        };
+        if constexpr (!TSPLIT) {
+            for (int it = 0; it < ntiles; ++it) {
+                tile(it, (it + 1 < ntiles) ? it + 1 : it);
+                pool(it, y);
+            }
+        } else {
+            for (int it0 = 0; it0 < ntiles; it0 += 4) {   // a round: tile it0 + w on wave w, then wave 0 pools the round's tiles in order
+                const int it = it0 + wave;
+                f32x4* yb = ybuf + ((it0 >> 2) & 1) * (4 * 5 * 64);
+                if (it < ntiles) {
+                    tile(it, (it + 4 < ntiles) ? it + 4 : it);
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) yb[(wave * 5 + n) * 64 + lane] = y[n];
+                }
+                __syncthreads();   // (the next round writes the OTHER buffer; wave 0 is through with this one before it reaches the next barrier)
+                if (wave == 0) {
+                    for (int w = 0; w < 4 && it0 + w < ntiles; ++w) {
+                        f32x4 yy[5];
+#pragma unroll
+                        for (int n = 0; n < 5; ++n) yy[n] = yb[(w * 5 + n) * 64 + lane];
+                        pool(it0 + w, yy);
+                    }
+                }
+            }
+            if (wave != 0) continue;   // the tail (merge, sampled moments, regress_nn, outputs) is wave 0's
         }
 #if BNN_ABLATE & 8
         {
@@ -503,10 +549,11 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     }
 }
 
-template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false, bool XNOISE = false>
+template <int KIN, bool FUSED, bool NOISY, bool STATS, bool MEGNO = false, bool XNOISE = false, bool TSPLIT = false>
 inline hipError_t launch_forward_form(unsigned nblk, hipStream_t st, const FwdParams& p) {
-    allow_big_lds<&bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO, XNOISE>>();   // once per (function, device), thread-safe
-    hipLaunchKernelGGL((bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO, XNOISE>), dim3(nblk), dim3(256), fwd_lds_bytes<KIN>(), st, p);
+    allow_big_lds<&bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO, XNOISE, TSPLIT>>();   // once per (function, device), thread-safe
+    constexpr size_t lds_bytes = fwd_lds_bytes<KIN, TSPLIT>();
+    hipLaunchKernelGGL((bnn_forward_kernel<KIN, FUSED, NOISY, STATS, MEGNO, XNOISE, TSPLIT>), dim3(nblk), dim3(256), lds_bytes, st, p);
     return hipGetLastError();
 }
 

@@ -40,7 +40,7 @@ struct FwdParams {
     int64_t csz;  // chunk size = ceil(cB / nch): torch.chunk over the whole batch
     int64_t cB;   // systems of the whole batch the chunks partition (= B unless the batch is sharded over devices)
     int64_t coff; // index of this call's row 0 in that batch
-    int32_t spc;  // systems per workgroup (multiple of 64)
+    int32_t spc;  // systems per workgroup (multiple of 64; 16 in the tile-split form)
     int32_t xcd_order;  // 1: XCD k takes the k-th contiguous eighth of the work order (work_item, bnn_common.hip.h)
     int32_t K, S;
     const float* W;  // [J,d] materialised draws (unfused) or nullptr
@@ -96,6 +96,7 @@ constexpr int RCP_N = 4096;  // supports T up to 16384 timesteps
 // Each returns hipGetLastError() after the launch.  grid = (draw, block-of-systems) pairs, 256 threads.
 hipError_t launch_fwd_k31(bool fused, unsigned nblk, hipStream_t st, const FwdParams& p);
 hipError_t launch_fwd_k41(bool fused, unsigned nblk, hipStream_t st, const FwdParams& p);
+hipError_t launch_fwd_small(bool fused, unsigned nblk, hipStream_t st, const FwdParams& p);   // v50 mask, tile-split form: 16 systems per workgroup (small grids)
 hipError_t launch_fwd_noisy(unsigned nblk, hipStream_t st, const FwdParams& p);
 hipError_t launch_fwd_stats(bool k31, unsigned nblk, hipStream_t st, const FwdParams& p);  // quiet forward + fused statistics tail
 hipError_t launch_fwd_lowp(int precision, unsigned nblk, hipStream_t st, const FwdParams& p);  // bf16 / half matrix pipe (bnn_precision)

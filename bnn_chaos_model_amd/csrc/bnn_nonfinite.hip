@@ -130,6 +130,8 @@ template <bool WLDS>
 __global__ __launch_bounds__(256) void bnn_nonfinite_fixup_kernel(const NfxParams q) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FwdParams& p = q.f;
+    // an empty list (the normal case: this launch follows EVERY forward launch) is left before anything else is read
+    if (__builtin_amdgcn_readfirstlane(q.rec[0]) <= 0) return;
     const GenArch4* Gc = (const GenArch4*)(uintptr_t)q.g;
     struct { int F, L, SM, d, megno, n_feat, n_reg, nin_blocks, off_inlv, off_sumlv; } G = {Gc->F, Gc->L, Gc->SM, Gc->d, Gc->megno, Gc->n_feat, Gc->n_reg,
                                                                                             Gc->nin_blocks, Gc->off_inlv, Gc->off_sumlv};

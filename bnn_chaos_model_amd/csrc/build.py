@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libbnn_chaos_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 # translation units (bnn_internal.h says what each holds); the forward-kernel units dominate the build time
-SRCS = ["bnn_fwd_generic.hip", "bnn_fwd_generic82.hip", "bnn_fwd_v50spec.hip", "bnn_fwd_k31.hip", "bnn_fwd_k41.hip", "bnn_fwd_noisy.hip", "bnn_fwd_stats.hip", "bnn_fwd_megno.hip", "bnn_fwd_lowp.hip",
+SRCS = ["bnn_fwd_generic.hip", "bnn_fwd_generic82.hip", "bnn_fwd_v50spec.hip", "bnn_fwd_k31.hip", "bnn_fwd_small.hip", "bnn_fwd_k41.hip", "bnn_fwd_noisy.hip", "bnn_fwd_stats.hip", "bnn_fwd_megno.hip", "bnn_fwd_lowp.hip",
         "bnn_abi.hip", "bnn_ops_draw.hip", "bnn_ops_reduce.hip", "bnn_ops_stats.hip", "bnn_ops_features.hip", "bnn_nonfinite.hip", "bnn_tables.cpp", "bnn_generic.cpp"]
 HEADERS = ["bnn_layout.h", "bnn_tables.h", "bnn_internal.h", "bnn_abi_common.h", "bnn_common.hip.h", "bnn_stats.hip.h", "bnn_forward.hip.h",
            "bnn_lowp.hip.h", "bnn_generic.h", "bnn_generic.hip.h", os.path.join("..", "..", "include", "bnn_chaos_hip.h")]

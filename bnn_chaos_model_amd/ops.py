@@ -111,10 +111,11 @@ def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto", chunk_B=0, chunk_of
 
 
 _records = {}          # (device index, stream handle) -> int32 buffer, grow-only: the scan records of eager calls
+_record_views = {}     # the same key -> {B: buffer[:4 + B]}
 _RECORDS_PER_DEVICE = 8
 
 
-def _record_buffer(B, device):
+def _record_buffer(B, device, stream_handle):
     """Where the default route keeps the scan record [4 + B] of ONE call.
 
     Eager calls: a buffer owned by this module per (device, stream), sized on first use and grown when a larger batch arrives -- no
@@ -126,14 +127,23 @@ def _record_buffer(B, device):
     out=...) inside the captured region)."""
     if torch.cuda.is_current_stream_capturing():
         return torch.empty((4 + B,), dtype=torch.int32, device=device)
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _records.get(key)
-    if buf is None or buf.numel() < 4 + B:
-        if buf is None and sum(1 for k in _records if k[0] == device.index) >= _RECORDS_PER_DEVICE:
-            _records.pop(next(k for k in _records if k[0] == device.index))    # oldest stream of this device (freeing is stream-ordered: safe)
-        buf = torch.empty((max(4 + B, 4 + 1024),), dtype=torch.int32, device=device)
-        _records[key] = buf
-    return buf[:4 + B]
+    key = (device.index, stream_handle)
+    ent = _records.get(key)
+    if ent is None or ent.numel() < 4 + B:
+        if ent is None and sum(1 for k in _records if k[0] == device.index) >= _RECORDS_PER_DEVICE:
+            old = next(k for k in _records if k[0] == device.index)    # oldest stream of this device (freeing is stream-ordered: safe)
+            _records.pop(old)
+            _record_views.pop(old, None)
+        ent = torch.empty((max(4 + B, 4 + 1024),), dtype=torch.int32, device=device)
+        _records[key] = ent
+        _record_views[key] = {}
+    views = _record_views[key]
+    v = views.get(B)
+    if v is None:
+        if len(views) > 64:
+            views.clear()
+        v = views[B] = ent[:4 + B]      # (a view per batch size, made once: slicing a tensor costs microseconds)
+    return v
 
 
 @_on_device_of(0)
@@ -159,8 +169,9 @@ def nonfinite_scan(x, plan=None, out=None):
 def _scan_into_own_record(x, plan):
     """The default route's scan: the record lives in this module's per-(device, stream) buffer (_record_buffer)."""
     B, T, _ = x.shape
-    rec = _record_buffer(B, x.device)
-    N.check(N.lib().bnn_nonfinite_scan_f32(plan.handle, N.ptr(x), B, T, N.ptr(rec), N.stream_ptr()))
+    st = torch.cuda.current_stream(x.device).cuda_stream
+    rec = _record_buffer(B, x.device, st)
+    N.check(N.lib().bnn_nonfinite_scan_f32(plan.handle, x.data_ptr(), B, T, rec.data_ptr(), st))
     return rec
 
 
@@ -339,7 +350,8 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
     _check_x(x, plan)
     w_avg, w2_avg, pre_D, S, d, K = _ensemble(plan, w_avg, w2_avg, pre_D)
     B, T, _ = x.shape
-    seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()
+    if seed_idx.device != x.device or seed_idx.dtype != torch.int32 or not seed_idx.is_contiguous():
+        seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()
     J = seed_idx.numel()
     _check_grid(J, nchunks, draw_id0)
     R = J // nchunks
@@ -364,7 +376,13 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
             raise NotImplementedError("single_launch (in-prologue draw) exists for the pretrained network at T % 4 == 0, K <= 32 only")
         single_launch = False
     if single_launch is None:
-        single_launch = -(-(chunk_B or B) // max(nchunks, 1)) <= 256
+        csz = -(-(chunk_B or B) // max(nchunks, 1))
+        # few systems per draw: every workgroup samples its draw in its prologue (no workspace, no draw launch).  That includes the small
+        # grids the library runs in its tile-split form (16 systems per workgroup, at most one workgroup per CU: bnn_abi.hip
+        # TSPLIT_MAX_BLOCKS) -- e.g. the 3 000-row batches of figures/main_figures.py:154-156 under ONE draw: 188 prologue draws side by
+        # side cost 7 us, a draw launch in front of the forward 24.
+        single_launch = csz <= 256 or (systems_per_block == 0 and plan.v50net and not plan.fix_megno and plan.arch.zero_mask == V50_ZERO_MASK
+                                       and -(-min(csz, B) // 16) * J <= 256)
     ws = None if single_launch else _workspace(J, d, x.device)
     N.check(N.lib().bnn_multiswag_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
                                       N.ptr(seed_idx), N.ptr(z1), N.ptr(z2), N.ptr(eps), float(scale), int(philox_seed),
@@ -502,7 +520,8 @@ def multiswag_stats(x, w_avg, w2_avg, pre_D, seed_idx, st=None, z1=None, z2=None
     _check_x(x, plan)
     w_avg, w2_avg, pre_D, S, d, K = _ensemble(plan, w_avg, w2_avg, pre_D)
     B, T, _ = x.shape
-    seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()
+    if seed_idx.device != x.device or seed_idx.dtype != torch.int32 or not seed_idx.is_contiguous():
+        seed_idx = seed_idx.to(device=x.device, dtype=torch.int32).contiguous()
     J = seed_idx.numel()
     _check_grid(J, nchunks, draw_id0)
     R = J // nchunks

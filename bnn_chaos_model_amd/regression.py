@@ -133,7 +133,7 @@ class FeatureRegressor(object):
             swag_model.cuda()
         out = swag_model.forward_swag_fast(X_sample, scale=0.5)
         if self.cuda:
-            swag_model.cpu()
+            swag_model.cpu()   # (a device label while the call's draw is pending: nothing is copied, spock_reg_model.VarModel.to)
         return out
 
     def sample(self, sim, indices=None, samples=1000):

@@ -111,10 +111,74 @@ def _state_layout(fix_megno=False, n_features=41, hidden=40, latent=20, depth_in
 _STATE_LAYOUT = _state_layout(False)
 
 
+_GPU_SEEN = False
+_GPU_DEVS = {}
+_CPU = torch.device("cpu")
+
+
 def _gpu():
-    if not torch.cuda.is_available():
-        raise RuntimeError("bnn_chaos_model_amd needs an MI355X (gfx950) GPU: there is no CPU implementation")
-    return torch.device("cuda", torch.cuda.current_device())
+    """The current GPU as a torch.device (availability is asked once; the device objects are made once per index: this runs per call of
+    the scripts' per-chunk loop)."""
+    global _GPU_SEEN
+    if not _GPU_SEEN:
+        if not torch.cuda.is_available():
+            raise RuntimeError("bnn_chaos_model_amd needs an MI355X (gfx950) GPU: there is no CPU implementation")
+        _GPU_SEEN = True
+    i = torch.cuda.current_device()
+    d = _GPU_DEVS.get(i)
+    if d is None:
+        d = _GPU_DEVS[i] = torch.device("cuda", i)
+    return d
+
+
+_TOPS = None       # torch.ops.bnn_chaos once torch_ops has registered it
+_IDX0 = {}         # device -> int32 [1] zeros: "ensemble member 0" of a one-member state (made once, not once per call)
+
+
+def _idx0(g):
+    t = _IDX0.get(g)
+    if t is None:
+        t = _IDX0[g] = torch.zeros(1, dtype=torch.int32, device=g)
+    return t
+
+
+_STRIDED_OK = {}   # device -> bool
+_TORCH_RANDN = torch.randn
+
+
+def _strided_normal_is_randn(g):
+    """True when `view.normal_()` on a strided [B, latent] view of a [B, 2, latent] tensor draws exactly what torch.randn(B, latent) draws
+    from the same generator state -- asked of the GPU's generator once per device, on a copy of its state (the global stream is not
+    advanced).  It does with torch 2.10 (the kernel maps logical element index -> Philox counter whatever the strides); if a torch version
+    ever changes that, the surface goes back to two torch.randn calls + a stack and stays on the reference's stream."""
+    if torch.randn is not _TORCH_RANDN:   # somebody records or replays the draws (tests' tapes and players patch torch.randn): draw through it
+        return False
+    ok = _STRIDED_OK.get(g)
+    if ok is None:
+        state = torch.cuda.get_rng_state(g)
+        try:
+            ok = True
+            for B in (3, 700):
+                torch.cuda.set_rng_state(state, g)
+                a, b = torch.randn(B, 20, device=g), torch.randn(B, 20, device=g)
+                torch.cuda.set_rng_state(state, g)
+                buf = torch.empty((B, 2, 20), device=g)
+                buf[:, 0].normal_()
+                buf[:, 1].normal_()
+                ok = ok and bool(torch.equal(buf[:, 0], a)) and bool(torch.equal(buf[:, 1], b))
+        finally:
+            torch.cuda.set_rng_state(state, g)
+        _STRIDED_OK[g] = ok
+    return ok
+
+
+def _as_gpu_f32(t, g):
+    """t as a contiguous float32 tensor on GPU g -- t itself when it already is one (a no-op .to() / .contiguous() pair still costs
+    microseconds, and the scripts' loop pays it per 15-row chunk)."""
+    t = t.detach()
+    if t.device == g and t.dtype == torch.float32 and t.is_contiguous():
+        return t
+    return t.to(g, torch.float32).contiguous()
 
 
 class VarModel:
@@ -214,7 +278,7 @@ class VarModel:
             xg, Wg, eps_in, noisy, did, plan, seed = self._last_latents_args
             if callable(Wg):   # after forward_swag_fast: the weights its fused kernel drew, re-drawn on demand from the call's own normals
                 Wg = Wg()[None].to(xg.device)   # (a closure over the draw, not over the module: load() / sample_weights() since do not matter)
-            self._latents_cache = ops.feature_latents(xg, Wg, eps_in=eps_in, noisy=noisy, philox_seed=seed, draw_id0=did, plan=plan,
+            self._latents_cache = ops.feature_latents(xg, Wg, eps_in=eps_in, noisy=noisy, philox_seed=seed, draw_id0=did, plan=plan or self._plan(),
                                                       assume_finite=self.assume_finite)[0]
         return self._latents_cache
 
@@ -249,13 +313,13 @@ class VarModel:
         self._w_store = v
 
     def to(self, device):
-        self._device = torch.device(device)
+        self._device = device if isinstance(device, torch.device) else torch.device(device)
         if self._pending_draw is None:  # a pending in-kernel draw stays pending: it lands on the new device when asked for
             self._w_store = self._w_store.to(self._device)
         return self
 
     def cpu(self):
-        return self.to("cpu")
+        return self.to(_CPU)
 
     def cuda(self, device=None):
         return self.to(_gpu() if device is None else device)
@@ -309,14 +373,24 @@ class VarModel:
                                         self.include_eplusminus)
 
     def _op_args(self):
-        """(zero_mask, lowest_std, net) as the torch.ops.bnn_chaos.* entry points take them (torch_ops.py)."""
-        a = self._arch
-        return self.zero_mask(), float(self.lowest), [a["n_features"], a["hidden"], a["latent"], a["depth_in"], a["depth_out"], int(self.fix_megno)]
+        """(zero_mask, lowest_std, net) as the torch.ops.bnn_chaos.* entry points take them (torch_ops.py).  Rebuilt only when one of the
+        flags it is made of has changed (the scripts' loop calls this once per chunk per sample)."""
+        key = (self.fix_megno, self.fix_megno2, self.include_mmr, self.include_nan, self.include_eplusminus, self.lowest)
+        hit = self.__dict__.get("_op_args_cache")
+        if hit is None or hit[0] != key:
+            a = self._arch
+            hit = (key, (self.zero_mask(), float(self.lowest),
+                         [a["n_features"], a["hidden"], a["latent"], a["depth_in"], a["depth_out"], int(self.fix_megno)]))
+            self.__dict__["_op_args_cache"] = hit
+        return hit[1]
 
     @staticmethod
     def _tops():
-        from . import torch_ops  # noqa: F401  (registers torch.ops.bnn_chaos.*)
-        return torch.ops.bnn_chaos
+        global _TOPS
+        if _TOPS is None:
+            from . import torch_ops  # noqa: F401  (registers torch.ops.bnn_chaos.*)
+            _TOPS = torch.ops.bnn_chaos
+        return _TOPS
 
     def _plan(self, zero_mask=None, device=None):
         plan = ops.get_plan(self.zero_mask() if zero_mask is None else zero_mask, self.lowest, device=device, fix_megno=self.fix_megno,
@@ -593,14 +667,19 @@ class SWAGModel(VarModel):
         return self.forward_swag_fast(x, scale=scale)
 
     def forward_swag_fast(self, x, scale=0.5):
-        """Sample weights, then forward without input/summary noise (:878-908), in ONE fused kernel."""
+        """Sample weights, then forward without input/summary noise (:878-908), in ONE fused kernel.
+        The scripts call this once per chunk per sample (figures/multiswag_5_planet.py:295-298: 15 rows a call), so the host path is kept
+        short: nothing is converted or copied that already is what the kernel takes (_as_gpu_f32), the per-device constants are made once
+        (_idx0), the op's arguments once per model (_op_args), and the plan is looked up only if somebody reads the sampled weights."""
         self._check_x(x)
         dev_in = x.device
         wa, w2, pd = self._state_gpu()
         g = wa.device
-        xg = x.detach().to(g, torch.float32).contiguous()
+        xg = _as_gpu_f32(x, g)
         B = xg.shape[0]
-        idx = torch.zeros(1, dtype=torch.int32, device=g)
+        idx = _idx0(g)
+        mask, lowest, net = self._op_args()
+        here = torch.cuda.current_device() == g.index
         if self.rng == "torch":
             L_, d_ = self._latent, self.w_avg.shape[0]
             if self._device.type == "cpu" and dev_in.type == "cpu":
@@ -615,30 +694,37 @@ class SWAGModel(VarModel):
                 eps = bg[d_ + self.K:].view(2, B, L_).permute(1, 0, 2).contiguous()[None]
             else:
                 z1, z2 = self._draw_noise()                                  # :830-831
-                e1 = torch.randn(B, L_, device=dev_in)                       # :426
-                e2 = torch.randn(B, L_, device=dev_in)                       # :427
-                eps = torch.stack([e1, e2], dim=1)[None].to(g).contiguous()
-                z1g, z2g = z1.to(g).contiguous(), z2.reshape(1, -1).to(g).contiguous()
-            mask, lowest, net = self._op_args()
-            with torch.cuda.device(g):
-                out = self._tops().multiswag(xg, wa, w2, pd, idx, z1g, z2g, eps, 1, float(scale), 0, 0, 0, mask, lowest, net,
-                                             bool(self.assume_finite))
-            # the reference leaves the sampled weights loaded in the module (:838)
-            plan = self._plan()
-            draw = lambda: ops.swag_draw(wa, w2, pd, idx, z1g, z2g, scale=scale, plan=plan)[0]
+                if dev_in == g and _strided_normal_is_randn(g):
+                    # randn_like([B, latent]) twice (:426-427), each drawn straight into its half of the kernels' [B, 2, latent] layout: the
+                    # generator hands a strided view the numbers it hands torch.randn of that shape (checked once per device) -- no stack kernel
+                    eps = torch.empty((1, B, 2, L_), dtype=torch.float32, device=g)
+                    eps[0, :, 0].normal_()
+                    eps[0, :, 1].normal_()
+                else:
+                    e1 = torch.randn(B, L_, device=dev_in)                   # :426
+                    e2 = torch.randn(B, L_, device=dev_in)                   # :427
+                    eps = _as_gpu_f32(torch.stack((e1, e2), dim=1), g)[None]
+                z1g, z2g = _as_gpu_f32(z1, g), _as_gpu_f32(z2.reshape(1, -1), g)
+            if here:
+                out = self._tops().multiswag(xg, wa, w2, pd, idx, z1g, z2g, eps, 1, float(scale), 0, 0, 0, mask, lowest, net, bool(self.assume_finite))
+            else:
+                with torch.cuda.device(g):
+                    out = self._tops().multiswag(xg, wa, w2, pd, idx, z1g, z2g, eps, 1, float(scale), 0, 0, 0, mask, lowest, net,
+                                                 bool(self.assume_finite))
+            # the reference leaves the sampled weights loaded in the module (:838): drawn on demand, from the same normals
+            draw = lambda: ops.swag_draw(wa, w2, pd, idx, z1g, z2g, scale=scale, plan=self._plan())[0]
         else:
-            did, seed, plan = self._next_philox_id(), self.philox_seed, self._plan()
-            mask, lowest, net = self._op_args()
+            did, seed = self._next_philox_id(), self.philox_seed
             with torch.cuda.device(g):
                 out = self._tops().multiswag(xg, wa, w2, pd, idx, None, None, None, 1, float(scale), int(seed), int(did), 0, mask, lowest, net,
                                              bool(self.assume_finite))
-            draw = lambda: ops.swag_draw(wa, w2, pd, idx, scale=scale, philox_seed=seed, draw_id0=did, plan=plan)[0]
+            draw = lambda: ops.swag_draw(wa, w2, pd, idx, scale=scale, philox_seed=seed, draw_id0=did, plan=self._plan())[0]
         self._pending_draw = draw
         self._last_forward = None          # (_cur_summary belongs to forward(); forward_swag_fast does not set it, :878-908)
         self._cur_summary_cache = None
-        self._last_latents_args = (xg, draw, None, False, 0, plan, 0)   # its compute_summary_stats call (:893) sets self.latents
+        self._last_latents_args = (xg, draw, None, False, 0, None, 0)   # its compute_summary_stats call (:893) sets self.latents
         self._latents_cache = None
-        return out[0].to(dev_in)
+        return out[0] if dev_in == g else out[0].to(dev_in)
 
 
 def save_swag(swag_model, path):

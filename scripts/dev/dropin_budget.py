@@ -32,6 +32,7 @@ for i in (0, 12):
 
 
 def timeit(fn, n=400, sync=True):
+    """microseconds per call over n back-to-back calls (with sync=True the GPU's work is inside the window: GPU-bound if it is the slower side)"""
     for _ in range(20):
         fn()
     torch.cuda.synchronize()
@@ -40,7 +41,20 @@ def timeit(fn, n=400, sync=True):
         fn()
     if sync:
         torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e6    # microseconds per call
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+def host_only(fn, burst=24, reps=15):
+    """HOST cost per call: bursts of `burst` calls issued into an idle queue (nothing waits on the GPU inside the window), median over reps"""
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(burst):
+            fn()
+        ts.append((time.perf_counter() - t0) / burst * 1e6)
+        torch.cuda.synchronize()
+    return sorted(ts)[len(ts) // 2]
 
 
 rows = []
@@ -52,7 +66,8 @@ for cuda in (True, False):
             X = X.cpu()
         r = {"tag": tag, "model_on_gpu": cuda, "shape": shape, "rows": B}
         r["call_plus_cpu_copy_us"] = timeit(lambda: model.sample_full_swag(X).detach().cpu(), sync=False)
-        r["call_enqueue_only_us"] = timeit(lambda: model.sample_full_swag(X))
+        r["call_back_to_back_us"] = timeit(lambda: model.sample_full_swag(X))
+        r["call_host_only_us"] = host_only(lambda: model.sample_full_swag(X))
         m = model.swag_ensemble[0]
         if cuda:
             m.cuda()
@@ -68,9 +83,12 @@ for cuda in (True, False):
         idx = torch.zeros(1, dtype=torch.int32, device="cuda")
         z1, z2, eps = torch.randn(1, 7583, device="cuda"), torch.randn(1, 30, device="cuda"), torch.randn(1, B, 2, 20, device="cuda")
         mask, lowest, net = m._op_args()
-        r["custom_op_us"] = timeit(lambda: torch.ops.bnn_chaos.multiswag(xg, wa, w2, pd, idx, z1, z2, eps, 1, 0.5, 0, 0, 0, mask, lowest, net, False))
-        r["ops_multiswag_us"] = timeit(lambda: ops.multiswag(xg, wa, w2, pd, idx, z1, z2, eps, plan=m._plan()))
-        r["ops_multiswag_assume_finite_us"] = timeit(lambda: ops.multiswag(xg, wa, w2, pd, idx, z1, z2, eps, plan=m._plan(), assume_finite=True))
+        r["custom_op_host_us"] = host_only(lambda: torch.ops.bnn_chaos.multiswag(xg, wa, w2, pd, idx, z1, z2, eps, 1, 0.5, 0, 0, 0, mask, lowest, net, False))
+        r["ops_multiswag_host_us"] = host_only(lambda: ops.multiswag(xg, wa, w2, pd, idx, z1, z2, eps, plan=m._plan()))
+        r["ops_multiswag_assume_finite_host_us"] = host_only(lambda: ops.multiswag(xg, wa, w2, pd, idx, z1, z2, eps, plan=m._plan(), assume_finite=True))
+        r["noise_draws_host_us"] = host_only(lambda: (torch.randn((1, 7583), device=m._device), torch.randn((30, 1), device=m._device),
+                                                      torch.randn(B, 20, device=dev_in), torch.randn(B, 20, device=dev_in)))
+        r["forward_swag_fast_host_us"] = host_only(lambda: m.forward_swag_fast(X, scale=0.5))
         out = ops.multiswag(xg, wa, w2, pd, idx, z1, z2, eps, plan=m._plan())
         r["result_to_cpu_us"] = timeit(lambda: out[0].detach().cpu(), sync=False)
         # GPU time of one call's kernels, from events around 50 back-to-back eager calls

@@ -25,6 +25,11 @@ for s in "$@"; do
     # (the product probe with the memset-header library + a damaged x FAULTS the GPU -- garbage header, out-of-bounds append: run once in
     #  round 6, never again; graph_nf_probe3.py refuses that combination)
     nodes)   step probe_nodes 300 python scripts/dev/graph_nf_probe3.py nodes ;;
+    trace)   rm -rf gpurun_out/r06_trace_small
+             (cd /tmp && export TMPDIR=/tmp && cd "$R" && step trace_small 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r06_trace_small -- python3 scripts/dev/small_call_trace.py)
+             f=$(find gpurun_out/r06_trace_small -name "*kernel_trace.csv" | head -1)
+             [ -n "$f" ] && python scripts/dev/trace_gaps.py "$f" | tee gpurun_out/r06_trace_gaps_${TAG:-x}.txt ;;
+    smalltiming) step small_timing 300 python scripts/dev/small_forward_timing.py ;;
     edges)   step edges 900 python -m pytest tests/test_hip_edges.py -x -q -m gpu ;;
     budget)  step budget_${TAG:-x} 600 python scripts/dev/dropin_budget.py "${TAG:-x}" ;;
     gputests) TAILN=30 step gputests 1100 python -m pytest tests -x -q -m gpu ;;

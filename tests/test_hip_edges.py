@@ -427,6 +427,41 @@ def test_default_route_keeps_its_scan_record_per_stream(ops, swag_states):
     assert torch.equal(a.nan_to_num(nan=-7.0), e.nan_to_num(nan=-7.0))
 
 
+@pytest.mark.parametrize("B,J,nch", ((1, 1, 1), (15, 1, 1), (16, 2, 1), (17, 3, 1), (150, 20, 10), (333, 6, 3), (3000, 1, 1), (4096, 1, 1), (4097, 1, 1)))
+def test_small_grids_take_the_tile_split_form_with_the_same_bits(B, J, nch, ops, swag_states):
+    """Small grids -- the evaluation scripts' per-chunk calls (figures/multiswag_5_planet.py:295-298: 15-row chunks; main_figures.py:154-156:
+    3 000-row batches) -- run the TILE-SPLIT launch form of the pretrained network's kernel (16 systems per workgroup, the four waves share
+    a batch's tiles, wave 0 pools them in order: bnn_forward.hip.h TSPLIT).  It is a launch form, not another arithmetic: outputs, pre-clamp
+    values and summaries are BIT-IDENTICAL to the plain form's (systems_per_block=64 keeps the plain form), for the in-prologue draw and the
+    workspace draw, explicit and in-kernel noise, every series length the kernels take (2, 3, 5, 25 tiles: waves without a tile of their
+    own), chunked draws, ragged last batches, and with damaged systems in the batch.  (4 097 rows is one workgroup too many: plain form.)"""
+    wa, w2, pd = (dev(a) for a in state(swag_states))
+    rng = np.random.default_rng(B * 31 + J)
+    idx = torch.zeros(J, dtype=torch.int32, device="cuda")
+    for T in ((100, 8, 12, 20) if B <= 333 else (100,)):
+        x = dev(synth(B, T, B + T))
+        for single in (True, False):
+            kw = dict(nchunks=nch, philox_seed=5, single_launch=single, debug=True)
+            a = ops.multiswag(x, wa, w2, pd, idx, **kw)                                  # default: tile-split when the grid is small
+            b = ops.multiswag(x, wa, w2, pd, idx, systems_per_block=64, **kw)            # the plain form
+            for u, v in zip(a, b):
+                assert torch.equal(u, v), (B, J, nch, T, single)
+        z1 = dev(rng.standard_normal((J, 7583), dtype=np.float32))
+        z2 = dev(rng.standard_normal((J, 30), dtype=np.float32))
+        eps = dev(rng.standard_normal((J // nch, B, 2, 20), dtype=np.float32))
+        a = ops.multiswag(x, wa, w2, pd, idx, z1, z2, eps, nchunks=nch)
+        assert torch.equal(a, ops.multiswag(x, wa, w2, pd, idx, z1, z2, eps, nchunks=nch, systems_per_block=64))
+        W = ops.swag_draw(wa, w2, pd, idx, z1, z2)
+        assert torch.equal(a, ops.forward(x, W, eps=eps, nchunks=nch)) and torch.equal(a, ops.forward(x, W, eps=eps, nchunks=nch, systems_per_block=128))
+    if B >= 15:
+        xb = x.clone()
+        xb[3, 1, 2] = float("nan")
+        xb[B - 1, 2, 20] = float("-inf")
+        a = ops.multiswag(xb, wa, w2, pd, idx, nchunks=nch, philox_seed=5)
+        b = ops.multiswag(xb, wa, w2, pd, idx, nchunks=nch, philox_seed=5, systems_per_block=64)
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.isnan(a[:, 3]).all() and torch.equal(a.nan_to_num(nan=-7.0), b.nan_to_num(nan=-7.0))
+
+
 def test_hundred_thousand_draws_in_one_call(ops, swag_states):
     """The 'paper-ready' 5-planet setting is 10 000 samples x 10 chunks = 100 000 draws (figures/multiswag_5_planet.py:52-55,
     295-298): more than a grid.y can hold.  One call == the same call in slabs of draws, bit for bit, in both launch modes."""
