@@ -157,6 +157,39 @@ DEVINL void philox_in6(int64_t row, int64_t sys, int block, uint64_t seed, float
     philox_normal6(philox_sys_ctr(TAG_IN, row, sys, block), seed, n);
 }
 
+// MEASUREMENT BUILDS ONLY (-DBNN_NIN16=1, round 6): EIGHT 16-bit uniforms per Philox block instead of six 21-bit
+// ones -- six blocks per 41-column row instead of seven, the last block finishing ONE Box-Muller pair (column 40) instead of four.  Only
+// the pretrained network's noisy kernel (in-kernel Philox form) switches; bnn_philox_normal_f32, the generic engine and the fix-up keep
+// the six-per-block stream, so a build with this flag fails the explicit == in-kernel tests by construction.
+#ifndef BNN_NIN16
+#define BNN_NIN16 0
+#endif
+constexpr int NIN16_PER_BLOCK = 8, NIN16_BLOCKS = 6;
+DEVINL uint32_t unit16_orc() {
+    uint32_t c = 0x3F800040u;   // +half a step of the 16-bit field: f is never 1 or 2
+    asm("" : "+v"(c));
+    return c;
+}
+DEVINL float unit16(uint32_t aligned, uint32_t orc) {   // bits [22:7] of `aligned` are the 16-bit field
+    return __builtin_bit_cast(float, (aligned & 0x007FFF80u) | orc);
+}
+template <int NPAIRS>
+DEVINL void philox_in8(int64_t row, int64_t sys, int block, uint64_t seed, float (&n)[8]) {
+    const uint4 r = philox4x32<NIN_ROUNDS>(philox_sys_ctr(TAG_IN, row, sys, block), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    const uint32_t orc = unit16_orc();
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < NPAIRS) {
+            const f32x2 a = box_muller21(unit16(w[q] << 7, orc), unit16(w[q] >> 9, orc));   // radius from the low half, angle from the high half
+            n[2 * q] = a.x;
+            n[2 * q + 1] = a.y;
+        } else {
+            n[2 * q] = n[2 * q + 1] = 0.0f;
+        }
+    }
+}
+
 DEVINL f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 DEVINL f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 

@@ -126,15 +126,21 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     // vector is copied / sampled -- one memory round trip instead of three in a row (a small grid's whole run time is a few of them).
     constexpr int NF2 = Y::NF2;
     constexpr int PER = (NF2 + 3) / 4;
+    // (Not in the FUSED forms: their prologue is the draw, which wants the registers for rows in flight.)
     int twr[WRL::NR], idx[PER];
+    auto fetch_tables = [&]() {
 #pragma unroll
-    for (int R = 0; R < WRL::NR; ++R) twr[R] = p.tab_wr[R * 64 + lane];
+        for (int R = 0; R < WRL::NR; ++R) twr[R] = p.tab_wr[R * 64 + lane];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int f = wave + 4 * i;
-        idx[i] = p.tab_f2[(f < NF2 ? f : NF2 - 1) * 64 + lane];
+        for (int i = 0; i < PER; ++i) {
+            const int f = wave + 4 * i;
+            idx[i] = p.tab_f2[(f < NF2 ? f : NF2 - 1) * 64 + lane];
+        }
+    };
+    if constexpr (!FUSED) {
+        fetch_tables();
+        asm volatile("" ::: "memory");
     }
-    asm volatile("" ::: "memory");
     bool bad_seed = false;
     if constexpr (FUSED) {
         int s = p.seed_idx[e];
@@ -146,7 +152,9 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         const float* w2 = p.w2_avg + (int64_t)s * D;
         const float* pd = p.pre_D + (int64_t)s * D * K;
         __syncthreads();
-#pragma unroll 3   // (three elements' loads in flight: the loop is a chain of L2 round trips)
+        // (Measured, round 6: this loop is bound by its ~140 vector instructions per element at one wave per SIMD -- 12 us of a 15-row call's
+        // 50 us kernel with explicit normals, 19 us with in-kernel Philox -- not by its memory round trips: five elements' rows requested
+        // ahead of the arithmetic changed nothing, and neither did 16-byte row loads.)
         for (int i = tid; i < D; i += 256) {
             float z1v = p.z1 ? p.z1[(int64_t)e * D + i] : philox_z(TAG_Z1, p.draw_id0 + e, i, p.seed);
             flat[i] = draw_row_direct(wa, w2, pd, i, K, zsh, z1v, p.c1, p.c2, p.scale);
@@ -156,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         for (int i = tid; i < D; i += 256) flat[i] = We[i];
     }
     if (tid == 0) flat[Y::ZERO] = 0.0f;
+    if constexpr (FUSED) fetch_tables();
     __syncthreads();
     // feature_nn weights -> registers (every wave holds the same 58): register R, lane 4a+i = W[neuron 4n+i][input k] of the
     // layer's MFMA number m = 16R + a = k * groups + n (bnn_layout.h, WR<KIN>); biases -> a small LDS image
@@ -166,8 +175,9 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     if constexpr (NOISY) {  // exp(input_noise_logvar/2) (:445), exp(summary_noise_logvar/2) (:449)
         if (tid < F + Y::SM) nsc[tid] = expf(flat[Y::INLV + tid] / 2.0f);
         if (tid < 56) {     // the same input scales per noise block, and 1.0 / 0.0 keep-factors for kept / zeroed columns
-            const int col = NIN_PER_BLOCK * (tid >> 3) + (tid & 7);
-            const bool live = (tid & 7) < NIN_PER_BLOCK && col < F;
+            constexpr int NPB = (BNN_NIN16 && !XNOISE) ? NIN16_PER_BLOCK : NIN_PER_BLOCK;
+            const int col = NPB * (tid >> 3) + (tid & 7);
+            const bool live = (tid & 7) < NPB && col < F;
             nsc[96 + tid] = live ? expf(flat[Y::INLV + col] / 2.0f) : 0.0f;
             nsc[96 + 56 + tid] = (live && !((p.zero_mask >> col) & 1ull)) ? 1.0f : 0.0f;
         }
@@ -296,9 +306,47 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                         }
                     }
                 };
+#if BNN_NIN16
+                // measurement build (bnn_common.hip.h, BNN_NIN16): blocks of EIGHT normals, six per row, in-kernel Philox form only
+                auto noise8 = [&](auto BLK) {
+                    constexpr int blk = BLK;
+                    constexpr int npairs = (F - 8 * blk + 1) / 2 < 4 ? (F - 8 * blk + 1) / 2 : 4;
+                    float n8[8];
+                    philox_in8<npairs>(p.row_id0 + r, p.sys_id0 + sysc0, (4 * it + ph0) * NIN16_BLOCKS + blk, p.seed, n8);
+                    const f32x4* nb = reinterpret_cast<const f32x4*>(nsc + 96 + 8 * blk);
+                    const f32x4 s0 = nb[0], s1 = nb[1], k0 = nb[14], k1 = nb[15];
+                    float scs[8], kpf[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { scs[j] = j < 4 ? s0[j] : s1[j - 4]; kpf[j] = j < 4 ? k0[j] : k1[j - 4]; }
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const int col = 8 * blk + j;
+                        if (col + 1 < KIN) {
+                            const f32x2 xp = {xv[col], xv[col + 1]};
+                            const f32x2 kp = {kpf[j], kpf[j + 1]};
+                            f32x2 nz = {n8[j], n8[j + 1]};
+                            const f32x2 sc = {scs[j], scs[j + 1]};
+                            nz = nz * sc;
+                            const f32x2 xs = __builtin_elementwise_fma(xp, kp, nz);
+                            xv[col] = xs.x;
+                            xv[col + 1] = xs.y;
+                        } else if (col < KIN) {
+                            xv[col] = fmaf(xv[col], kpf[j], n8[j] * scs[j]);
+                        }
+                    }
+                };
+#endif
                 static_for<KIN * 10>([&](auto M) {
                     constexpr int m = M, k = m / 10, n = m % 10;
-                    if constexpr (NOISY && n == 0 && k % 6 == 0) {  // a scheduling region of its own: the MFMAs around it do not move across
+                    if constexpr (NOISY && BNN_NIN16 && !XNOISE) {
+#if BNN_NIN16
+                        if constexpr (n == 0 && k % 8 == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            noise8(std::integral_constant<int, k / 8>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#endif
+                    } else if constexpr (NOISY && n == 0 && k % 6 == 0) {  // a scheduling region of its own: the MFMAs around it do not move across
                         __builtin_amdgcn_sched_barrier(0);
                         noise6(k / 6);
                         __builtin_amdgcn_sched_barrier(0);

@@ -23,12 +23,8 @@ namespace bnn {
 // record (int32): [0] = listed systems, [1] = of which certainly NaN, [2], [3] reserved (zero); [4 + i] = (system << 1) | certain.
 DEVINL bool nf_bits(uint32_t b) { return (b & 0x7f800000u) == 0x7f800000u; }
 
-__global__ __launch_bounds__(256) void bnn_nonfinite_scan_kernel(const float* __restrict__ x, int64_t B, int64_t per, int F, uint64_t zero_mask,
-                                                                 int32_t* __restrict__ rec) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const float* xs = x + b * per;
+// One wave looks through one system's [T, F] block: any = it holds NaN / +-inf, certain = a NaN anywhere or +-inf in a masked column.
+DEVINL void nf_scan_system(const float* __restrict__ xs, int64_t per, int F, uint64_t zero_mask, int lane, bool& wany, bool& wcert) {
     bool any = false, certain = false;
     auto look = [&](float v, int64_t i) {   // the rare path: which kind, which column
         const uint32_t bits = __float_as_uint(v);
@@ -57,12 +53,46 @@ __global__ __launch_bounds__(256) void bnn_nonfinite_scan_kernel(const float* __
         }
     }
     for (int64_t i = 4 * nvec + lane; i < per; i += 64) look(xs[i], i);
-    const bool wany = __ballot(any) != 0ull, wcert = __ballot(certain) != 0ull;
+    wany = __ballot(any) != 0ull;
+    wcert = __ballot(certain) != 0ull;
+}
+
+__global__ __launch_bounds__(256) void bnn_nonfinite_scan_kernel(const float* __restrict__ x, int64_t B, int64_t per, int F, uint64_t zero_mask,
+                                                                 int32_t* __restrict__ rec) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    bool wany, wcert;
+    nf_scan_system(x + b * per, per, F, zero_mask, lane, wany, wcert);
     if (lane == 0 && wany) {
         const int slot = atomicAdd(&rec[0], 1);
         if (wcert) atomicAdd(&rec[1], 1);
         rec[4 + slot] = (int32_t)((b << 1) | (wcert ? 1 : 0));
     }
+}
+
+// A batch of at most NF_SMALL_MAX systems (the evaluation scripts' 15-row chunks, figures/multiswag_5_planet.py:295-298): ONE workgroup of
+// sixteen waves scans it, keeps the list in LDS and writes header AND entries itself -- no header to clear beforehand, one launch instead of two.
+constexpr int NF_SMALL_MAX = 64;
+__global__ __launch_bounds__(1024) void bnn_nonfinite_scan_small_kernel(const float* __restrict__ x, int B, int64_t per, int F, uint64_t zero_mask,
+                                                                        int32_t* __restrict__ rec) {
+    __shared__ int cnt[2];
+    __shared__ int list[NF_SMALL_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int b = wave; b < B; b += 16) {
+        bool wany, wcert;
+        nf_scan_system(x + (int64_t)b * per, per, F, zero_mask, lane, wany, wcert);
+        if (lane == 0 && wany) {
+            const int slot = atomicAdd(&cnt[0], 1);
+            if (wcert) atomicAdd(&cnt[1], 1);
+            list[slot] = (b << 1) | (wcert ? 1 : 0);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) rec[threadIdx.x] = threadIdx.x < 2 ? cnt[threadIdx.x] : 0;
+    if ((int)threadIdx.x < cnt[0]) rec[4 + threadIdx.x] = list[threadIdx.x];
 }
 
 // The record's header is cleared by a KERNEL, never by hipMemsetAsync.  Round 5's first form used hipMemsetAsync(rec, 0, 16) and failed
@@ -84,6 +114,10 @@ __global__ void bnn_nonfinite_reset_kernel(int32_t* __restrict__ rec) {
 }
 
 hipError_t launch_nonfinite_scan(const float* x, int64_t B, int64_t per, int F, uint64_t zero_mask, int32_t* rec, hipStream_t st) {
+    if (B > 0 && B <= NF_SMALL_MAX) {
+        hipLaunchKernelGGL(bnn_nonfinite_scan_small_kernel, dim3(1), dim3(1024), 0, st, x, (int)B, per, F, zero_mask, rec);
+        return hipGetLastError();
+    }
 #if defined(BNN_NF_HEADER_MEMSET)   // PROBE BUILDS ONLY (scripts/dev/graph_nf_probe3.py): round 5's first form, a memset node in front of the kernels
     hipError_t e = hipMemsetAsync(rec, 0, 4 * sizeof(int32_t), st);
 #else

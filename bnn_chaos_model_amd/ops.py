@@ -110,6 +110,20 @@ def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto", chunk_B=0, chunk_of
     return g
 
 
+def _scan_st(x, plan, assume_finite, nonfinite):
+    """(record or None, stream handle) for a call on x: the stream handle is looked up once per op (torch.cuda.current_stream() costs
+    microseconds) and shared by the scan and the launch behind it."""
+    st = torch.cuda.current_stream(x.device).cuda_stream
+    if nonfinite is not None:
+        return _nonfinite_record(x, plan, assume_finite, nonfinite), st
+    if assume_finite:
+        return None, st
+    B, T, _ = x.shape
+    rec = _record_buffer(B, x.device, st)
+    N.check(N.lib().bnn_nonfinite_scan_f32(plan.handle, x.data_ptr(), B, T, rec.data_ptr(), st))
+    return rec, st
+
+
 _records = {}          # (device index, stream handle) -> int32 buffer, grow-only: the scan records of eager calls
 _record_views = {}     # the same key -> {B: buffer[:4 + B]}
 _RECORDS_PER_DEVICE = 8
@@ -365,12 +379,12 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
         raise ValueError(f"eps must be [{R},{B},2,{plan.latent}]")
     if out is None:
         out = torch.empty((R, B, 2), dtype=torch.float32, device=x.device)
-    elif tuple(out.shape) != (R, B, 2) or out.dtype != torch.float32 or not out.is_contiguous():
-        raise ValueError("out has the wrong shape/dtype")
+    elif tuple(out.shape) != (R, B, 2) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise ValueError(f"out must be a contiguous float32 [{R},{B},2] tensor on x's device")
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, plan.summary_width), dtype=torch.float32, device=x.device) if debug else None
-    g = _grid(B, T, J, nchunks, systems_per_block, engine=engine, chunk_B=chunk_B, chunk_off=chunk_off,
-              nonfinite=_nonfinite_record(x, plan, assume_finite, nonfinite))
+    rec, st = _scan_st(x, plan, assume_finite, nonfinite)
+    g = _grid(B, T, J, nchunks, systems_per_block, engine=engine, chunk_B=chunk_B, chunk_off=chunk_off, nonfinite=rec)
     if not fused_draw_available(plan, T, K) or engine != "auto":
         if single_launch:
             raise NotImplementedError("single_launch (in-prologue draw) exists for the pretrained network at T % 4 == 0, K <= 32 only")
@@ -384,10 +398,11 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
         single_launch = csz <= 256 or (systems_per_block == 0 and plan.v50net and not plan.fix_megno and plan.arch.zero_mask == V50_ZERO_MASK
                                        and -(-min(csz, B) // 16) * J <= 256)
     ws = None if single_launch else _workspace(J, d, x.device)
-    N.check(N.lib().bnn_multiswag_f32(plan.handle, C.byref(g), N.ptr(x), N.ptr(w_avg), N.ptr(w2_avg), N.ptr(pre_D), S, K,
-                                      N.ptr(seed_idx), N.ptr(z1), N.ptr(z2), N.ptr(eps), float(scale), int(philox_seed),
-                                      int(draw_id0), int(system_id0), N.ptr(ws), N.ptr(out), N.ptr(pre), N.ptr(summ),
-                                      N.stream_ptr()))
+    # (x, the ensemble, the noise tensors and out were checked above -- float32, contiguous, on x's device: their addresses as they are)
+    dp = lambda t: None if t is None else t.data_ptr()
+    N.check(N.lib().bnn_multiswag_f32(plan.handle, C.byref(g), x.data_ptr(), w_avg.data_ptr(), w2_avg.data_ptr(), pre_D.data_ptr(), S, K,
+                                      seed_idx.data_ptr(), dp(z1), dp(z2), dp(eps), float(scale), int(philox_seed),
+                                      int(draw_id0), int(system_id0), dp(ws), out.data_ptr(), dp(pre), dp(summ), st))
     return (out, pre, summ) if debug else out
 
 

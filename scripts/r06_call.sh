@@ -30,6 +30,7 @@ for s in "$@"; do
              f=$(find gpurun_out/r06_trace_small -name "*kernel_trace.csv" | head -1)
              [ -n "$f" ] && python scripts/dev/trace_gaps.py "$f" | tee gpurun_out/r06_trace_gaps_${TAG:-x}.txt ;;
     smalltiming) step small_timing 300 python scripts/dev/small_forward_timing.py ;;
+    abnoisy) step ab_noisy 900 python scripts/ab_variants.py --workload noisy --reps 3 --steps 6 libbnn_chaos_hip.so libbnn_nin16.so ;;
     edges)   step edges 900 python -m pytest tests/test_hip_edges.py -x -q -m gpu ;;
     budget)  step budget_${TAG:-x} 600 python scripts/dev/dropin_budget.py "${TAG:-x}" ;;
     gputests) TAILN=30 step gputests 1100 python -m pytest tests -x -q -m gpu ;;

@@ -470,7 +470,7 @@ def test_headline_kernels_use_no_scratch(N):
     import resusage
     ks = resusage.kernels(N.SO_PATH)
     fwd = [k for k in ks if k["name"].startswith("bnn::bnn_forward_kernel<")]
-    assert len(fwd) >= 13
+    assert len(fwd) >= 15    # (incl. the two tile-split forms of the small grids, bnn_fwd_small.hip)
     for k in fwd:
         args = [a.strip() for a in k["name"].split("<", 1)[1].rstrip(">").split(",")]   # KIN, FUSED, NOISY, STATS, MEGNO, XNOISE
         megno_noisy = args[2] == "true" and args[4] == "true"
@@ -497,6 +497,6 @@ def test_headline_kernels_use_no_scratch(N):
     # the non-finite scan streams x at the copy rate: few registers (many waves in flight), no scratch; the exact re-evaluation likewise
     nf = {k["name"]: k for k in ks if "bnn_nonfinite_" in k["name"]}
     assert sorted(n.split("::")[-1] for n in nf) == ["bnn_nonfinite_fixup_kernel<false>", "bnn_nonfinite_fixup_kernel<true>", "bnn_nonfinite_reset_kernel",
-                                                     "bnn_nonfinite_scan_kernel"]
+                                                     "bnn_nonfinite_scan_kernel", "bnn_nonfinite_scan_small_kernel"]
     assert all(k["scratch"] == 0 and k["vgpr_spills"] == 0 for k in nf.values())
     assert [k for n, k in nf.items() if n.endswith("scan_kernel")][0]["vgpr"] <= 64

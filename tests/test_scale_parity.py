@@ -130,6 +130,11 @@ def test_hip_against_the_reference_at_scale(case):
                           "hip_vs_truth": rel_stats(hip_noisy, case["noisy_truth"])},
         "bit_identical_outputs": {"forward_swag_fast": int((hip == case["out32"]).sum()), "noisy_forward": int((hip_noisy == case["noisy32"]).sum())},
     }
+    # which outputs miss the truth by more than 1e-5: the same ones for the reference and for the HIP path?
+    beyond = lambda a: np.abs(a.astype(np.float64) - case["truth"]) > 1e-5 * np.abs(case["truth"])
+    br, bh = beyond(case["out32"]), beyond(hip)
+    table["forward_swag_fast"]["beyond_1e-5_of_truth"] = {"reference": int(br.sum()), "hip": int(bh.sum()), "both": int((br & bh).sum()),
+                                                          "systems_involved": int((br | bh).any(-1).sum())}
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "r06_scale_parity.json"), "w") as f:
