@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
     // vector is copied / sampled -- one memory round trip instead of three in a row (a small grid's whole run time is a few of them).
     constexpr int NF2 = Y::NF2;
     constexpr int PER = (NF2 + 3) / 4;
-    // (Not in the FUSED forms: their prologue is the draw, which wants the registers for rows in flight.)
+    // (Small grids only, and not in the FUSED forms, whose prologue is the draw.)
     int twr[WRL::NR], idx[PER];
     auto fetch_tables = [&]() {
 #pragma unroll
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
             idx[i] = p.tab_f2[(f < NF2 ? f : NF2 - 1) * 64 + lane];
         }
     };
-    if constexpr (!FUSED) {
+    constexpr bool TABLES_FIRST = !FUSED && TSPLIT;   // (in the plain form the early request measured 1.3 % SLOWER at configs[2], same box)
+    if constexpr (TABLES_FIRST) {
         fetch_tables();
         asm volatile("" ::: "memory");
     }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         for (int i = tid; i < D; i += 256) flat[i] = We[i];
     }
     if (tid == 0) flat[Y::ZERO] = 0.0f;
-    if constexpr (FUSED) fetch_tables();
+    if constexpr (!TABLES_FIRST) fetch_tables();
     __syncthreads();
     // feature_nn weights -> registers (every wave holds the same 58): register R, lane 4a+i = W[neuron 4n+i][input k] of the
     // layer's MFMA number m = 16R + a = k * groups + n (bnn_layout.h, WR<KIN>); biases -> a small LDS image
@@ -386,20 +387,23 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                 y[n] = mfma4b<(m & 15)>(wr[WRL::R1 + WRL::R2 + (m >> 4)], h2[k >> 2][k & 3], y[n]);
             });
         };
-        // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps, tile `it` = its (it + 1)-th
-        auto pool = [&](const int it, const f32x4 (&yy)[5]) {
+        // torch.mean / torch.std over time (:418-419): Welford over this lane's timesteps; y = the latents of tile `it`, its (it + 1)-th.
+        // The plain loop below carries the SAME statements inline: called through this lambda the SLP vectoriser splits the headline
+        // loop's 20 packed subtractions into 20 scalar + 10 packed ones -- 10 more vector instructions per 910-MFMA tile, 2.4 % of the
+        // kernel's cycles (round 6: seen in SQ_INSTS_VALU, 2.80e10 -> 2.96e10 per configs[2] launch, before it was seen in time).
+        auto pool = [&](const int it) {
 #if BNN_ABLATE & 2
 #pragma unroll
-            for (int n = 0; n < 5; ++n) asm volatile("" : : "v"(yy[n]));   // the latents stay computed, nothing consumes them
+            for (int n = 0; n < 5; ++n) asm volatile("" : : "v"(y[n]));   // the latents stay computed, nothing consumes them
 #else
             const float rcn = p.rcp_tab[it];
 #pragma unroll
             for (int n = 0; n < 5; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float dl = yy[n][i] - mean[n][i];
+                    float dl = y[n][i] - mean[n][i];
                     float mn = fmaf(dl, rcn, mean[n][i]);
-                    m2[n][i] = fmaf(dl, yy[n][i] - mn, m2[n][i]);
+                    m2[n][i] = fmaf(dl, y[n][i] - mn, m2[n][i]);
                     mean[n][i] = mn;
                 }
 #endif
@@ -407,7 +411,20 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
         if constexpr (!TSPLIT) {
             for (int it = 0; it < ntiles; ++it) {
                 tile(it, (it + 1 < ntiles) ? it + 1 : it);
-                pool(it, y);
+#if BNN_ABLATE & 2
+                pool(it);
+#else
+                const float rcn = p.rcp_tab[it];
+#pragma unroll
+                for (int n = 0; n < 5; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float dl = y[n][i] - mean[n][i];
+                        float mn = fmaf(dl, rcn, mean[n][i]);
+                        m2[n][i] = fmaf(dl, y[n][i] - mn, m2[n][i]);
+                        mean[n][i] = mn;
+                    }
+#endif
             }
         } else {
             for (int it0 = 0; it0 < ntiles; it0 += 4) {   // a round: tile it0 + w on wave w, then wave 0 pools the round's tiles in order
@@ -421,10 +438,9 @@ __global__ __launch_bounds__(256, 2) void bnn_forward_kernel(const FwdParams p) 
                 __syncthreads();   // (the next round writes the OTHER buffer; wave 0 is through with this one before it reaches the next barrier)
                 if (wave == 0) {
                     for (int w = 0; w < 4 && it0 + w < ntiles; ++w) {
-                        f32x4 yy[5];
 #pragma unroll
-                        for (int n = 0; n < 5; ++n) yy[n] = yb[(w * 5 + n) * 64 + lane];
-                        pool(it0 + w, yy);
+                        for (int n = 0; n < 5; ++n) y[n] = yb[(w * 5 + n) * 64 + lane];   // (its own tile's latents are in the buffer too: y is free)
+                        pool(it0 + w);
                     }
                 }
             }

@@ -461,6 +461,24 @@ def test_sharded_bands_gather_gloo(n_sims, world):
     assert np.array_equal(got, want)
 
 
+def test_headline_tile_loop_instruction_mix(N):
+    """The headline kernel's time is the SUM of its matrix and vector instructions (nothing co-issues with the 4x4x1 MFMA), so the tile
+    loop's vector-instruction count is its performance: 910 MFMAs + 121 other vector instructions per 64-row tile (80 ReLU, 20 + 20 packed
+    Welford, 1).  Round 6 caught a refactoring that left every result bit-identical and cost 2.4 % -- the pool called through a lambda, its
+    20 packed subtractions split into 20 scalar + 10 packed ones -- only in SQ_INSTS_VALU.  scripts/loop_histogram.py reads the loop out of
+    the BUILT library: this test fails the CPU suite when the count moves."""
+    import re
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "loop_histogram.py"),
+                          "_ZN3bnn18bnn_forward_kernelILi31ELb0ELb0ELb0ELb0ELb0ELb0EEE", N.SO_PATH], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    counts = {m.group(2).strip(): int(m.group(1)) for m in re.finditer(r"^\s+(\d+)\s+(.+)$", out.stdout, re.M)}
+    mfma = sum(v for k, v in counts.items() if k.startswith("MFMA"))
+    vector = sum(v for k, v in counts.items() if k.startswith(("packed", "v_max_i32", "other vector", "transcendental", "v_mad_u64", "v_bitop3")))
+    assert mfma == 910, out.stdout
+    assert vector <= 121, out.stdout
+
+
 def test_headline_kernels_use_no_scratch(N):
     """The register-resident forward forms sit at 236-256 VGPRs under __launch_bounds__(256, 2): a compiler update or a small edit would
     tip them into scratch silently.  Read the built library's code-object notes (scripts/resusage.py): the quiet and noisy forms of the
