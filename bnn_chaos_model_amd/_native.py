@@ -150,8 +150,24 @@ def ptr(t):
     return t.data_ptr()
 
 
-def stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+# torch's public accessors build a Stream object (or run a lazy-init check) per call: 2-5 us each, five to six of them per op on the scripts'
+# per-chunk route.  The private C entry points return the same numbers directly; fall back to the public API where a torch build lacks them.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def current_device():
+    """Index of the current GPU (torch.cuda.current_device())."""
+    if _raw_device is not None and torch.cuda.is_initialized():
+        return _raw_device()
+    return torch.cuda.current_device()
+
+
+def stream_ptr(device_index=None):
+    """Raw handle of torch's current stream on the given (default: the current) device."""
+    if _raw_stream is not None and torch.cuda.is_initialized():
+        return _raw_stream(current_device() if device_index is None else device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
 
 
 SPEC_POOL_REGS = 1

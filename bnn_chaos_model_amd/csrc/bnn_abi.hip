@@ -175,7 +175,11 @@ int bnn_plan_attach_spec(bnn_plan* pl, int32_t noisy, int32_t w8, int32_t flags,
         return fail(BNN_ERR_HIP, std::string("the code object has no kernel bnn_spec_forward: ") + hipGetErrorString(e));
     }
     if (pl->spec_mod[noisy]) {   // launches of the form being replaced may still be queued on any stream: drain the device before its
-        HIP_TRY(hipDeviceSynchronize());   // code leaves (a setup call, like plan creation: the only kind that synchronises)
+        const hipError_t es = hipDeviceSynchronize();   // code leaves (a setup call, like plan creation: the only kind that synchronises)
+        if (es != hipSuccess) {
+            (void)hipModuleUnload(mod);   // (the freshly loaded module must not outlive a failed attach)
+            return fail(BNN_ERR_HIP, std::string("hipDeviceSynchronize before replacing a specialised form: ") + hipGetErrorString(es));
+        }
         (void)hipModuleUnload(pl->spec_mod[noisy]);
     }
     pl->spec_mod[noisy] = mod;

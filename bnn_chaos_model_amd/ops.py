@@ -25,7 +25,7 @@ def _on_device_of(argname_index=0):
         @functools.wraps(fn)
         def wrapper(*args, **kwargs):
             t = args[argname_index] if len(args) > argname_index else None
-            if isinstance(t, torch.Tensor) and t.is_cuda and t.device.index != torch.cuda.current_device():
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.device.index != N.current_device():
                 with torch.cuda.device(t.device):
                     return fn(*args, **kwargs)
             return fn(*args, **kwargs)
@@ -53,7 +53,7 @@ def get_plan(zero_mask=V50_ZERO_MASK, lowest_std=0.5, device=None, fix_megno=Fal
     """One plan per (device, network, column mask).  n_features / hidden / latent / depth_in / depth_out describe the network the
     reference builds from hparams (spock_reg_model.py:301-321, 346-362; depth = hparams['in'] / ['out']); the defaults are the
     pretrained ensemble's.  fix_megno: hparams['fix_megno'] (:360-362): summary two wider; the mask must zero column 7."""
-    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    dev = N.current_device() if device is None else torch.device(device).index
     key = (dev, int(zero_mask), float(lowest_std), bool(fix_megno), int(n_features), int(hidden), int(latent), int(depth_in), int(depth_out))
     if key not in _plans:
         with torch.cuda.device(dev):
@@ -110,10 +110,21 @@ def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto", chunk_B=0, chunk_of
     return g
 
 
+def small_grid(plan, B, T, J, nchunks=1, chunk_B=0, systems_per_block=0, engine="auto"):
+    """True where the library runs the pretrained network's kernel in its TILE-SPLIT form (bnn_abi.hip: launch_forward, TSPLIT_MAX_BLOCKS):
+    the v50 mask, whole 4-step tiles, no explicit block size, and at most 256 blocks of 16 systems in the whole grid -- the evaluation
+    scripts' per-chunk calls (15 .. 3 000 rows under one draw)."""
+    if not (plan.v50net and not plan.fix_megno and plan.arch.zero_mask == V50_ZERO_MASK and T % 4 == 0 and T >= 8 and systems_per_block == 0
+            and engine == "auto" and B > 0 and J > 0):
+        return False
+    csz = -(-(chunk_B or B) // max(nchunks, 1))
+    return -(-min(csz, B) // 16) * J <= 256
+
+
 def _scan_st(x, plan, assume_finite, nonfinite):
     """(record or None, stream handle) for a call on x: the stream handle is looked up once per op (torch.cuda.current_stream() costs
     microseconds) and shared by the scan and the launch behind it."""
-    st = torch.cuda.current_stream(x.device).cuda_stream
+    st = N.stream_ptr(x.device.index)
     if nonfinite is not None:
         return _nonfinite_record(x, plan, assume_finite, nonfinite), st
     if assume_finite:
@@ -183,7 +194,7 @@ def nonfinite_scan(x, plan=None, out=None):
 def _scan_into_own_record(x, plan):
     """The default route's scan: the record lives in this module's per-(device, stream) buffer (_record_buffer)."""
     B, T, _ = x.shape
-    st = torch.cuda.current_stream(x.device).cuda_stream
+    st = N.stream_ptr(x.device.index)
     rec = _record_buffer(B, x.device, st)
     N.check(N.lib().bnn_nonfinite_scan_f32(plan.handle, x.data_ptr(), B, T, rec.data_ptr(), st))
     return rec
@@ -383,6 +394,7 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
         raise ValueError(f"out must be a contiguous float32 [{R},{B},2] tensor on x's device")
     pre = torch.empty_like(out) if debug else None
     summ = torch.empty((R, B, plan.summary_width), dtype=torch.float32, device=x.device) if debug else None
+    small = small_grid(plan, B, T, J, nchunks, chunk_B, systems_per_block, engine)
     rec, st = _scan_st(x, plan, assume_finite, nonfinite)
     g = _grid(B, T, J, nchunks, systems_per_block, engine=engine, chunk_B=chunk_B, chunk_off=chunk_off, nonfinite=rec)
     if not fused_draw_available(plan, T, K) or engine != "auto":
@@ -390,13 +402,10 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
             raise NotImplementedError("single_launch (in-prologue draw) exists for the pretrained network at T % 4 == 0, K <= 32 only")
         single_launch = False
     if single_launch is None:
-        csz = -(-(chunk_B or B) // max(nchunks, 1))
         # few systems per draw: every workgroup samples its draw in its prologue (no workspace, no draw launch).  That includes the small
-        # grids the library runs in its tile-split form (16 systems per workgroup, at most one workgroup per CU: bnn_abi.hip
-        # TSPLIT_MAX_BLOCKS) -- e.g. the 3 000-row batches of figures/main_figures.py:154-156 under ONE draw: 188 prologue draws side by
-        # side cost 7 us, a draw launch in front of the forward 24.
-        single_launch = csz <= 256 or (systems_per_block == 0 and plan.v50net and not plan.fix_megno and plan.arch.zero_mask == V50_ZERO_MASK
-                                       and -(-min(csz, B) // 16) * J <= 256)
+        # grids of the tile-split form -- e.g. the 3 000-row batches of figures/main_figures.py:154-156 under ONE draw: 188 prologue draws
+        # side by side cost less than a draw launch in front of the forward.
+        single_launch = -(-(chunk_B or B) // max(nchunks, 1)) <= 256 or small
     ws = None if single_launch else _workspace(J, d, x.device)
     # (x, the ensemble, the noise tensors and out were checked above -- float32, contiguous, on x's device: their addresses as they are)
     dp = lambda t: None if t is None else t.data_ptr()

@@ -28,6 +28,7 @@ import os
 import torch
 from torch import nn
 
+from . import _native as _N
 from . import ops
 from .checkpoint import AttributeDict, read_swag_file, write_swag_file
 
@@ -124,7 +125,7 @@ def _gpu():
         if not torch.cuda.is_available():
             raise RuntimeError("bnn_chaos_model_amd needs an MI355X (gfx950) GPU: there is no CPU implementation")
         _GPU_SEEN = True
-    i = torch.cuda.current_device()
+    i = _N.current_device()
     d = _GPU_DEVS.get(i)
     if d is None:
         d = _GPU_DEVS[i] = torch.device("cuda", i)
@@ -679,7 +680,7 @@ class SWAGModel(VarModel):
         B = xg.shape[0]
         idx = _idx0(g)
         mask, lowest, net = self._op_args()
-        here = torch.cuda.current_device() == g.index
+        here = _N.current_device() == g.index
         if self.rng == "torch":
             L_, d_ = self._latent, self.w_avg.shape[0]
             if self._device.type == "cpu" and dev_in.type == "cpu":

@@ -31,6 +31,8 @@ for s in "$@"; do
              [ -n "$f" ] && python scripts/dev/trace_gaps.py "$f" | tee gpurun_out/r06_trace_gaps_${TAG:-x}.txt ;;
     smalltiming) step small_timing 300 python scripts/dev/small_forward_timing.py ;;
     abheadline) step ab_headline 900 python scripts/ab_variants.py --workload c3 --reps 3 --steps 4 libbnn_r05.so libbnn_chaos_hip.so ;;
+    cprofile) TAILN=60 step cprofile 300 python scripts/dev/dropin_cprofile.py ;;
+    smoke)   step smoke 600 python __graft_entry__.py --smoke ;;
     abnoisy) step ab_noisy 900 python scripts/ab_variants.py --workload noisy --reps 3 --steps 6 libbnn_chaos_hip.so libbnn_nin16.so ;;
     edges)   step edges 900 python -m pytest tests/test_hip_edges.py -x -q -m gpu ;;
     budget)  step budget_${TAG:-x} 600 python scripts/dev/dropin_budget.py "${TAG:-x}" ;;
