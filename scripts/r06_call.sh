@@ -34,6 +34,7 @@ for s in "$@"; do
     cprofile) TAILN=60 step cprofile 300 python scripts/dev/dropin_cprofile.py ;;
     smoke)   step smoke 600 python __graft_entry__.py --smoke ;;
     abnoisy) step ab_noisy 900 python scripts/ab_variants.py --workload noisy --reps 3 --steps 6 libbnn_chaos_hip.so libbnn_nin16.so ;;
+    surface) step surface 900 python -m pytest tests/test_surface_gpu.py tests/test_scale_parity.py -x -q -m gpu ;;
     edges)   step edges 900 python -m pytest tests/test_hip_edges.py -x -q -m gpu ;;
     budget)  step budget_${TAG:-x} 600 python scripts/dev/dropin_budget.py "${TAG:-x}" ;;
     gputests) TAILN=30 step gputests 1100 python -m pytest tests -x -q -m gpu ;;

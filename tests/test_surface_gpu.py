@@ -213,6 +213,59 @@ def test_cuda_inputs_stay_on_gpu(models, inputs):
         m.cpu()
 
 
+def test_gpu_resident_route_draws_the_reference_calls_in_order(models, inputs, swag_states):
+    """FeatureRegressor(cuda=True)'s per-call route: model, x and generator on the GPU.  forward_swag_fast draws into buffers the model keeps
+    per (stream, batch size) -- randn(out=), normal_() on strided views -- and must consume the GPU generator exactly like the reference's four
+    calls in its order (spock_reg_model.py:830-831 randn((1,d)), randn((K,1)); :426-427 two randn_like([B, latent])): same outputs as
+    ops.multiswag fed with those four torch.randn results, call after call (buffer reuse), for another batch size, and on another stream;
+    the weights the module then "has loaded" (:838) are those of ITS last call."""
+    from bnn_chaos_model_amd import ops
+    m = models[0]
+    st = swag_states[0]
+    g = torch.device("cuda", torch.cuda.current_device())
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    wa, w2, pd = d(st["w_avg"][None]), d(st["w2_avg"][None]), d(st["pre_D"][None])
+    idx = torch.zeros(1, dtype=torch.int32, device="cuda")
+    x32 = torch.tensor(inputs["slow"]).cuda()
+    m.cuda()
+    try:
+        def reference_order(x, seed):
+            torch.manual_seed(seed)
+            z1 = torch.randn((1, 7583), device=g)
+            z2 = torch.randn((30, 1), device=g)
+            e1 = torch.randn(x.shape[0], 20, device=g)
+            e2 = torch.randn(x.shape[0], 20, device=g)
+            out = ops.multiswag(x, wa, w2, pd, idx, z1, z2.reshape(1, -1).contiguous(), torch.stack((e1, e2), 1)[None].contiguous())[0]
+            return out, ops.swag_draw(wa, w2, pd, idx, z1, z2.reshape(1, -1).contiguous())[0], torch.randn(3, device=g)
+        for x, seed in ((x32, 11), (x32, 12), (x32[:15].contiguous(), 13), (x32, 14)):
+            want, w_want, next_want = reference_order(x, seed)
+            torch.manual_seed(seed)
+            got = m.forward_swag_fast(x, scale=0.5)
+            nxt = torch.randn(3, device=g)                      # the generator stands where the reference's would
+            assert got.is_cuda and torch.equal(got, want) and torch.equal(nxt, next_want), seed
+            assert torch.equal(m.flatten().to(g), w_want), seed  # :838, re-drawn lazily from the call's own normals
+        s2 = torch.cuda.Stream()
+        s2.wait_stream(torch.cuda.current_stream())
+        want, _, _ = reference_order(x32, 15)
+        with torch.cuda.stream(s2):
+            torch.manual_seed(15)
+            got = m.forward_swag_fast(x32, scale=0.5)
+        s2.synchronize()
+        assert torch.equal(got, want)
+        # a second model has buffers of its own: its call does not touch what the first one "has loaded"
+        m2 = models[12]
+        m2.cuda()
+        torch.manual_seed(16)
+        m.forward_swag_fast(x32, scale=0.5)
+        _, w_want, _ = reference_order(x32, 16)
+        torch.manual_seed(17)
+        m2.forward_swag_fast(x32, scale=0.5)
+        assert torch.equal(m.flatten().to(g), w_want)
+        m2.cpu()
+    finally:
+        m.cpu()
+
+
 def test_data_setup_kernel_drop_in():
     from bnn_chaos_model_amd import regression
     z = load_golden("case_features.npz")
