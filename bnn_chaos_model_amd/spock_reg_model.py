@@ -297,6 +297,7 @@ class VarModel:
         (forward(noisy_val=True): an x-sized eps_in) and weights.  `_cur_summary` / `latents` read None afterwards, until the next call."""
         self._last_forward = self._last_latents_args = None
         self._cur_summary_cache = self._latents_cache = None
+        self.__dict__.pop("_noise_bufs", None)   # (the GPU-resident route's per-(stream, batch size) noise buffers)
         return self
 
     # ---- nn.Module-like conveniences used by the evaluation scripts --------------------------------------------
@@ -707,14 +708,15 @@ class SWAGModel(VarModel):
                     # of this model on this stream overwrites them in stream order, behind the kernel that read them; the weights the
                     # module "has loaded" (:838) are re-drawn lazily from them, and are the LAST call's, as in the reference.
                     st = _N.stream_ptr(g.index)
-                    nb = self.__dict__.get("_noise_bufs")
-                    if nb is None or nb[0] != (g, st, B):
+                    bufs = self.__dict__.setdefault("_noise_bufs", {})
+                    nb = bufs.get((g, st, B))
+                    if nb is None:
+                        if len(bufs) >= 4:      # (a ragged last chunk alternates two batch sizes: both stay; an unbounded series does not pile up)
+                            bufs.clear()
                         eps = torch.empty((1, B, 2, L_), dtype=torch.float32, device=g)
-                        nb = ((g, st, B), torch.empty((1, d_), dtype=torch.float32, device=g), torch.empty((self.K, 1), dtype=torch.float32, device=g),
-                              eps, eps[0, :, 0], eps[0, :, 1])
-                        nb = nb + (nb[2].view(1, self.K),)
-                        self.__dict__["_noise_bufs"] = nb
-                    _, z1g, z2, eps, ev0, ev1, z2g = nb
+                        z2 = torch.empty((self.K, 1), dtype=torch.float32, device=g)
+                        nb = bufs[(g, st, B)] = (torch.empty((1, d_), dtype=torch.float32, device=g), z2, eps, eps[0, :, 0], eps[0, :, 1], z2.view(1, self.K))
+                    z1g, z2, eps, ev0, ev1, z2g = nb
                     torch.randn((1, d_), out=z1g)                             # :830
                     torch.randn((self.K, 1), out=z2)                          # :831
                     ev0.normal_()                                             # :426  randn_like([B, latent])
