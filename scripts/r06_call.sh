@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round-6 GPU call runner: each step under its own timeout, logs under gpurun_out/; a step that fails an assertion does not stop the
 # call, a step that is KILLED (timeout: 124 / 137) does -- nothing further touches the GPU after that.
-#   scripts/r06_call.sh <step> [<step> ...]      steps: scale probe edges budget gputests bench
+#   scripts/r06_call.sh <step> [<step> ...]      steps: scale micro nodes trace smalltiming cprofile smoke surface edges budget gputests bench
+#   (abheadline / abnoisy need the variant libraries built first: `python -m bnn_chaos_model_amd.csrc.build -DBNN_NIN16=1 -o libbnn_nin16.so`;
+#    libbnn_r05.so = the round-5 library, built from a worktree of commit 6de3a5d)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R" || exit 1
