@@ -89,27 +89,34 @@ def x_block(member, b0=0, nb=SYSTEMS):
     return x
 
 
-def draw_noise(member, draw, nb=SYSTEMS, dtype=np.float32):
+def draw_noise(member, draw, nb=SYSTEMS, dtype=np.float32, d=D, k=K, latent=LATENT):
     """What sample_weights + compute_summary_stats consume in one forward_swag_fast call:
-    z1 [1, D], z2 [K, 1], eps1 [nb, LATENT], eps2 [nb, LATENT]."""
+    z1 [1, d], z2 [k, 1], eps1 [nb, latent], eps2 [nb, latent].  (d, k, latent: the network's; the defaults are the pretrained ensemble's.
+    Strides of the counters use the LARGEST sizes any fixture asks for, so streams of different networks never overlap within a member.)"""
     j = member * DRAWS + draw
-    z1 = normal12(S_Z1, j * D + np.arange(D, dtype=np.int64), dtype)[None, :]
-    z2 = normal12(S_Z2, j * K + np.arange(K, dtype=np.int64), dtype)[:, None]
+    DS, KS, LS = max(d, 65536), max(k, 64), max(latent, 128)
+    if (d, k, latent) == (D, K, LATENT):
+        DS, KS, LS = D, K, LATENT          # (the pretrained fixture's counters, as generated in round 6)
+    z1 = normal12(S_Z1, j * DS + np.arange(d, dtype=np.int64), dtype)[None, :]
+    z2 = normal12(S_Z2, j * KS + np.arange(k, dtype=np.int64), dtype)[:, None]
     b = np.arange(nb, dtype=np.int64)[:, None]
-    l = np.arange(LATENT, dtype=np.int64)[None, :]
-    e = [normal12(S_EPS, ((j * SYSTEMS + b) * 2 + kind) * LATENT + l, dtype) for kind in (0, 1)]
+    l = np.arange(latent, dtype=np.int64)[None, :]
+    e = [normal12(S_EPS, ((j * SYSTEMS + b) * 2 + kind) * LS + l, dtype) for kind in (0, 1)]
     return z1, z2, e[0], e[1]
 
 
-def noisy_noise(member, nb=NOISY_SYSTEMS, dtype=np.float32):
-    """What VarModel.forward(noisy_val=True) consumes: randn_like(x) [nb,T,F], eps1, eps2 [nb,LATENT], randn_like(summary) [nb,2*LATENT]."""
+def noisy_noise(member, nb=NOISY_SYSTEMS, dtype=np.float32, latent=LATENT, summary=None):
+    """What VarModel.forward(noisy_val=True) consumes: randn_like(x) [nb,T,F], eps1, eps2 [nb,latent], randn_like(summary) [nb,summary]
+    (summary = 2 * latent, + 2 with fix_megno)."""
+    summary = 2 * latent if summary is None else summary
+    LS = LATENT if (latent, summary) == (LATENT, 2 * LATENT) else 128
     b = np.arange(nb, dtype=np.int64)
     e_in = normal12(S_EPS_IN, ((member * SYSTEMS + b)[:, None, None] * T + np.arange(T, dtype=np.int64)[None, :, None]) * F
                     + np.arange(F, dtype=np.int64)[None, None, :], dtype)
-    l = np.arange(LATENT, dtype=np.int64)[None, :]
-    e = [normal12(S_EPS_NOISY, ((member * SYSTEMS + b[:, None]) * 2 + kind) * LATENT + l, dtype) for kind in (0, 1)]
-    s = np.arange(2 * LATENT, dtype=np.int64)[None, :]
-    e_sum = normal12(S_EPS_SUM, (member * SYSTEMS + b[:, None]) * 2 * LATENT + s, dtype)
+    l = np.arange(latent, dtype=np.int64)[None, :]
+    e = [normal12(S_EPS_NOISY, ((member * SYSTEMS + b[:, None]) * 2 + kind) * LS + l, dtype) for kind in (0, 1)]
+    s = np.arange(summary, dtype=np.int64)[None, :]
+    e_sum = normal12(S_EPS_SUM, (member * SYSTEMS + b[:, None]) * 2 * LS + s, dtype)
     return e_in, e[0], e[1], e_sum
 
 

@@ -190,3 +190,106 @@ def test_module_surface_replays_the_reference_at_scale(case, tmp_path):
     assert torch.equal(out, direct)
     s = rel_stats(out.cpu().numpy(), case["out32"][m, 1])
     assert max(s["mu"]["max"], s["std"]["max"]) <= ENVELOPE["max_between_fp32"], s
+
+
+# ---------------------------------------------------------------------------------------- other hparams-built networks, at scale
+ARCH_NAMES = ("h64l16", "h20l10", "h33l7", "deep22", "deep30", "lin00", "k40", "h48megno", "allcols", "lin0out8")
+
+
+def _arch_hparams(z):
+    hp = json.loads(str(z["hparams_json"]))
+    for k, v in list(hp.items()):
+        if isinstance(v, str) and v in ("True", "False"):
+            hp[k] = v == "True"
+    return hp
+
+
+def _arch_kw(z):
+    hp = _arch_hparams(z)
+    flags = (hp.get("fix_megno", False), hp.get("fix_megno2", False), hp["include_mmr"], hp["include_nan"], hp.get("include_eplusminus", True))
+    lowest = 0.1 if hp.get("lower_std", False) else 0.5
+    net = dict(n_features=int(z["n_features"]), hidden=hp["hidden"], latent=hp["latent"], depth_in=hp["in"], depth_out=hp["out"])
+    return flags, lowest, bool(hp.get("fix_megno", False)), net, int(json.loads(str(z["swa_params_json"]))["K"])
+
+
+def test_oracle_against_the_reference_at_scale_other_networks():
+    """case_scale_arch.npz (make_golden_scale_arch.py): the unmodified reference class built with OTHER hparams -- widths, depths, masks,
+    K = 40, fix_megno: ten networks -- on 2 048 recipe systems each.  The oracle (natural order) on the first 256 of each vs the
+    reference's outputs; its float64 build vs the reference's float64 run."""
+    from oracle import oracle as orc
+    zs = load_golden("case_scale_arch.npz")
+    assert tuple(str(n) for n in zs["names"]) == ARCH_NAMES
+    nb = 256
+    worst32 = worst64 = 0.0
+    nbad = 0
+    for k, name in enumerate(ARCH_NAMES):
+        z = load_golden(f"case_arch_{name}.npz")
+        flags, lowest, megno, net, K = _arch_kw(z)
+        mask = orc.zero_mask_from_flags(*flags)
+        arch = orc.make_arch(T=100, zero_mask=mask, lowest=lowest, fix_megno=megno, **net)
+        d, L = int(z["w_avg"].size), net["latent"]
+        blk = int(zs["block0"]) + k
+        x = R.x_block(blk, 0, nb)
+        z1, z2, e1, e2 = R.draw_noise(blk, 0, nb, d=d, k=K, latent=L)
+        ref = zs[f"{name}_fast32"][:nb]
+        truth = ref.astype(np.float64) + zs[f"{name}_fast_truth_delta"][:nb]
+        for dt in (np.float32, np.float64):
+            w = orc.swag_draw(z["w_avg"], z["w2_avg"], z["pre_D"], z1, z2, scale=0.5, dtype=dt)
+            got = orc.forward(x, w, e1, e2, arch=arch, dtype=dt)
+            s = rel_stats(got, ref if dt == np.float32 else truth)
+            if dt == np.float32:
+                worst32 = max(worst32, s["mu"]["max"], s["std"]["max"])
+                nbad += s["mu"]["beyond_1e-5"] + s["std"]["beyond_1e-5"]
+            else:
+                worst64 = max(worst64, s["mu"]["max"], s["std"]["max"])
+    assert worst64 < 1e-9, worst64
+    assert nbad == 0 and worst32 < 1e-5, (nbad, worst32)
+
+
+@pytest.mark.gpu
+def test_hip_against_the_reference_at_scale_other_networks():
+    """The generic engine (ahead-of-time forms, and the pretrained shapes' own kernels for K = 40) on the ten other networks of
+    case_scale_arch.npz: 2 048 systems through forward_swag_fast and 512 through the noisy forward each, against the reference's outputs
+    -- no exceedance of 1e-5 -- and against its float64 run (no farther from the truth than the reference, as distributions).  Table:
+    gpurun_out/r06_scale_parity_arch.json (judged copy: profiles/)."""
+    import torch
+    from bnn_chaos_model_amd import ops
+    zs = load_golden("case_scale_arch.npz")
+    S, NB = int(zs["systems"]), int(zs["noisy_systems"])
+    table = {}
+    tot_bad = 0
+    import warnings
+    for k, name in enumerate(ARCH_NAMES):
+        z = load_golden(f"case_arch_{name}.npz")
+        flags, lowest, megno, net, K = _arch_kw(z)
+        plan = ops.get_plan(ops.zero_mask_from_flags(*flags), lowest, fix_megno=megno, **net)
+        d, L = int(z["w_avg"].size), net["latent"]
+        SM = 2 * L + (2 if megno else 0)
+        blk = int(zs["block0"]) + k
+        x = _dev(R.x_block(blk, 0, S))
+        wa, w2, pd = _dev(z["w_avg"][None]), _dev(z["w2_avg"][None]), _dev(z["pre_D"][None])
+        z1, z2, e1, e2 = R.draw_noise(blk, 0, S, d=d, k=K, latent=L)
+        idx = torch.zeros(1, dtype=torch.int32)
+        hip = ops.multiswag(x, wa, w2, pd, idx, _dev(z1), _dev(z2[:, 0][None]), _dev(np.stack([e1, e2], 1)[None]), scale=0.5, plan=plan)[0].cpu().numpy()
+        e_in, n1, n2, e_sum = R.noisy_noise(blk, NB, latent=L, summary=SM)
+        hipn = ops.forward(x[:NB], wa, eps=_dev(np.stack([n1, n2], 1)[None]), eps_in=_dev(e_in[None]), eps_sum=_dev(e_sum[None]), plan=plan)[0].cpu().numpy()
+        row = {}
+        for leg, got in (("fast", hip), ("noisy", hipn)):
+            ref = zs[f"{name}_{leg}32"]
+            truth = ref.astype(np.float64) + zs[f"{name}_{leg}_truth_delta"]
+            row[leg] = {"hip_vs_reference": rel_stats(got, ref), "reference_vs_truth": rel_stats(ref, truth), "hip_vs_truth": rel_stats(got, truth),
+                        "bit_identical": int((got == ref).sum())}
+            for kk in ("mu", "std"):
+                tot_bad += row[leg]["hip_vs_reference"][kk]["beyond_1e-5"]
+                assert row[leg]["hip_vs_reference"][kk]["max"] <= 1e-5, (name, leg, kk, row[leg]["hip_vs_reference"][kk])
+                assert row[leg]["hip_vs_truth"][kk]["max"] <= max(2.5e-5, 2.0 * row[leg]["reference_vs_truth"][kk]["max"]), (name, leg, kk)
+        table[name] = row
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "r06_scale_parity_arch.json"), "w") as f:
+            json.dump(table, f, indent=1)
+    except OSError:
+        pass
+    print(json.dumps({n: {leg: {"max_vs_ref": max(t[leg]["hip_vs_reference"][q]["max"] for q in ("mu", "std")), "bit_identical": t[leg]["bit_identical"]}
+                          for leg in t} for n, t in table.items()}, indent=1))
+    assert tot_bad == 0
