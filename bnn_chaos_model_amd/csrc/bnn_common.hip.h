@@ -316,7 +316,28 @@ DEVINL f32x4 regress16(const float (&skeep)[Lay<MEGNO>::NK4], const float* f2fra
 // Callers bracket the two phases with workgroup barriers (stage -> barrier -> compute -> barrier), once per chunk of columns.
 // ------------------------------------------------------------------------------------------------
 DEVINL void draw_stage(const float* __restrict__ pre_D_s, int i0, int d, int K, int kc, int Kc, int lane, float* slab) {
-    // columns [kc, kc + Kc) of rows [i0, i0 + 64): slab[r * Kc + c].  With kc = 0, Kc = K (every K <= 32) this is one contiguous run.
+    // columns [kc, kc + Kc) of rows [i0, i0 + 64): slab[r * Kc + c].  With kc = 0, Kc = K (every K <= 32) this is one contiguous run:
+    // a plain copy, eight loads in flight per lane (the general loop below divides by Kc and waits for every load: 30 memory round trips in
+    // a row, 15 us for ONE draw -- nothing next to a configs[2] step, a quarter of a 3 000-row call of the evaluation scripts).
+    if (kc == 0 && Kc == K) {
+        const int rows = d - i0 < 64 ? d - i0 : 64;
+        const int total = rows * K;
+        const float* src = pre_D_s + (int64_t)i0 * K;
+        for (int n0 = 0; n0 < K; n0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = (n0 + u) * 64 + lane;
+                v[u] = (n0 + u < K && idx < total) ? src[idx] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = (n0 + u) * 64 + lane;
+                if (n0 + u < K && idx < total) slab[idx] = v[u];
+            }
+        }
+        return;
+    }
     for (int n = 0; n < Kc; ++n) {
         const int idx = n * 64 + lane, r = idx / Kc, c = idx - r * Kc;
         if (i0 + r < d) slab[idx] = pre_D_s[(int64_t)(i0 + r) * K + kc + c];

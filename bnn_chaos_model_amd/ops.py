@@ -402,10 +402,12 @@ def multiswag(x, w_avg, w2_avg, pre_D, seed_idx, z1=None, z2=None, eps=None, nch
             raise NotImplementedError("single_launch (in-prologue draw) exists for the pretrained network at T % 4 == 0, K <= 32 only")
         single_launch = False
     if single_launch is None:
-        # few systems per draw: every workgroup samples its draw in its prologue (no workspace, no draw launch).  That includes the small
-        # grids of the tile-split form -- e.g. the 3 000-row batches of figures/main_figures.py:154-156 under ONE draw: 188 prologue draws
-        # side by side cost less than a draw launch in front of the forward.
-        single_launch = -(-(chunk_B or B) // max(nchunks, 1)) <= 256 or small
+        # Few systems per draw: every workgroup samples its draw in its prologue (no workspace, no draw launch).  In the tile-split form of
+        # the small grids a draw shared by MANY workgroups is cheaper drawn once: 188 prologue draws side by side (a 3 000-row batch of
+        # figures/main_figures.py:154-156) re-read the member's 0.9 MB through L2 and cost the kernel 17 us against 12 for one, a draw
+        # launch in front of it 5 (scripts/dev/small_forward_timing.py: 48 against 58 us for the pair).
+        csz = -(-(chunk_B or B) // max(nchunks, 1))
+        single_launch = (-(-min(csz, B) // 16) <= 8) if small else csz <= 256
     ws = None if single_launch else _workspace(J, d, x.device)
     # (x, the ensemble, the noise tensors and out were checked above -- float32, contiguous, on x's device: their addresses as they are)
     dp = lambda t: None if t is None else t.data_ptr()

@@ -40,6 +40,11 @@ for B in (15, 3000):
         x = bench.synthetic_x(B, torch.device("cuda"), 1)[:, :T].contiguous()
         out = torch.empty((1, B, 2), device="cuda")
         row = {"B": B, "T": T, "rounds": (T // 4 + 3) // 4}
+        row["draw_kernel_us"] = per_launch(lambda: ops.swag_draw(wa, w2, pd, idx, philox_seed=1))
+        zz1, zz2 = torch.randn(1, 7583, device="cuda"), torch.randn(1, 30, device="cuda")
+        row["draw_kernel_explicit_z_us"] = per_launch(lambda: ops.swag_draw(wa, w2, pd, idx, zz1, zz2))
+        row["workspace_small_us"] = per_launch(lambda: ops.multiswag(x, wa, w2, pd, idx, zz1, zz2, philox_seed=3, assume_finite=True, single_launch=False, out=out))
+        row["fused_small_explicit_z_us"] = per_launch(lambda: ops.multiswag(x, wa, w2, pd, idx, zz1, zz2, philox_seed=3, assume_finite=True, single_launch=True, out=out))
         row["forward_small_us"] = per_launch(lambda: ops.forward(x, W, philox_seed=3, assume_finite=True))
         row["forward_plain_us"] = per_launch(lambda: ops.forward(x, W, philox_seed=3, assume_finite=True, systems_per_block=64))
         row["fused_small_us"] = per_launch(lambda: ops.multiswag(x, wa, w2, pd, idx, philox_seed=3, assume_finite=True, single_launch=True, out=out))
