@@ -319,10 +319,12 @@ static int launch_forward(const bnn_plan* pl, const bnn_grid* g, FwdParams& p, b
     p.spc = pick_spc(g, cseg, p.xcd_order != 0);
     // Small grids (the evaluation scripts' per-chunk calls: 15 .. 3 000 rows under one draw) take the TILE-SPLIT form of the pretrained
     // network's kernel: 16 systems per workgroup, the four waves sharing a batch's tiles (bnn_forward.hip.h, TSPLIT) -- same bits, a
-    // quarter of the time per batch -- as long as every workgroup is resident at once (one per CU: 93 KB of LDS).  An explicit
+    // quarter of the time per batch -- as long as every workgroup is resident at once (one per CU: 93 KB of LDS), ...  An explicit
     // systems_per_block keeps the plain form (that is also how the tests compare the two).
+    // ... or a draw never covers more than 16 systems (the 5-planet loop as ONE call: 15-row chunks under thousands of draws -- in the
+    // plain form three of a workgroup's four waves would have no system at all).
     const bool tsplit = !generic && !lowp && !noisy && !p.sink && !pl->megno && pl->tab[0].kin4 == 31 && g->systems_per_block == 0 &&
-                        ((cseg + 15) / 16) * (int64_t)g->J <= TSPLIT_MAX_BLOCKS;
+                        (((cseg + 15) / 16) * (int64_t)g->J <= TSPLIT_MAX_BLOCKS || cseg <= 16);
     if (tsplit) p.spc = 16;
     p.row_id0 = p.draw_id0 / g->nchunks;
     p.tab_f2 = pl->d_f2; p.tab_wr = noisy ? pl->d_f4n : pl->d_f4; p.rcp_tab = pl->d_rcp;

@@ -113,12 +113,13 @@ def _grid(B, T, J, nchunks, spb, noisy=False, engine="auto", chunk_B=0, chunk_of
 def small_grid(plan, B, T, J, nchunks=1, chunk_B=0, systems_per_block=0, engine="auto"):
     """True where the library runs the pretrained network's kernel in its TILE-SPLIT form (bnn_abi.hip: launch_forward, TSPLIT_MAX_BLOCKS):
     the v50 mask, whole 4-step tiles, no explicit block size, and at most 256 blocks of 16 systems in the whole grid -- the evaluation
-    scripts' per-chunk calls (15 .. 3 000 rows under one draw)."""
+    scripts' per-chunk calls (15 .. 3 000 rows under one draw) -- or draws that cover at most 16 systems each, however many (the 5-planet
+    loop as one call)."""
     if not (plan.v50net and not plan.fix_megno and plan.arch.zero_mask == V50_ZERO_MASK and T % 4 == 0 and T >= 8 and systems_per_block == 0
             and engine == "auto" and B > 0 and J > 0):
         return False
     csz = -(-(chunk_B or B) // max(nchunks, 1))
-    return -(-min(csz, B) // 16) * J <= 256
+    return -(-min(csz, B) // 16) * J <= 256 or min(csz, B) <= 16
 
 
 def _scan_st(x, plan, assume_finite, nonfinite):

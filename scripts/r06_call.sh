@@ -31,9 +31,11 @@ for s in "$@"; do
              (cd /tmp && export TMPDIR=/tmp && cd "$R" && step trace_small 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r06_trace_small -- python3 scripts/dev/small_call_trace.py)
              f=$(find gpurun_out/r06_trace_small -name "*kernel_trace.csv" | head -1)
              [ -n "$f" ] && python scripts/dev/trace_gaps.py "$f" | tee gpurun_out/r06_trace_gaps_${TAG:-x}.txt ;;
+    manychunks) step many_chunks 400 python scripts/dev/many_small_chunks_timing.py ;;
     smalltiming) step small_timing 300 python scripts/dev/small_forward_timing.py ;;
     abheadline) step ab_headline 900 python scripts/ab_variants.py --workload c3 --reps 3 --steps 4 libbnn_r05.so libbnn_chaos_hip.so ;;
     cprofile) TAILN=60 step cprofile 300 python scripts/dev/dropin_cprofile.py ;;
+    example) step example 600 python examples/five_planet_pipeline.py ;;
     smoke)   step smoke 600 python __graft_entry__.py --smoke ;;
     abnoisy) step ab_noisy 900 python scripts/ab_variants.py --workload noisy --reps 3 --steps 6 libbnn_chaos_hip.so libbnn_nin16.so ;;
     surface) step surface 900 python -m pytest tests/test_surface_gpu.py tests/test_scale_parity.py -x -q -m gpu ;;
