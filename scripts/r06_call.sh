@@ -31,6 +31,8 @@ for s in "$@"; do
              (cd /tmp && export TMPDIR=/tmp && cd "$R" && step trace_small 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r06_trace_small -- python3 scripts/dev/small_call_trace.py)
              f=$(find gpurun_out/r06_trace_small -name "*kernel_trace.csv" | head -1)
              [ -n "$f" ] && python scripts/dev/trace_gaps.py "$f" | tee gpurun_out/r06_trace_gaps_${TAG:-x}.txt ;;
+    smallkernels) TAILN=14 step small_kernels 400 python scripts/small_kernels_r05.py ;;
+    stats)   step stats_tests 600 python -m pytest tests/test_stats_stream.py tests/test_hip_parity.py -x -q -m gpu ;;
     manychunks) step many_chunks 400 python scripts/dev/many_small_chunks_timing.py ;;
     smalltiming) step small_timing 300 python scripts/dev/small_forward_timing.py ;;
     abheadline) step ab_headline 900 python scripts/ab_variants.py --workload c3 --reps 3 --steps 4 libbnn_r05.so libbnn_chaos_hip.so ;;
