@@ -134,7 +134,10 @@ typedef struct bnn_grid {
                         chunk size ceil(B/nchunks)) and writes output row e / nchunks.
                         1 = every draw covers all systems (dense systems x draws grid).
                         figures/multiswag_5_planet.py:295-298 is nchunks = 10.                     */
-    int32_t systems_per_block; /* 0 = choose; else a multiple of 64                                */
+    int32_t systems_per_block; /* 0 = choose; else a multiple of 64.  With 0 the pretrained network's quiet forward takes a
+                        TILE-SPLIT launch form on small grids (at most 256 blocks of 16 systems, or draws that cover at most 16
+                        systems each: the evaluation scripts' per-chunk calls, figures/multiswag_5_planet.py:295-298): 16 systems per
+                        workgroup, its four waves sharing a batch's tiles -- bit-identical outputs; an explicit value keeps the plain form */
     int32_t noisy;   /* bnn_forward_f32 only: 1 = forward(noisy_val=True) with ALL noise generated in-kernel
                         (eps, eps_in, eps_sum all NULL); explicit eps_in/eps_sum imply noisy regardless          */
     int32_t engine;  /* 0 = choose (the pretrained network at T % 4 == 0, T >= 8: its register-resident kernels; else the generic engine,
